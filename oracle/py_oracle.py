@@ -1,0 +1,407 @@
+"""CPU oracle, Python side.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product path (stark-anatomy_amd/) never does.
+
+Two things live here:
+  * `C` -- a ctypes view of oracle/libstark_oracle.so (stark_oracle.c), used for sizes where pure
+    Python is too slow;
+  * pure-Python restatements, on plain ints mod p, of the reference functions on the hot path
+    (code/ntt.py, code/fri.py:85, code/merkle.py), each citing the reference lines it follows.
+    These are what bench.py times as the "pure-Python CPU path" baseline (kind = "port").
+
+Parity pin: tests/test_oracle.py checks every function against tests/golden/*.json, which
+tests/golden/make_golden.py produced by importing the reference itself.
+"""
+import ctypes
+import os
+from hashlib import blake2b
+
+P = 1 + 407 * (1 << 119)                     # code/algebra.py:96-98
+GENERATOR = 85408008396924667383611388730472331217   # code/algebra.py:100-102
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- field (code/algebra.py)
+def inv(a):
+    """Field.inverse (algebra.py:87-89): xgcd inverse, inverse(0) == 0."""
+    return pow(a, P - 2, P)
+
+
+def primitive_nth_root(n):
+    """Field.primitive_nth_root (algebra.py:104-114)."""
+    assert n <= 1 << 119 and (n & (n - 1)) == 0
+    root, order = GENERATOR, 1 << 119
+    while order != n:
+        root = root * root % P
+        order >>= 1
+    return root
+
+
+def sample(byte_array):
+    """Field.sample (algebra.py:116-120)."""
+    acc = 0
+    for b in byte_array:
+        acc = (acc << 8) ^ int(b)
+    return acc % P
+
+
+# --------------------------------------------------------------------------- code/ntt.py
+def ntt(root, values):
+    """ntt.py:3-18 -- recursive even/odd split, one modular power per output element per level."""
+    n = len(values)
+    assert n & (n - 1) == 0, "cannot compute ntt of non-power-of-two sequence"
+    if n <= 1:
+        return values
+    assert pow(root, n, P) == 1, "primitive root must be nth root of unity, where n is len(values)"
+    assert pow(root, n // 2, P) != 1, "primitive root is not primitive nth root of unity, where n is len(values)"
+    half = n // 2
+    r2 = root * root % P
+    odds = ntt(r2, values[1::2])
+    evens = ntt(r2, values[::2])
+    return [(evens[i % half] + pow(root, i, P) * odds[i % half]) % P for i in range(n)]
+
+
+def intt(root, values):
+    """ntt.py:20-30."""
+    n = len(values)
+    assert n & (n - 1) == 0, "cannot compute intt of non-power-of-two sequence"
+    if n == 1:
+        return values
+    ninv = inv(n % P)
+    return [ninv * v % P for v in ntt(inv(root), values)]
+
+
+def degree(c):
+    """Polynomial.degree (univariate.py:7-17): index of last non-zero coefficient, -1 if none."""
+    d = -1
+    for i, x in enumerate(c):
+        if x != 0:
+            d = i
+    return d
+
+
+def schoolbook_mul(a, b):
+    """Polynomial.__mul__ (univariate.py:37-47)."""
+    if not a or not b:
+        return []
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        if x == 0:
+            continue
+        for j, y in enumerate(b):
+            out[i + j] = (out[i + j] + x * y) % P
+    return out
+
+
+def schoolbook_divmod(num, den):
+    """Polynomial.divide (univariate.py:80-97); returns (quotient, remainder) coefficient lists."""
+    dd = degree(den)
+    assert dd >= 0
+    if degree(num) < dd:
+        return [], list(num)
+    rem = list(num)
+    quo = [0] * (degree(num) - dd + 1)
+    lead_inv = inv(den[dd])
+    for _ in range(len(quo)):
+        dr = degree(rem)
+        if dr < dd:
+            break
+        c = rem[dr] * lead_inv % P
+        shift = dr - dd
+        quo[shift] = c
+        for j in range(dd + 1):
+            rem[shift + j] = (rem[shift + j] - c * den[j]) % P
+    return quo, rem
+
+
+def scale(c, factor):
+    """Polynomial.scale (univariate.py:153-154)."""
+    return [pow(factor, i, P) * x % P for i, x in enumerate(c)]
+
+
+def _shrink(root, order, deg):
+    while deg < order // 2:          # ntt.py:47-49 / :155-157
+        root = root * root % P
+        order //= 2
+    return root, order
+
+
+def fast_multiply(lhs, rhs, root, order):
+    """ntt.py:32-64 on coefficient lists."""
+    assert pow(root, order, P) == 1 and pow(root, order // 2, P) != 1
+    dl, dr = degree(lhs), degree(rhs)
+    if dl < 0 or dr < 0:
+        return []
+    deg = dl + dr
+    if deg < 8:
+        return schoolbook_mul(lhs, rhs)
+    root, order = _shrink(root, order, deg)
+    a = lhs[:dl + 1] + [0] * (order - dl - 1)
+    b = rhs[:dr + 1] + [0] * (order - dr - 1)
+    had = [x * y % P for x, y in zip(ntt(root, a), ntt(root, b))]
+    return intt(root, had)[:deg + 1]
+
+
+def fast_zerofier(domain, root, order):
+    """ntt.py:66-80."""
+    if len(domain) == 0:
+        return []
+    if len(domain) == 1:
+        return [(-domain[0]) % P, 1]
+    half = len(domain) // 2
+    return fast_multiply(fast_zerofier(domain[:half], root, order), fast_zerofier(domain[half:], root, order), root, order)
+
+
+def evaluate(c, x):
+    """Polynomial.evaluate (univariate.py:134-140)."""
+    acc, xi = 0, 1
+    for k in c:
+        acc = (acc + k * xi) % P
+        xi = xi * x % P
+    return acc
+
+
+def fast_evaluate(c, domain, root, order):
+    """ntt.py:82-100."""
+    if len(domain) == 0:
+        return []
+    if len(domain) == 1:
+        return [evaluate(c, domain[0])]
+    half = len(domain) // 2
+    lz = fast_zerofier(domain[:half], root, order)
+    rz = fast_zerofier(domain[half:], root, order)
+    return (fast_evaluate(schoolbook_divmod(c, lz)[1], domain[:half], root, order)
+            + fast_evaluate(schoolbook_divmod(c, rz)[1], domain[half:], root, order))
+
+
+def poly_add(a, b):
+    """Polynomial.__add__ (univariate.py:22-32): a zero operand returns the other one unchanged."""
+    if degree(a) == -1:
+        return b
+    if degree(b) == -1:
+        return a
+    out = [0] * max(len(a), len(b))
+    for i, x in enumerate(a):
+        out[i] = x
+    for i, x in enumerate(b):
+        out[i] = (out[i] + x) % P
+    return out
+
+
+def fast_interpolate(domain, values, root, order):
+    """ntt.py:102-130."""
+    assert len(domain) == len(values)
+    if len(domain) == 0:
+        return []
+    if len(domain) == 1:
+        return [values[0]]
+    half = len(domain) // 2
+    lz = fast_zerofier(domain[:half], root, order)
+    rz = fast_zerofier(domain[half:], root, order)
+    lo = fast_evaluate(rz, domain[:half], root, order)
+    ro = fast_evaluate(lz, domain[half:], root, order)
+    lt = [n * inv(d) % P for n, d in zip(values[:half], lo)]
+    rt = [n * inv(d) % P for n, d in zip(values[half:], ro)]
+    li = fast_interpolate(domain[:half], lt, root, order)
+    ri = fast_interpolate(domain[half:], rt, root, order)
+    return poly_add(schoolbook_mul(li, rz), schoolbook_mul(ri, lz))
+
+
+def fast_coset_evaluate(c, offset, generator, order):
+    """ntt.py:132-135 (pads by len(coefficients), not degree)."""
+    return ntt(generator, scale(c, offset) + [0] * (order - len(c)))
+
+
+def fast_coset_divide(lhs, rhs, offset, root, order):
+    """ntt.py:137-176 (clean division only)."""
+    assert degree(rhs) >= 0, "cannot divide by zero polynomial"
+    dl, dr = degree(lhs), degree(rhs)
+    if dl < 0:
+        return []
+    assert dr <= dl, "cannot divide by polynomial of larger degree"
+    deg = max(dl, dr)
+    if deg < 8:
+        q, r = schoolbook_divmod(lhs, rhs)
+        assert degree(r) == -1
+        return q
+    root, order = _shrink(root, order, deg)
+    a = scale(lhs, offset)[:dl + 1] + [0] * (order - dl - 1)
+    b = scale(rhs, offset)[:dr + 1] + [0] * (order - dr - 1)
+    ca, cb = ntt(root, a), ntt(root, b)
+    assert all(x != 0 for x in cb), "divide by zero"
+    quo = intt(root, [x * inv(y) % P for x, y in zip(ca, cb)])[:dl - dr + 1]
+    return scale(quo, inv(offset))
+
+
+# --------------------------------------------------------------------------- code/fri.py:85
+def fold(codeword, alpha, offset, omega):
+    """fri.py:85 literally: per output one inverse of two and two field divisions."""
+    N = len(codeword)
+    out = []
+    for i in range(N // 2):
+        x = offset * pow(omega, i, P) % P
+        t = alpha * inv(x) % P
+        out.append(inv(2) * ((1 + t) * codeword[i] + (1 - t) * codeword[N // 2 + i]) % P)
+    return out
+
+
+# --------------------------------------------------------------------------- code/merkle.py
+def leaf_bytes(v):
+    """bytes(FieldElement) (algebra.py:53-57)."""
+    return str(v).encode()
+
+
+def merkle_commit(values):
+    """Merkle.commit (merkle.py:6-14), iterative over levels."""
+    level = [blake2b(leaf_bytes(v)).digest() for v in values]
+    assert len(level) & (len(level) - 1) == 0, "length must be power of two"
+    while len(level) > 1:
+        level = [blake2b(level[i] + level[i + 1]).digest() for i in range(0, len(level), 2)]
+    return level[0]
+
+
+def merkle_open(index, values):
+    """Merkle.open (merkle.py:16-27): siblings bottom-up."""
+    level = [blake2b(leaf_bytes(v)).digest() for v in values]
+    assert 0 <= index < len(level)
+    path = []
+    while len(level) > 1:
+        path.append(level[index ^ 1])
+        level = [blake2b(level[i] + level[i + 1]).digest() for i in range(0, len(level), 2)]
+        index >>= 1
+    return path
+
+
+# --------------------------------------------------------------------------- C oracle binding
+class _C:
+    """Lazy ctypes view of libstark_oracle.so; build with `make -C oracle`."""
+
+    def __init__(self):
+        self._lib = None
+
+    @property
+    def lib(self):
+        if self._lib is None:
+            path = os.path.join(_HERE, "libstark_oracle.so")
+            if not os.path.exists(path):
+                raise RuntimeError("oracle/libstark_oracle.so missing -- run `make -C oracle` (or __graft_entry__.build())")
+            lib = ctypes.CDLL(path)
+            vp, u64, sz = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t
+            sigs = {
+                "so_add": (None, [vp, vp, vp]), "so_sub": (None, [vp, vp, vp]), "so_mul": (None, [vp, vp, vp]),
+                "so_inv": (None, [vp, vp]), "so_pow": (None, [vp, vp, vp]),
+                "so_synth": (None, [u64, u64, u64, vp]),
+                "so_ntt": (ctypes.c_int, [vp, vp, vp, u64]), "so_intt": (ctypes.c_int, [vp, vp, vp, u64]),
+                "so_scale": (None, [vp, u64, vp, vp]),
+                "so_coset_evaluate": (ctypes.c_int, [vp, u64, vp, vp, u64, vp]),
+                "so_pointwise_mul": (None, [vp, vp, u64, vp]), "so_pointwise_div": (ctypes.c_int, [vp, vp, u64, vp]),
+                "so_fold": (ctypes.c_int, [vp, u64, vp, vp, vp, vp]),
+                "so_blake2b": (None, [vp, sz, vp]), "so_leaf_bytes": (sz, [vp, vp]),
+                "so_merkle_tree": (ctypes.c_int, [vp, u64, vp]),
+                "so_merkle_commit": (ctypes.c_int, [vp, u64, vp]), "so_merkle_open": (ctypes.c_int, [vp, u64, u64, vp]),
+            }
+            for name, (res, args) in sigs.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            self._lib = lib
+        return self._lib
+
+    # -- helpers on packed buffers (bytes of 16-byte little-endian elements) --
+    @staticmethod
+    def _fe(v):
+        return int(v).to_bytes(16, "little")
+
+    def _unary_vec(self, fname, root, data, n):
+        out = ctypes.create_string_buffer(16 * n if n else 16)
+        rc = getattr(self.lib, fname)(self._fe(root), bytes(data), out, n)
+        if rc:
+            raise AssertionError("%s failed rc=%d" % (fname, rc))
+        return out.raw[:16 * n]
+
+    def ntt(self, root, data, n):
+        return self._unary_vec("so_ntt", root, data, n)
+
+    def intt(self, root, data, n):
+        return self._unary_vec("so_intt", root, data, n)
+
+    def synth(self, seed, n, start=0):
+        out = ctypes.create_string_buffer(16 * n if n else 16)
+        self.lib.so_synth(seed, start, n, out)
+        return out.raw[:16 * n]
+
+    def scale(self, data, n, factor):
+        out = ctypes.create_string_buffer(16 * n if n else 16)
+        self.lib.so_scale(bytes(data), n, self._fe(factor), out)
+        return out.raw[:16 * n]
+
+    def coset_evaluate(self, coeffs, m, offset, generator, order):
+        out = ctypes.create_string_buffer(16 * order)
+        rc = self.lib.so_coset_evaluate(bytes(coeffs), m, self._fe(offset), self._fe(generator), order, out)
+        if rc:
+            raise AssertionError("so_coset_evaluate rc=%d" % rc)
+        return out.raw
+
+    def pointwise_mul(self, a, b, n):
+        out = ctypes.create_string_buffer(16 * n)
+        self.lib.so_pointwise_mul(bytes(a), bytes(b), n, out)
+        return out.raw
+
+    def pointwise_div(self, a, b, n):
+        out = ctypes.create_string_buffer(16 * n)
+        rc = self.lib.so_pointwise_div(bytes(a), bytes(b), n, out)
+        if rc:
+            raise AssertionError("divide by zero")
+        return out.raw
+
+    def fold(self, data, N, alpha, offset, omega):
+        out = ctypes.create_string_buffer(8 * N)
+        rc = self.lib.so_fold(bytes(data), N, self._fe(alpha), self._fe(offset), self._fe(omega), out)
+        if rc:
+            raise AssertionError("so_fold rc=%d" % rc)
+        return out.raw
+
+    def blake2b(self, msg):
+        out = ctypes.create_string_buffer(64)
+        self.lib.so_blake2b(bytes(msg), len(msg), out)
+        return out.raw
+
+    def leaf_bytes(self, v):
+        buf = ctypes.create_string_buffer(40)
+        k = self.lib.so_leaf_bytes(self._fe(v), buf)
+        return buf.raw[:k]
+
+    def merkle_tree(self, data, N):
+        out = ctypes.create_string_buffer(64 * (2 * N - 1))
+        rc = self.lib.so_merkle_tree(bytes(data), N, out)
+        if rc:
+            raise AssertionError("length must be power of two")
+        return out.raw
+
+    def merkle_commit(self, data, N):
+        out = ctypes.create_string_buffer(64)
+        rc = self.lib.so_merkle_commit(bytes(data), N, out)
+        if rc:
+            raise AssertionError("length must be power of two")
+        return out.raw
+
+    def merkle_open(self, data, N, index):
+        k = N.bit_length() - 1
+        out = ctypes.create_string_buffer(64 * max(k, 1))
+        rc = self.lib.so_merkle_open(bytes(data), N, index, out)
+        if rc:
+            raise AssertionError("cannot open invalid index")
+        return [out.raw[64 * i:64 * (i + 1)] for i in range(k)]
+
+    def binop(self, name, a, b):
+        out = ctypes.create_string_buffer(16)
+        getattr(self.lib, "so_" + name)(self._fe(a), self._fe(b), out)
+        return int.from_bytes(out.raw, "little")
+
+    def inv(self, a):
+        out = ctypes.create_string_buffer(16)
+        self.lib.so_inv(self._fe(a), out)
+        return int.from_bytes(out.raw, "little")
+
+
+C = _C()
