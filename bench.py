@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- NTT field-elements/s on MI355X (BASELINE.json metric), one JSON line on stdout.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N = 1: workload = BASELINE configs[1]: forward + inverse 2^20-point NTT, data resident in HBM.
+       One step = one forward + one inverse transform;  value = 2 * n * K / elapsed  (field elements / s).
+N > 1: four-step NTT sharded over the ranks with one RCCL all-to-all (see stark-anatomy_amd/sharded.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "stark-anatomy_amd")
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_ELEMENT_PER_TRANSFORM = 32   # read once + write once, 16-byte elements
+
+
+def cpu_baseline(sample_log2n):
+    """Pure-Python port of the reference's recursive ntt/intt (oracle/py_oracle.py), 1 core, bounded sample."""
+    from oracle import py_oracle as po
+    import synth
+    n = 1 << sample_log2n
+    xs = synth.synth_ints(1, n)
+    root = po.primitive_nth_root(n)
+    sys.setrecursionlimit(10000)
+    t0 = time.perf_counter()
+    ys = po.ntt(root, xs)
+    zs = po.intt(root, ys)
+    dt = time.perf_counter() - t0
+    assert zs == xs
+    out = {"value": 2 * n / dt, "unit": "field-elements/s", "cores": 1, "kind": "port",
+           "sample": "pure-Python port of code/ntt.py ntt+intt at n=2^%d, %.1f s, host has %d cores" % (sample_log2n, dt, os.cpu_count())}
+    # second comparator: the C restatement (oracle/stark_oracle.c), 1 core, at the bench size class
+    try:
+        m = 1 << 18
+        data = synth.synth_packed(1, m).tobytes()
+        r2 = po.primitive_nth_root(m)
+        t0 = time.perf_counter()
+        y = po.C.ntt(r2, data, m)
+        po.C.intt(r2, y, m)
+        dtc = time.perf_counter() - t0
+        out["c_port"] = {"value": 2 * m / dtc, "unit": "field-elements/s", "cores": 1, "sample": "oracle/stark_oracle.c ntt+intt at n=2^18, %.2f s" % dtc}
+    except Exception as e:      # the C oracle is optional for the baseline
+        out["c_port"] = {"error": str(e)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--log2n", type=int, default=None, help="override the transform size")
+    ap.add_argument("--cpu-sample-log2n", type=int, default=14)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import numpy as np
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("STARKCORE_DEVICE", str(local_rank))
+    import starkcore as sc
+    import synth
+    sc.init(local_rank)
+    lib = sc.lib()
+
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from sharded import ShardedNtt
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    P = synth.P
+    GEN = 85408008396924667383611388730472331217
+
+    def nth_root(n):
+        r, order = GEN, 1 << 119
+        while order != n:
+            r, order = r * r % P, order >> 1
+        return r
+
+    stream = torch.cuda.current_stream()
+    sptr = ctypes_void(stream.cuda_stream)
+
+    if world == 1:
+        log2n = args.log2n or 20
+        n = 1 << log2n
+        root = sc.fe_bytes(nth_root(n))
+        host = synth.synth_packed(1, n)
+        x = torch.from_numpy(host.view(np.int64)).to(dev)
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+
+        def step():
+            sc._check(lib.sc_ntt_dev(x.data_ptr(), y.data_ptr(), n, root, 0, sptr))
+            sc._check(lib.sc_ntt_dev(y.data_ptr(), z.data_ptr(), n, root, 1, sptr))
+
+        launches_per_step = 2 * ntt_passes(log2n)
+        workload = "ntt_fwd_inv_2^%d_1gpu" % log2n
+        total_n = n
+        parallelism = "single"
+    else:
+        log2n = args.log2n or (20 + (world.bit_length() - 1) + 1)     # 2^21 per GPU: 8 GPUs -> 2^24
+        n = 1 << log2n
+        eng = ShardedNtt(log2n, nth_root(n), rank, world, dev)
+        x = eng.synthetic_input(seed=1)
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+
+        def step():
+            eng.forward(x, y)
+            eng.inverse(y, z)
+
+        launches_per_step = eng.launches_per_transform * 2
+        workload = "ntt_fwd_inv_2^%d_fourstep_%dgpu" % (log2n, world)
+        total_n = n
+        parallelism = "four-step, column-sharded, 1 all-to-all per transform"
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness guard inside the bench: the round trip must reproduce the input bit for bit
+    ok = bool(torch.equal(z, x))
+
+    if rank == 0:
+        value = 2.0 * total_n * args.steps / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        # dominant kernel: ntt_pass_kernel (every launch in the timed region is one pass of it).
+        # algorithmic bytes per launch = 32 B/element/transform * n elements / passes-per-transform
+        passes = launches_per_step // 2
+        avg_launch_s = (ev_ms * 1e-3) / (args.steps * launches_per_step)
+        alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * (total_n / world) / passes
+        achieved = alg_bytes_per_launch / avg_launch_s / 1e9
+        out = {
+            "metric": "ntt_field_elements_per_sec", "value": value, "unit": "field-elements/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u128 (2x64-bit limbs, Montgomery constants)", "data": "synthetic",
+            "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
+                       "passes_per_transform": passes, "roundtrip_bit_exact": ok},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "ntt_pass_kernel", "avg_launch_us": avg_launch_s * 1e6,
+                         "note": "VALU-bound 128-bit modmul; see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit("round trip mismatch")
+
+
+def ctypes_void(v):
+    import ctypes
+    return ctypes.c_void_p(v)
+
+
+def ntt_passes(log2n):
+    """passes the library plans for a 2^log2n transform at default tuning (mirrors csrc/ntt_plan.h plan_num_passes)."""
+    if log2n <= 11:
+        return 1
+    return max(2, (log2n + 7) // 8)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+/*
+ * starkcore.h -- C ABI of the MI355X-native STARK polynomial core (libstarkcore.so).
+ *
+ * The reference (aszepieniec/stark-anatomy, pure Python) has no FFI; its boundary for this path is
+ * the set of module-level callables in code/ntt.py, the fold expression in code/fri.py:85 and
+ * code/merkle.py.  Each entry point below names the reference callable it replaces (file:line);
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - element = 16 bytes, two little-endian uint64 limbs (lo, hi), CANONICAL residue in [0, p),
+ *     p = 1 + 407 * 2^119 (code/algebra.py:96-98); arrays contiguous, natural index order.
+ *   - every function returns 0 on success or a negative SC_ERR_* code; sc_last_error() gives text.
+ *     Nothing throws across the ABI; host-buffer calls block until the output buffer is valid.
+ *   - host-buffer entry points (sc_ntt, ...) take caller-owned host memory.
+ *   - *_dev entry points take device pointers (hipMalloc / torch tensor storage, 16-byte aligned) and
+ *     a hipStream_t (NULL = the library's own stream) and are asynchronous on that stream.
+ *   - sc_vec_t / sc_merkle_t are library-owned device objects behind opaque handles.
+ */
+#ifndef STARKCORE_H
+#define STARKCORE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_OK 0
+#define SC_ERR_HIP (-1)              /* HIP runtime error (no GPU, OOM, launch failure) */
+#define SC_ERR_NOT_POW2 (-2)         /* ntt.py:4 / merkle.py:7 "length must be power of two" */
+#define SC_ERR_ROOT_ORDER (-3)       /* ntt.py:10 root^n != 1 */
+#define SC_ERR_ROOT_NOT_PRIMITIVE (-4) /* ntt.py:11 root^(n/2) == 1 */
+#define SC_ERR_DIV_ZERO (-5)         /* algebra.py:92 "divide by zero" */
+#define SC_ERR_BAD_ARG (-6)
+#define SC_ERR_UNSUPPORTED (-7)
+#define SC_ERR_NOT_INIT (-8)
+
+typedef struct sc_vec sc_vec_t;        /* device-resident vector of field elements */
+typedef struct sc_merkle sc_merkle_t;  /* device-resident BLAKE2b Merkle tree (all levels kept) */
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int sc_device_count(void);
+int sc_init(int device);               /* idempotent; selects the device and creates the library stream */
+int sc_shutdown(void);                 /* frees plans, scratch and the stream */
+const char* sc_last_error(void);
+int sc_synchronize(void);              /* wait for the library stream */
+/* tuning knobs for experiments: key in {"max_tile_log","loge","max_col_log","min_tiles_log",
+ * "single_pass_max_log","max_digit_log"}; clears cached plans */
+int sc_set_tuning(const char* key, int value);
+
+/* ---- device vectors ----------------------------------------------------------------------- */
+int sc_vec_alloc(uint64_t n, sc_vec_t** out);
+int sc_vec_free(sc_vec_t* v);
+uint64_t sc_vec_len(const sc_vec_t* v);
+void* sc_vec_ptr(sc_vec_t* v);         /* raw device pointer */
+int sc_vec_upload(sc_vec_t* v, uint64_t offset, const void* host, uint64_t count);
+int sc_vec_download(const sc_vec_t* v, uint64_t offset, void* host, uint64_t count);
+int sc_vec_gather(const sc_vec_t* v, const uint64_t* indices, uint64_t k, void* host_out); /* host_out[i] = v[indices[i]] */
+
+/* ---- ntt / intt : code/ntt.py:3-18, :20-30 -------------------------------------------------- */
+/* out[i] = sum_j in[j] * root^(i*j); inverse != 0: uses root^-1 and scales by n^-1 (ntt.py:27-30).
+ * n must be a power of two (n <= 1 copies).  root is validated like ntt.py:10-11. */
+int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int inverse);
+int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2], int inverse, void* stream);
+
+/* ---- fast_coset_evaluate : code/ntt.py:132-135 (Polynomial.scale univariate.py:153-154 fused) -- */
+/* out[i] = sum_{j<m} coeffs[j] * (offset * generator^i)^j, i < order; m <= order. */
+int sc_coset_evaluate(const void* coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* out);
+int sc_coset_evaluate_dev(const void* d_coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* d_out, void* stream);
+
+/* ---- NTT core of fast_multiply : code/ntt.py:51-64 ----------------------------------------- */
+/* out[0..n_out) = intt(root, ntt(root, a||0) * ntt(root, b||0))[0..n_out); na, nb, n_out <= order.
+ * (the degree bookkeeping / order halving of ntt.py:38-49 stays in the host shim.) */
+int sc_poly_mul(const void* a, uint64_t na, const void* b, uint64_t nb, const uint64_t root[2], uint64_t order, void* out, uint64_t n_out);
+
+/* ---- NTT core of fast_coset_divide : code/ntt.py:159-176 ----------------------------------- */
+/* out[0..n_out) = unscale( intt( ntt(scale(a)) / ntt(scale(b)) ) ); SC_ERR_DIV_ZERO if a divisor value is 0 */
+int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order, void* out, uint64_t n_out);
+
+/* ---- pointwise helpers (ntt.py:61, :172; univariate.py:153-154) ------------------------------ */
+int sc_pointwise_mul_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream);
+int sc_pointwise_div_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream); /* sync; SC_ERR_DIV_ZERO */
+int sc_scale_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t factor[2], void* stream); /* out[i] = in[i] * factor^i */
+
+/* ---- FRI split-and-fold : code/fri.py:85 ---------------------------------------------------- */
+/* out[i] = 2^-1 * ((1 + alpha/(offset*omega^i)) * in[i] + (1 - alpha/(offset*omega^i)) * in[N/2+i]), i < N/2 */
+int sc_fri_fold(const void* in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* out);
+int sc_fri_fold_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* d_out, void* stream);
+
+/* ---- Merkle : code/merkle.py:6-27 ------------------------------------------------------------ */
+/* leaf = BLAKE2b-512(decimal ASCII of the residue) (algebra.py:53-57, merkle.py:14); node = H(left||right) */
+int sc_merkle_commit(const void* elems, uint64_t N, uint8_t root_out[64]);                 /* Merkle.commit, merkle.py:13-14 */
+int sc_merkle_build(const void* elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree);
+int sc_merkle_build_dev(const void* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree, void* stream); /* sync (returns root) */
+int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */
+int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out /* k*64*log2 N */);
+uint64_t sc_merkle_leaves(const sc_merkle_t* tree);
+int sc_merkle_free(sc_merkle_t* tree);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,188 @@
+// merkle.cuh -- BLAKE2b-512 Merkle tree kernels (reference code/merkle.py:6-27).
+//
+//   leaf  = BLAKE2b-512( str(value).encode() )      decimal ASCII, no padding (code/algebra.py:53-57, merkle.py:14)
+//   node  = BLAKE2b-512( left || right )            one 128-byte block (merkle.py:11)
+//
+// One thread = one compression (64-bit ARX, 12 rounds, fully unrolled: sigma is compile-time).  The whole
+// tree is kept in HBM (level 0 = leaf digests, then N/2, ..., root; (2N-1) * 64 bytes) so that
+// Merkle.open is a gather of log2 N digests instead of the reference's rebuild-per-open.
+#pragma once
+#include "field.cuh"
+
+namespace sc {
+
+#if defined(__HIPCC__)
+
+__device__ __constant__ const uint64_t B2_IV[8] = {
+    0x6A09E667F3BCC908ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull, 0xA54FF53A5F1D36F1ull,
+    0x510E527FADE682D1ull, 0x9B05688C2B3E6C1Full, 0x1F83D9ABFB41BD6Bull, 0x5BE0CD19137E2179ull};
+
+__device__ __forceinline__ uint64_t rotr64(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
+
+#define B2_G(a, b, c, d, x, y)                   \
+    do {                                         \
+        v[a] = v[a] + v[b] + (x);                \
+        v[d] = rotr64(v[d] ^ v[a], 32);          \
+        v[c] = v[c] + v[d];                      \
+        v[b] = rotr64(v[b] ^ v[c], 24);          \
+        v[a] = v[a] + v[b] + (y);                \
+        v[d] = rotr64(v[d] ^ v[a], 16);          \
+        v[c] = v[c] + v[d];                      \
+        v[b] = rotr64(v[b] ^ v[c], 63);          \
+    } while (0)
+
+#define B2_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    B2_G(0, 4, 8, 12, m[s0], m[s1]);   B2_G(1, 5, 9, 13, m[s2], m[s3]);                 \
+    B2_G(2, 6, 10, 14, m[s4], m[s5]);  B2_G(3, 7, 11, 15, m[s6], m[s7]);                \
+    B2_G(0, 5, 10, 15, m[s8], m[s9]);  B2_G(1, 6, 11, 12, m[s10], m[s11]);              \
+    B2_G(2, 7, 8, 13, m[s12], m[s13]); B2_G(3, 4, 9, 14, m[s14], m[s15]);
+
+// Single-block unkeyed BLAKE2b-512 of a message of `len` <= 128 bytes held zero-padded in m[16].
+__device__ __forceinline__ void blake2b_single_block(const uint64_t m[16], uint32_t len, uint64_t h[8]) {
+    uint64_t v[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { h[i] = B2_IV[i]; }
+    h[0] ^= 0x01010040ull;       // digest 64, key 0, fanout 1, depth 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = B2_IV[i]; }
+    v[12] ^= (uint64_t)len;
+    v[14] = ~v[14];              // final block
+    B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    B2_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    B2_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    B2_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    B2_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    B2_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    B2_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    B2_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    B2_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+
+__device__ __forceinline__ uint32_t ndigits9(uint32_t x) {   // decimal digits of x < 10^9, x > 0
+    return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) + (x >= 10000000u) + (x >= 100000000u);
+}
+
+__device__ __forceinline__ uint64_t sel6(const uint64_t W[6], uint32_t idx) {
+    uint64_t r = 0;
+    r = idx == 0 ? W[0] : r; r = idx == 1 ? W[1] : r; r = idx == 2 ? W[2] : r;
+    r = idx == 3 ? W[3] : r; r = idx == 4 ? W[4] : r; r = idx == 5 ? W[5] : r;
+    return r;
+}
+
+// Decimal ASCII of a canonical residue into the first words of a zeroed BLAKE2b block; returns the length.
+__device__ __forceinline__ uint32_t leaf_message(Fe x, uint64_t m[16]) {
+    uint32_t d[4] = {(uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.hi, (uint32_t)(x.hi >> 32)};
+    uint32_t grp[5];   // base-10^9 digits, least significant first
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        uint64_t rem = 0;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            uint64_t cur = (rem << 32) | d[i];
+            uint64_t q = cur / 1000000000ull;
+            rem = cur - q * 1000000000ull;
+            d[i] = (uint32_t)q;
+        }
+        grp[g] = (uint32_t)rem;
+    }
+    // 45 characters, most significant first, packed little-endian into W
+    uint64_t W[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int g = 4; g >= 0; --g) {
+        uint32_t y = grp[g];
+#pragma unroll
+        for (int j = 8; j >= 0; --j) {
+            uint32_t q = y / 10u;
+            uint32_t digit = y - q * 10u;
+            y = q;
+            const int pos = (4 - g) * 9 + j;
+            W[pos >> 3] |= (uint64_t)(0x30u + digit) << (8 * (pos & 7));
+        }
+    }
+    uint32_t nd = 1;
+    if (grp[4]) nd = 36 + ndigits9(grp[4]);
+    else if (grp[3]) nd = 27 + ndigits9(grp[3]);
+    else if (grp[2]) nd = 18 + ndigits9(grp[2]);
+    else if (grp[1]) nd = 9 + ndigits9(grp[1]);
+    else if (grp[0]) nd = ndigits9(grp[0]);
+    const uint32_t z = 45u - nd;               // leading zero characters to drop
+    const uint32_t zw = z >> 3, zb = (z & 7u) * 8u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        uint64_t lo = sel6(W, i + zw), hi = sel6(W, i + zw + 1);
+        m[i] = zb ? ((lo >> zb) | (hi << (64u - zb))) : lo;
+    }
+    return nd;
+}
+
+__global__ void __launch_bounds__(256) merkle_leaf_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ digests, uint64_t N) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint64_t m[16], h[8];
+    uint32_t len = leaf_message(elems[i], m);
+    blake2b_single_block(m, len, h);
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 8 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = make_ulonglong2(h[2 * k], h[2 * k + 1]);
+}
+
+__device__ __forceinline__ void merkle_node(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t i) {
+    uint64_t m[16], h[8];
+    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(in + 16 * i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ulonglong2 t = s[k]; m[2 * k] = t.x; m[2 * k + 1] = t.y; }
+    blake2b_single_block(m, 128u, h);
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 8 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = make_ulonglong2(h[2 * k], h[2 * k + 1]);
+}
+
+// one level: count parents from 2*count children
+__global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) merkle_node(in, out, i);
+}
+
+// finishes the tree from a level of `width` <= 2048 digests down to the root inside ONE workgroup
+// (levels are written once and read only after the barrier, so L1 cannot hold a stale copy).
+__global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint64_t width) {
+    uint64_t* cur = level;
+    for (uint64_t w = width; w > 1; w >>= 1) {
+        uint64_t* nxt = cur + 8 * w;
+        if (threadIdx.x < (w >> 1)) merkle_node(cur, nxt, threadIdx.x);
+        __threadfence_block();
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
+// authentication paths (merkle.py:16-27): for query q, digest l of the path = level_l[(index >> l) ^ 1]
+__global__ void __launch_bounds__(256) merkle_open_kernel(const uint64_t* __restrict__ levels, uint64_t N, int logN,
+                                                          const uint64_t* __restrict__ indices, uint64_t k, uint64_t* __restrict__ out) {
+    // one thread per (query, level, 16-byte quarter)
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = k * (uint64_t)logN * 4;
+    if (t >= total) return;
+    uint32_t quarter = (uint32_t)(t & 3);
+    uint64_t ql = t >> 2;
+    uint32_t l = (uint32_t)(ql % (uint64_t)logN);
+    uint64_t q = ql / (uint64_t)logN;
+    uint64_t idx = indices[q];
+    // offset of level l in digests: N + N/2 + ... = 2N - (N >> (l-1)) for l >= 1
+    uint64_t off = (l == 0) ? 0 : (2 * N - (N >> (l - 1)));
+    uint64_t node = (idx >> l) ^ 1ull;
+    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(levels + 8 * (off + node));
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 8 * ql);
+    o[quarter] = s[quarter];
+}
+
+#endif  // __HIPCC__
+
+}  // namespace sc

@@ -1,0 +1,162 @@
+// ntt_plan.h -- host-side pass planning for the tiled NTT (digits, tile shapes, strides).
+// Plain C++ shared by the C-ABI library (starkcore.hip) and the CPU emulation used in tests.
+#pragma once
+#include "ntt_tile.cuh"
+
+namespace sc {
+
+struct NttTuning {
+    int max_tile_log = 12;   // LDS tile = 2^max_tile_log elements (64 KiB at 12)
+    int loge = 3;            // elements per thread = 2^loge
+    int max_col_log = 6;     // at most 64 columns (1 KiB runs)
+    int min_tiles_log = 10;  // shrink tiles until there are at least this many per pass (fill 256 CUs)
+    int single_pass_max_log = 11;
+    int max_digit_log = 8;   // passes = ceil(logn / max_digit_log)
+};
+
+struct NttTables {
+    const Fe* mt = nullptr;  // mt[e] = w_(2^mt_log)^e, e < 2^(mt_log-1)      (Montgomery form)
+    int mt_log = 0;
+    const Fe* tl = nullptr;  // tl[e] = root^e, e < min(n, 4096)
+    const Fe* th = nullptr;  // th[h] = root^(4096 h), h < max(1, n/4096)
+    const Fe* th_scaled = nullptr;  // th[h] * scale (n^-1 for the inverse transform); used by the FIRST pass's twiddle only
+};
+
+struct NttPassDesc {
+    PassParams p;
+    int loge;
+    uint32_t ntiles;
+    uint32_t threads;
+    uint32_t lds_bytes;
+};
+
+struct NttPlanDesc {
+    int logn = 0;
+    int npasses = 0;
+    int digits[4] = {0, 0, 0, 0};
+    NttPassDesc pass[4];
+};
+
+struct NttIo {
+    const Fe* in = nullptr;
+    Fe* work = nullptr;      // n elements of scratch (unused when npasses == 1)
+    Fe* out = nullptr;
+    uint64_t in_limit = ~0ull;
+    const Fe* ol = nullptr;  // coset scaling tables (nullptr = none)
+    const Fe* oh = nullptr;
+    bool scale_last = false; // multiply outputs by `scale` in the last pass (used when there is no four-step twiddle to fold it into)
+    Fe scale = Fe{0, 0};
+};
+
+inline int plan_num_passes(int logn, const NttTuning& tu) {
+    if (logn <= tu.single_pass_max_log) return 1;
+    const int m = (logn + tu.max_digit_log - 1) / tu.max_digit_log;
+    return m < 2 ? 2 : m;
+}
+
+// Fill the pass descriptors for a length-2^logn transform.  Returns false if unsupported.
+inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo& io, const NttTuning& tu) {
+    if (logn < 1 || logn > 32) return false;
+    d.logn = logn;
+    const int m = plan_num_passes(logn, tu);
+    if (m > 4) return false;
+    d.npasses = m;
+    {
+        int base = logn / m, extra = logn % m;
+        for (int i = 0; i < m; ++i) d.digits[i] = base + (i < extra ? 1 : 0);
+    }
+    const uint64_t n = 1ull << logn;
+    int tile_cap = tu.max_tile_log;
+    while (tile_cap > 6 && logn - tile_cap < tu.min_tiles_log && m > 1) --tile_cap;
+
+    int logA = 0;                         // log2 of the product of the digits already transformed
+    for (int i = 0; i < m; ++i) {
+        NttPassDesc& pd = d.pass[i];
+        PassParams& p = pd.p;
+        p = PassParams{};
+        const int logR = d.digits[i];
+        const int logB = logn - logA - logR;
+        const bool lastp = (i == m - 1);
+        p.logR = logR;
+        p.in = (i == 0) ? io.in : io.work;
+        p.out = lastp ? io.out : io.work;
+        p.mt = tb.mt;
+        p.mt_shift = tb.mt_log - logR;
+        p.tl = tb.tl;
+        p.th = (i == 0 && tb.th_scaled) ? tb.th_scaled : tb.th;
+        p.in_limit = (i == 0) ? io.in_limit : ~0ull;
+        p.coset_enable = (i == 0 && io.ol != nullptr) ? 1 : 0;
+        p.ol = io.ol;
+        p.oh = io.oh;
+        p.scale_enable = (lastp && io.scale_last) ? 1 : 0;
+        p.scale = io.scale;
+        if (m == 1) {
+            p.logC = 0;
+            p.lo_log = 0; p.mid_log = 0;
+            p.in_rs = 1; p.out_rs = 1;
+            p.in_cs = 0; p.out_cs = 0;
+            p.rfast_load = 0;
+            p.tw_enable = 0;
+            pd.ntiles = 1;
+        } else if (!lastp) {
+            // column pass on [A][R][B]
+            int logC = tile_cap - logR;
+            if (logC > logB) logC = logB;
+            if (logC > tu.max_col_log) logC = tu.max_col_log;
+            if (logC < 0) logC = 0;
+            p.logC = logC;
+            p.lo_log = logB - logC;       // t_lo = column block, t_mid = a
+            p.mid_log = logA;
+            p.in_lo = p.out_lo = 1ull << logC;
+            p.in_mid = p.out_mid = 1ull << (logR + logB);
+            p.in_hi = p.out_hi = 0;
+            p.in_rs = p.out_rs = 1ull << logB;
+            p.in_cs = p.out_cs = 1;
+            p.rfast_load = 0;
+            p.tw_enable = 1;
+            p.tw_scale = 1ull << logA;
+            pd.ntiles = (uint32_t)(n >> (logR + logC));
+        } else {
+            // transposing pass: memory [k_1][k_2]..[k_{m-1}][j_m] -> natural k = k_1 + N_1 k_2 + ... ; C adjacent k_1 per tile
+            const int logN1 = d.digits[0];
+            int logC = tile_cap - logR;
+            if (logC > logN1) logC = logN1;
+            if (logC > tu.max_col_log) logC = tu.max_col_log;
+            if (logC < 0) logC = 0;
+            p.logC = logC;
+            // tile id -> (t_hi = k_1 block, t_mid = k_2, t_lo = k_3); for m == 2 there is no k_2/k_3, for m == 3 no k_3
+            const int logN2 = (m >= 3) ? d.digits[1] : 0;
+            const int logN3 = (m >= 4) ? d.digits[2] : 0;
+            p.lo_log = logN3;
+            p.mid_log = logN2;
+            p.in_rs = 1;
+            p.in_cs = n >> logN1;                              // next k_1
+            p.in_hi = (n >> logN1) << logC;
+            p.in_mid = 1ull << (logR + logN3);                  // next k_2
+            p.in_lo = 1ull << logR;                             // next k_3
+            p.out_cs = 1;
+            p.out_hi = 1ull << logC;
+            p.out_mid = 1ull << logN1;
+            p.out_lo = 1ull << (logN1 + logN2);
+            p.out_rs = n >> logR;                               // k_m is the most significant output digit
+            p.rfast_load = 1;
+            p.tw_enable = 0;
+            pd.ntiles = (uint32_t)(n >> (logR + logC));
+        }
+        int loge = tu.loge;
+        const int logT = p.logR + p.logC;
+        if (loge > logT) loge = logT;
+        // threads per workgroup: <= 1024 (loge 1,2), 512 (loge 3), 256 (loge 4) -- matches the kernels' launch bounds
+        while (logT - loge > (loge >= 4 ? 8 : (loge == 3 ? 9 : 10))) ++loge;
+        if (loge > 4) return false;
+        if (lastp && m > 1 && p.logR <= loge) loge = p.logR - 1;   // transposing pass needs >= 2 rounds (load r-fast, store c-fast)
+        if (loge < 1) return false;
+        pd.loge = loge;
+        pd.threads = 1u << (logT - loge);
+        pd.lds_bytes = (uint32_t)sizeof(Fe) << logT;
+        logA += logR;
+    }
+    return true;
+}
+
+}  // namespace sc

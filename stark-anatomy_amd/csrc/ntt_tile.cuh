@@ -1,0 +1,213 @@
+// ntt_tile.cuh -- one pass of the multi-pass NTT: a tile of R rows x C columns is transformed along
+// the row axis (length-R decimation-in-frequency NTT per column) with the tile held in LDS.
+//
+// Replaces the recursive radix-2 of reference code/ntt.py:3-18.  The whole transform of length
+// n = N_1 * N_2 * ... * N_m (digits chosen by the host, ntt_plan in starkcore.hip) runs m such passes:
+//
+//   x[j],  j = j_1*(N_2..N_m) + j_2*(N_3..N_m) + ... + j_m        (natural order in)
+//   X[k],  k = k_1 + N_1*k_2 + N_1*N_2*k_3 + ...                  (natural order out)
+//
+//   pass i < m ("column pass", in place):  memory viewed as [A][R=N_i][B], A = N_1..N_{i-1} (already
+//       transformed digits), B = N_{i+1}..N_m; length-R NTT over the middle axis for every (a, b),
+//       then the four-step twiddle  w_n^(A * b * k_i).  A tile = all R rows x C adjacent b.
+//   pass m ("transposing pass", out of place):  contiguous rows of length R = N_m are transformed and
+//       written to natural positions; a tile takes C adjacent k_1 so that the stores form C*16-byte runs.
+//
+// Inside a tile the R-point NTT is radix-2 DIF, log2(E) stages per round held in registers
+// (E = elements per thread), rounds exchanging through LDS; DIF leaves row position rp holding output
+// row bitrev(rp), which is undone for free in the store addressing.
+//
+// The round body is host+device so tests/ can run the identical index logic on the CPU (emulation of
+// one workgroup = loop over thread ids per round).
+#pragma once
+#include "field.cuh"
+
+namespace sc {
+
+struct PassParams {
+    const Fe* in;
+    Fe* out;
+    int logR, logC;            // tile geometry; threads = 2^(logR+logC-LOGE)
+    // tile id t -> (t_hi, t_mid, t_lo);  t_lo = t & (2^lo_log - 1), t_mid = (t >> lo_log) & (2^mid_log - 1)
+    int lo_log, mid_log;
+    uint64_t in_hi, in_mid, in_lo, in_rs, in_cs;      // element strides (units of Fe)
+    uint64_t out_hi, out_mid, out_lo, out_rs, out_cs;
+    int rfast_load;            // round 0 maps lanes along rows (transposing pass: in_rs == 1)
+    // butterfly twiddles: mt[e << mt_shift] = w_R^e in Montgomery form, e < R/2
+    const Fe* mt;
+    int mt_shift;
+    // four-step twiddle  w_n^(colidx * k * tw_scale), colidx = t_lo*C + c ; tl[e & 4095] * th[e >> 12]
+    int tw_enable;
+    uint64_t tw_scale;
+    const Fe* tl;
+    const Fe* th;
+    // final constant multiply (Montgomery form), e.g. n^-1 for a single-pass inverse transform
+    int scale_enable;
+    Fe scale;
+    // input side (first pass only; memory index == natural index j there)
+    uint64_t in_limit;         // j >= in_limit reads as zero (zero padding, ntt.py:134 / :51-56)
+    int coset_enable;          // x[j] *= offset^j (Polynomial.scale, univariate.py:153-154): ol[j & 4095] * oh[j >> 12]
+    const Fe* ol;
+    const Fe* oh;
+};
+
+SC_HD uint32_t bitrev32(uint32_t x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0u;
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+// LDS placement of tile element (r, c): row-major with the column XOR-swizzled by the row so that both
+// lane-along-column and lane-along-row access patterns spread over the 16-byte bank slots.
+SC_HD uint32_t lds_index(uint32_t r, uint32_t c, int logC) {
+    uint32_t cm = (1u << logC) - 1u;
+    return (r << logC) | ((c ^ r) & cm);
+}
+
+// two-level power table lookup: base^e = lo[e & 4095] * hi[e >> 12]   (Montgomery form in, Montgomery form out)
+SC_HD Fe pow2level(const Fe* lo, const Fe* hi, uint64_t e) {
+    Fe a = lo[e & 4095u];
+    Fe b = hi[e >> 12];
+    // a~ * b~ * R^-1 = (ab)~
+    return mont_mul(a, b);
+}
+
+// table entry i of a power table: base^(i*step) * scale   (all Montgomery form)
+SC_HD Fe pow_table_entry(Fe base_m, uint64_t i, uint64_t step, Fe scale_m) {
+    return mont_mul(mont_pow(base_m, i * step), scale_m);   // (x~ * s~) R^-1 = (x s)~
+}
+
+// One round of one workgroup's tile, for thread `tid`: S radix-2 DIF stages on row bits [sh, sh+S).
+template <int LOGE, int S>
+SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds) {
+    constexpr int E = 1 << LOGE;
+    constexpr int F = 1 << S;          // elements per butterfly group
+    const int logR = P.logR, logC = P.logC;
+    const uint32_t T = 1u << (logR + logC - LOGE);   // threads per workgroup
+    const bool last = (sh == 0);
+
+    const uint32_t t_lo = tile & ((1u << P.lo_log) - 1u);
+    const uint32_t t_mid = (tile >> P.lo_log) & ((1u << P.mid_log) - 1u);
+    const uint32_t t_hi = tile >> (P.lo_log + P.mid_log);
+
+    Fe x[E];
+    uint32_t rr[E >> S];   // per group: row bits outside the field, packed (rrem)
+    uint32_t cc[E >> S];   // per group: column
+
+#pragma unroll
+    for (int g = 0; g < (E >> S); ++g) {
+        uint32_t rem = (uint32_t)g * T + tid;      // < 2^(logR+logC-S)
+        uint32_t rrem, c;
+        if (first && P.rfast_load) {
+            rrem = rem & ((1u << (logR - S)) - 1u);
+            c = rem >> (logR - S);
+        } else {
+            c = rem & ((1u << logC) - 1u);
+            rrem = rem >> logC;
+        }
+        rr[g] = rrem;
+        cc[g] = c;
+    }
+
+    // ---- gather
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int g = i >> S, fi = i & (F - 1);
+        const uint32_t rrem = rr[g], c = cc[g];
+        const uint32_t r = ((rrem >> sh) << (sh + S)) | ((uint32_t)fi << sh) | (rrem & ((1u << sh) - 1u));
+        if (first) {
+            uint64_t j = (uint64_t)t_hi * P.in_hi + (uint64_t)t_mid * P.in_mid + (uint64_t)t_lo * P.in_lo + (uint64_t)r * P.in_rs + (uint64_t)c * P.in_cs;
+            Fe v = fe_zero();
+            if (j < P.in_limit) {
+                v = P.in[j];
+                if (P.coset_enable) v = mont_mul(v, pow2level(P.ol, P.oh, j));
+            }
+            x[i] = v;
+        } else {
+            x[i] = lds[lds_index(r, c, logC)];
+        }
+    }
+
+    // ---- S radix-2 DIF stages on the field bits, highest bit first
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+        const int bit = S - 1 - q;          // field bit
+        const int b = sh + bit;             // row bit
+        const int tau = logR - 1 - b;       // twiddle exponent scale: w_R^(2^tau * (r mod 2^b))
+#pragma unroll
+        for (int i0 = 0; i0 < E; ++i0) {
+            if (i0 & (1 << bit)) continue;
+            const int i1 = i0 | (1 << bit);
+            const int g = i0 >> S;
+            const uint32_t fi_low = (uint32_t)(i0 & (F - 1)) & ((1u << bit) - 1u);
+            Fe u = x[i0], v = x[i1];
+            x[i0] = fe_add(u, v);
+            Fe d = fe_sub(u, v);
+            if (b == 0 || (last && fi_low == 0)) {
+                x[i1] = d;                  // twiddle is w^0 = 1
+            } else {
+                const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
+                const uint32_t e = ((fi_low << sh) | row_lo) << tau;     // < R/2
+                x[i1] = mont_mul(d, P.mt[(uint64_t)e << P.mt_shift]);
+            }
+        }
+    }
+
+    // ---- scatter
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int g = i >> S, fi = i & (F - 1);
+        const uint32_t rrem = rr[g], c = cc[g];
+        const uint32_t r = ((rrem >> sh) << (sh + S)) | ((uint32_t)fi << sh) | (rrem & ((1u << sh) - 1u));
+        if (last) {
+            const uint32_t k = bitrev32(r, logR);
+            Fe v = x[i];
+            if (P.tw_enable) {
+                const uint64_t colidx = ((uint64_t)t_lo << logC) | c;
+                const uint64_t e = colidx * (uint64_t)k * P.tw_scale;
+                v = mont_mul(v, pow2level(P.tl, P.th, e));
+            }
+            if (P.scale_enable) v = mont_mul(v, P.scale);
+            uint64_t j = (uint64_t)t_hi * P.out_hi + (uint64_t)t_mid * P.out_mid + (uint64_t)t_lo * P.out_lo + (uint64_t)k * P.out_rs + (uint64_t)c * P.out_cs;
+            P.out[j] = v;
+        } else {
+            lds[lds_index(r, c, logC)] = x[i];
+        }
+    }
+}
+
+// dispatch on the (runtime) number of stages in this round
+template <int LOGE>
+SC_HD void ntt_round_dispatch(const PassParams& P, int s, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds) {
+    if constexpr (LOGE >= 4) { if (s == 4) { ntt_round<LOGE, 4>(P, sh, first, tile, tid, lds); return; } }
+    if constexpr (LOGE >= 3) { if (s == 3) { ntt_round<LOGE, 3>(P, sh, first, tile, tid, lds); return; } }
+    if constexpr (LOGE >= 2) { if (s == 2) { ntt_round<LOGE, 2>(P, sh, first, tile, tid, lds); return; } }
+    ntt_round<LOGE, 1>(P, sh, first, tile, tid, lds);
+}
+
+// Round schedule shared by the kernel and the CPU emulation: the short round (if any) goes first.
+struct RoundSched {
+    int nrounds;
+    int s[16];
+    int sh[16];
+};
+SC_HD RoundSched make_rounds(int logR, int loge) {
+    RoundSched rs;
+    rs.nrounds = (logR + loge - 1) / loge;
+    if (rs.nrounds == 0) rs.nrounds = 1;
+    int rem = logR;
+    for (int i = 0; i < rs.nrounds; ++i) {
+        int s = (i == 0) ? (logR - loge * (rs.nrounds - 1)) : loge;
+        if (s < 1) s = (logR == 0) ? 0 : 1;
+        rem -= s;
+        rs.s[i] = s;
+        rs.sh[i] = rem;
+    }
+    return rs;
+}
+
+}  // namespace sc

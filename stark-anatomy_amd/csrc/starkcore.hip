@@ -1,0 +1,739 @@
+// starkcore.hip -- C-ABI library: plans, launches and host glue for the MI355X STARK polynomial core.
+// gfx950 only; see include/starkcore.h for the contract and the reference lines each entry replaces.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/starkcore.h"
+#include "merkle.cuh"
+#include "ntt_plan.h"
+
+using namespace sc;
+
+// ============================================================================ kernels
+
+// threads per workgroup are capped per LOGE so the register allocator gets the budget the tile needs
+template <int LOGE> struct PassThreads { static constexpr int value = LOGE >= 4 ? 256 : (LOGE == 3 ? 512 : 1024); };
+
+template <int LOGE>
+__global__ void __launch_bounds__(PassThreads<LOGE>::value) ntt_pass_kernel(const PassParams P, uint32_t ntiles, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Fe* lds = reinterpret_cast<Fe*>(smem_raw);
+    // XCD-aware tile mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of tiles so
+    // that neighbouring tiles (which share twiddle rows and adjacent memory) stay within one L2.
+    uint32_t tile = blockIdx.x;
+    if (xcd_remap) tile = (blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3);
+    // same schedule as make_rounds() (short round first), computed inline to keep it in SGPRs
+    const int nrounds = (P.logR + LOGE - 1) / LOGE;
+    int sh = P.logR;
+    for (int r = 0; r < nrounds; ++r) {
+        const int s = (r == 0) ? (P.logR - LOGE * (nrounds - 1)) : LOGE;
+        sh -= s;
+        ntt_round_dispatch<LOGE>(P, s, sh, r == 0, tile, threadIdx.x, lds);
+        if (r + 1 < nrounds) __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) pow_table_kernel(Fe* out, uint64_t count, Fe base_m, uint64_t step, Fe scale_m) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = pow_table_entry(base_m, i, step, scale_m);
+}
+
+// out = a * b (canonical in, canonical out)
+__global__ void __launch_bounds__(256) pointwise_mul_kernel(const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fe_mul(a[i], b[i]);
+}
+
+// out = a / b with Montgomery's batch-inversion trick, K elements per thread (strided for coalescing).
+// flag[0] |= 1 if any divisor is zero (Field.divide asserts, code/algebra.py:91-94).
+template <int K>
+__global__ void __launch_bounds__(256) pointwise_div_kernel(const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n, uint32_t* flag) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fe bm[K], pre[K];
+    Fe acc = fe_mont_one();
+    bool zero = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint64_t i = t + (uint64_t)k * nthreads;
+        Fe v = (i < n) ? b[i] : fe_one();
+        zero |= fe_is_zero(v);
+        bm[k] = to_mont(v);
+        pre[k] = acc;                  // product of bm[0..k)
+        acc = mont_mul(acc, bm[k]);
+    }
+    if (zero) atomicOr(flag, 1u);
+    Fe inv = mont_inv(acc);
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+        uint64_t i = t + (uint64_t)k * nthreads;
+        Fe ik = mont_mul(inv, pre[k]);             // (b_k)^-1 in Montgomery form
+        inv = mont_mul(inv, bm[k]);
+        if (i < n) out[i] = mont_mul(a[i], ik);
+    }
+}
+
+// out[i] = in[i] * base^i  (Polynomial.scale, code/univariate.py:153-154) via the two-level power table
+__global__ void __launch_bounds__(256) scale_pow_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, uint64_t n, const Fe* __restrict__ lo, const Fe* __restrict__ hi) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mont_mul(in[i], pow2level(lo, hi, i));
+}
+
+// split-and-fold (code/fri.py:85) rewritten as
+//   out[i] = (a + b)/2 + (a - b) * c * w^-i,   a = in[i], b = in[i + N/2], c = alpha / (2 * offset)
+// lo/hi are the power tables of omega^-1, c_m is c in Montgomery form.
+__global__ void __launch_bounds__(256) fri_fold_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, uint64_t half, const Fe* __restrict__ lo, const Fe* __restrict__ hi, Fe c_m) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    Fe a = in[i], b = in[i + half];
+    Fe t = mont_mul(pow2level(lo, hi, i), c_m);          // (c * w^-i) in Montgomery form
+    out[i] = fe_add(fe_half(fe_add(a, b)), mont_mul(fe_sub(a, b), t));
+}
+
+__global__ void __launch_bounds__(256) gather_kernel(const Fe* __restrict__ v, const uint64_t* __restrict__ idx, uint64_t k, Fe* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) out[i] = v[idx[i]];
+}
+
+// ============================================================================ host state
+
+struct sc_vec {
+    Fe* d;
+    uint64_t n;
+};
+struct sc_merkle {
+    uint64_t* d_levels;   // (2N-1) digests of 8 x u64
+    uint64_t N;
+    int logN;
+};
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct PlanKey {
+    int logn;
+    uint64_t lo, hi;
+    bool operator<(const PlanKey& o) const { return std::tie(logn, lo, hi) < std::tie(o.logn, o.lo, o.hi); }
+};
+struct PlanTables {      // power tables of one root of order n = 2^logn
+    Fe* mt = nullptr;
+    int mt_log = 0;
+    Fe* tl = nullptr;
+    Fe* th = nullptr;
+    Fe* th_ninv = nullptr;   // th * n^-1 (built on first inverse use)
+};
+struct PowKey {
+    uint64_t lo, hi, hi_count;
+    bool operator<(const PowKey& o) const { return std::tie(lo, hi, hi_count) < std::tie(o.lo, o.hi, o.hi_count); }
+};
+struct PowTables {
+    Fe* lo = nullptr;
+    Fe* hi = nullptr;
+};
+
+struct Ctx {
+    bool init = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    NttTuning tuning;
+    std::map<PlanKey, PlanTables> plans;
+    std::map<PowKey, PowTables> pows;
+    DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    int xcd_remap = 1;
+};
+
+Ctx g;
+std::mutex g_mu;
+
+int fail(int code, const std::string& msg) {
+    g.err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return fail(SC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+    } while (0)
+
+#define SCCHK(expr)              \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != SC_OK) return _rc; \
+    } while (0)
+
+int ensure_init() {
+    if (g.init) return SC_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(SC_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    int dev = 0;
+    if (const char* lr = getenv("LOCAL_RANK")) dev = atoi(lr) % n;
+    if (const char* sd = getenv("STARKCORE_DEVICE")) dev = atoi(sd) % n;
+    HIPCHK(hipSetDevice(dev));
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.device = dev;
+    g.init = true;
+    return SC_OK;
+}
+
+int scratch(int slot, size_t bytes, void** out) {
+    DevBuf& b = g.scratch[slot];
+    if (b.bytes < bytes) {
+        if (b.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        HIPCHK(hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return SC_OK;
+}
+
+inline hipStream_t pick_stream(void* s) { return s ? (hipStream_t)s : g.stream; }
+inline Fe fe_from(const uint64_t v[2]) { return Fe{v[0], v[1]}; }
+inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+inline int ilog2(uint64_t n) { int l = 0; while ((1ull << l) < n) ++l; return l; }
+
+// host check of ntt.py:10-11
+int check_root(Fe root, uint64_t n) {
+    if (fe_ge_p(root)) return fail(SC_ERR_BAD_ARG, "root is not a canonical residue");
+    Fe rm = to_mont(root);
+    Fe one = fe_mont_one();
+    Fe half = mont_pow(rm, n / 2);
+    Fe full = mont_mul(half, half);
+    if (!fe_eq(full, one)) return fail(SC_ERR_ROOT_ORDER, "primitive root must be nth root of unity, where n is len(values)");
+    if (fe_eq(half, one)) return fail(SC_ERR_ROOT_NOT_PRIMITIVE, "primitive root is not primitive nth root of unity, where n is len(values)");
+    return SC_OK;
+}
+
+int build_pow_table(Fe** out, uint64_t count, Fe base_m, uint64_t step, Fe scale_m, hipStream_t st) {
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void**)out, count * sizeof(Fe)));
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(pow_table_kernel, dim3(blocks), dim3(256), 0, st, *out, count, base_m, step, scale_m);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+void free_plans() {
+    for (auto& kv : g.plans) {
+        hipFree(kv.second.mt); hipFree(kv.second.tl); hipFree(kv.second.th);
+        if (kv.second.th_ninv) hipFree(kv.second.th_ninv);
+    }
+    g.plans.clear();
+    for (auto& kv : g.pows) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
+    g.pows.clear();
+}
+
+// tables for a primitive n-th root (Montgomery form entries)
+int get_plan(Fe root, int logn, bool need_ninv, hipStream_t st, PlanTables** out) {
+    PlanKey key{logn, root.lo, root.hi};
+    auto it = g.plans.find(key);
+    bool built = false;
+    if (it == g.plans.end()) {
+        if (g.plans.size() >= 64) { HIPCHK(hipDeviceSynchronize()); free_plans(); }
+        const uint64_t n = 1ull << logn;
+        Fe rm = to_mont(root);
+        PlanTables t;
+        t.mt_log = logn < 12 ? logn : 12;
+        SCCHK(build_pow_table(&t.mt, 1ull << (t.mt_log - 1), rm, n >> t.mt_log, fe_mont_one(), st));
+        SCCHK(build_pow_table(&t.tl, n < 4096 ? n : 4096, rm, 1, fe_mont_one(), st));
+        SCCHK(build_pow_table(&t.th, n > 4096 ? n >> 12 : 1, rm, 4096, fe_mont_one(), st));
+        it = g.plans.emplace(key, t).first;
+        built = true;
+    }
+    if (need_ninv && !it->second.th_ninv) {
+        const uint64_t n = 1ull << logn;
+        Fe ninv_m = mont_inv(to_mont(Fe{n, 0}));
+        SCCHK(build_pow_table(&it->second.th_ninv, n > 4096 ? n >> 12 : 1, to_mont(root), 4096, ninv_m, st));
+        built = true;
+    }
+    if (built) HIPCHK(hipStreamSynchronize(st));   // tables are shared across streams afterwards
+    *out = &it->second;
+    return SC_OK;
+}
+
+// two-level power tables base^i, i < count
+int get_pow(Fe base, uint64_t count, hipStream_t st, PowTables** out) {
+    uint64_t hi_count = (count >> 12) + 1;
+    // round up so that nearby sizes share a table
+    uint64_t hc = 1; while (hc < hi_count) hc <<= 1;
+    PowKey key{base.lo, base.hi, hc};
+    auto it = g.pows.find(key);
+    if (it == g.pows.end()) {
+        if (g.pows.size() >= 64) { HIPCHK(hipDeviceSynchronize()); free_plans(); }
+        Fe bm = to_mont(base);
+        PowTables t;
+        SCCHK(build_pow_table(&t.lo, 4096, bm, 1, fe_mont_one(), st));
+        SCCHK(build_pow_table(&t.hi, hc, bm, 4096, fe_mont_one(), st));
+        HIPCHK(hipStreamSynchronize(st));
+        it = g.pows.emplace(key, t).first;
+    }
+    *out = &it->second;
+    return SC_OK;
+}
+
+template <int LOGE>
+void launch_pass(const NttPassDesc& pd, hipStream_t st) {
+    int remap = (g.xcd_remap && pd.ntiles >= 16 && (pd.ntiles & 7u) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(ntt_pass_kernel<LOGE>, dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap);
+}
+
+struct NttOpts {
+    uint64_t in_limit = ~0ull;
+    const PowTables* coset = nullptr;
+};
+
+// core transform on device pointers; root already validated.  forward: out = NTT_root(in); inverse handled by caller
+// passing root^-1 and inverse=true (adds the n^-1 scaling).
+int ntt_device(const Fe* d_in, Fe* d_out, int logn, Fe root, bool inverse_scale, const NttOpts& o, hipStream_t st) {
+    PlanTables* pt;
+    SCCHK(get_plan(root, logn, inverse_scale, st, &pt));
+    const uint64_t n = 1ull << logn;
+    const int m = plan_num_passes(logn, g.tuning);
+    NttTables tb;
+    tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
+    tb.th_scaled = (inverse_scale && m > 1) ? pt->th_ninv : nullptr;
+    NttIo io;
+    io.in = d_in; io.out = d_out; io.in_limit = o.in_limit;
+    if (m > 1) { void* w; SCCHK(scratch(0, n * sizeof(Fe), &w)); io.work = (Fe*)w; }
+    if (o.coset) { io.ol = o.coset->lo; io.oh = o.coset->hi; }
+    if (inverse_scale && m == 1) { io.scale_last = true; io.scale = mont_inv(to_mont(Fe{n, 0})); }
+    NttPlanDesc d;
+    if (!plan_ntt(d, logn, tb, io, g.tuning)) return fail(SC_ERR_UNSUPPORTED, "unsupported transform length");
+    for (int i = 0; i < d.npasses; ++i) {
+        switch (d.pass[i].loge) {
+            case 1: launch_pass<1>(d.pass[i], st); break;
+            case 2: launch_pass<2>(d.pass[i], st); break;
+            case 3: launch_pass<3>(d.pass[i], st); break;
+            case 4: launch_pass<4>(d.pass[i], st); break;
+            default: return fail(SC_ERR_UNSUPPORTED, "bad loge");
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return SC_OK;
+}
+
+Fe root_inverse(Fe root, uint64_t n) {   // root^-1 = root^(n-1) for an n-th root of unity
+    return from_mont(mont_pow(to_mont(root), n - 1));
+}
+
+int ntt_any(const Fe* d_in, Fe* d_out, uint64_t n, Fe root, bool inverse, const NttOpts& o, hipStream_t st) {
+    if (n <= 1) {
+        if (n == 1 && d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, sizeof(Fe), hipMemcpyDeviceToDevice, st));
+        return SC_OK;
+    }
+    if (!is_pow2(n)) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    SCCHK(check_root(root, n));
+    return ntt_device(d_in, d_out, ilog2(n), inverse ? root_inverse(root, n) : root, inverse, o, st);
+}
+
+int upload(void* d, const void* h, size_t bytes, hipStream_t st) {
+    if (bytes) HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
+    return SC_OK;
+}
+int download(void* h, const void* d, size_t bytes, hipStream_t st) {
+    if (bytes) HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SC_OK;
+}
+
+int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st) {
+    if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
+    uint64_t* levels = nullptr;
+    HIPCHK(hipMalloc((void**)&levels, (2 * N - 1) * 64));
+    hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_elems, levels, N);
+    uint64_t* cur = levels;
+    uint64_t w = N;
+    while (w > 2048) {
+        uint64_t* nxt = cur + 8 * w;
+        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((w / 2 + 255) / 256)), dim3(256), 0, st, cur, nxt, w / 2);
+        cur = nxt;
+        w >>= 1;
+    }
+    if (w > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, cur, w);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hipFree(levels); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    e = hipMemcpyAsync(root_out, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { hipFree(levels); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    if (tree) {
+        sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
+        *tree = t;
+    } else {
+        HIPCHK(hipFree(levels));
+    }
+    return SC_OK;
+}
+
+int fold_device(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st) {
+    if (N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
+    if (fe_is_zero(offset) || fe_is_zero(omega)) return fail(SC_ERR_DIV_ZERO, "divide by zero");
+    // omega^-1 power tables; c = alpha / (2 * offset)
+    Fe winv = from_mont(mont_inv(to_mont(omega)));
+    PowTables* pw;
+    SCCHK(get_pow(winv, N / 2, st, &pw));
+    Fe two_off = fe_add(offset, offset);
+    Fe c_m = mont_mul(to_mont(alpha), mont_inv(to_mont(two_off)));     // alpha~ * (2 offset)^-1~ / R = c~
+    uint64_t half = N / 2;
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, d_in, d_out, half, pw->lo, pw->hi, c_m);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st) {
+    void* fl;
+    SCCHK(scratch(4, 256, &fl));
+    HIPCHK(hipMemsetAsync(fl, 0, 4, st));
+    constexpr int K = 8;
+    uint64_t threads = (n + K - 1) / K;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(pointwise_div_kernel<K>, dim3(blocks), dim3(256), 0, st, a, b, out, n, (uint32_t*)fl);
+    HIPCHK(hipGetLastError());
+    uint32_t hflag = 0;
+    HIPCHK(hipMemcpyAsync(&hflag, fl, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (hflag) return fail(SC_ERR_DIV_ZERO, "divide by zero");
+    return SC_OK;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+
+extern "C" {
+
+int sc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sc_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.init && (device < 0 || device == g.device)) return SC_OK;
+    if (g.init) return fail(SC_ERR_BAD_ARG, "already initialised on another device");
+    if (device >= 0) { char buf[16]; snprintf(buf, sizeof buf, "%d", device); setenv("STARKCORE_DEVICE", buf, 1); }
+    return ensure_init();
+}
+
+int sc_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.init) return SC_OK;
+    hipDeviceSynchronize();
+    free_plans();
+    for (auto& b : g.scratch) { if (b.p) hipFree(b.p); b = DevBuf{}; }
+    if (g.stream) hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+    g.init = false;
+    return SC_OK;
+}
+
+const char* sc_last_error(void) { return g.err.c_str(); }
+
+int sc_synchronize(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return SC_OK;
+}
+
+int sc_set_tuning(const char* key, int value) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::string k(key ? key : "");
+    if (k == "max_tile_log") g.tuning.max_tile_log = value;
+    else if (k == "loge") g.tuning.loge = value;
+    else if (k == "max_col_log") g.tuning.max_col_log = value;
+    else if (k == "min_tiles_log") g.tuning.min_tiles_log = value;
+    else if (k == "single_pass_max_log") g.tuning.single_pass_max_log = value;
+    else if (k == "max_digit_log") g.tuning.max_digit_log = value;
+    else if (k == "xcd_remap") g.xcd_remap = value;
+    else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
+    return SC_OK;
+}
+
+// ---- vectors
+int sc_vec_alloc(uint64_t n, sc_vec_t** out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    sc_vec* v = new sc_vec{nullptr, n};
+    hipError_t e = hipMalloc((void**)&v->d, (n ? n : 1) * sizeof(Fe));
+    if (e != hipSuccess) { delete v; return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    *out = v;
+    return SC_OK;
+}
+int sc_vec_free(sc_vec_t* v) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!v) return SC_OK;
+    hipStreamSynchronize(g.stream);
+    hipFree(v->d);
+    delete v;
+    return SC_OK;
+}
+uint64_t sc_vec_len(const sc_vec_t* v) { return v ? v->n : 0; }
+void* sc_vec_ptr(sc_vec_t* v) { return v ? v->d : nullptr; }
+int sc_vec_upload(sc_vec_t* v, uint64_t offset, const void* host, uint64_t count) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!v || offset + count > v->n) return fail(SC_ERR_BAD_ARG, "upload out of range");
+    SCCHK(upload(v->d + offset, host, count * sizeof(Fe), g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return SC_OK;
+}
+int sc_vec_download(const sc_vec_t* v, uint64_t offset, void* host, uint64_t count) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!v || offset + count > v->n) return fail(SC_ERR_BAD_ARG, "download out of range");
+    return download(host, v->d + offset, count * sizeof(Fe), g.stream);
+}
+int sc_vec_gather(const sc_vec_t* v, const uint64_t* indices, uint64_t k, void* host_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!v) return fail(SC_ERR_BAD_ARG, "null vector");
+    if (k == 0) return SC_OK;
+    for (uint64_t i = 0; i < k; ++i) if (indices[i] >= v->n) return fail(SC_ERR_BAD_ARG, "gather index out of range");
+    void* buf;
+    const size_t idx_bytes = (k * 8 + 255) & ~255ull;
+    SCCHK(scratch(4, 256 + idx_bytes + k * sizeof(Fe), &buf));
+    uint64_t* d_idx = (uint64_t*)((char*)buf + 256);
+    Fe* d_out = (Fe*)((char*)buf + 256 + idx_bytes);
+    SCCHK(upload(d_idx, indices, k * 8, g.stream));
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, g.stream, v->d, d_idx, k, d_out);
+    HIPCHK(hipGetLastError());
+    return download(host_out, d_out, k * sizeof(Fe), g.stream);
+}
+
+// ---- ntt
+int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2], int inverse, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    return ntt_any((const Fe*)d_in, (Fe*)d_out, n, fe_from(root), inverse != 0, NttOpts{}, pick_stream(stream));
+}
+
+int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int inverse) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (n == 0) return SC_OK;
+    if (!is_pow2(n)) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    void* a; void* b;
+    SCCHK(scratch(1, n * sizeof(Fe), &a));
+    SCCHK(scratch(2, n * sizeof(Fe), &b));
+    SCCHK(upload(a, in, n * sizeof(Fe), g.stream));
+    SCCHK(ntt_any((const Fe*)a, (Fe*)b, n, fe_from(root), inverse != 0, NttOpts{}, g.stream));
+    return download(out, b, n * sizeof(Fe), g.stream);
+}
+
+// ---- coset evaluate
+int sc_coset_evaluate_dev(const void* d_coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (m > order) return fail(SC_ERR_BAD_ARG, "more coefficients than the evaluation order");
+    if (order <= 1) {
+        // ntt returns its input unchanged for length <= 1 (ntt.py:5-6); coefficient 0 is scaled by offset^0 = 1
+        if (order == 1) {
+            if (m == 1) HIPCHK(hipMemcpyAsync(d_out, d_coeffs, sizeof(Fe), hipMemcpyDeviceToDevice, st));
+            else HIPCHK(hipMemsetAsync(d_out, 0, sizeof(Fe), st));
+        }
+        return SC_OK;
+    }
+    if (!is_pow2(order)) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    Fe gen = fe_from(generator), off = fe_from(offset);
+    SCCHK(check_root(gen, order));
+    if (fe_ge_p(off)) return fail(SC_ERR_BAD_ARG, "offset is not a canonical residue");
+    PowTables* pw;
+    SCCHK(get_pow(off, m ? m : 1, st, &pw));
+    NttOpts o;
+    o.in_limit = m;
+    o.coset = pw;
+    return ntt_device((const Fe*)d_coeffs, (Fe*)d_out, ilog2(order), gen, false, o, st);
+}
+
+int sc_coset_evaluate(const void* coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* out) {
+    void* a; void* b;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        SCCHK(ensure_init());
+        if (order == 0) return SC_OK;
+        if (m > order) return fail(SC_ERR_BAD_ARG, "more coefficients than the evaluation order");
+        SCCHK(scratch(1, (m ? m : 1) * sizeof(Fe), &a));
+        SCCHK(scratch(2, order * sizeof(Fe), &b));
+        SCCHK(upload(a, coeffs, m * sizeof(Fe), g.stream));
+    }
+    SCCHK(sc_coset_evaluate_dev(a, m, offset, generator, order, b, nullptr));
+    std::lock_guard<std::mutex> lk(g_mu);
+    return download(out, b, order * sizeof(Fe), g.stream);
+}
+
+// ---- pointwise
+int sc_pointwise_mul_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!n) return SC_OK;
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pick_stream(stream), (const Fe*)d_a, (const Fe*)d_b, (Fe*)d_out, n);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+int sc_pointwise_div_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!n) return SC_OK;
+    return pointwise_div_device((const Fe*)d_a, (const Fe*)d_b, (Fe*)d_out, n, pick_stream(stream));
+}
+int sc_scale_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t factor[2], void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!n) return SC_OK;
+    hipStream_t st = pick_stream(stream);
+    PowTables* pw;
+    SCCHK(get_pow(fe_from(factor), n, st, &pw));
+    hipLaunchKernelGGL(scale_pow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fe*)d_in, (Fe*)d_out, n, pw->lo, pw->hi);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+// ---- poly mul: intt(ntt(a) * ntt(b)) truncated
+int sc_poly_mul(const void* a, uint64_t na, const void* b, uint64_t nb, const uint64_t root[2], uint64_t order, void* out, uint64_t n_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!is_pow2(order) || order < 2) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    if (na > order || nb > order || n_out > order || na == 0 || nb == 0) return fail(SC_ERR_BAD_ARG, "operand longer than the transform order");
+    Fe rt = fe_from(root);
+    SCCHK(check_root(rt, order));
+    hipStream_t st = g.stream;
+    void *da, *db, *dc;
+    SCCHK(scratch(1, order * sizeof(Fe), &da));
+    SCCHK(scratch(2, order * sizeof(Fe), &db));
+    SCCHK(scratch(3, order * sizeof(Fe), &dc));
+    const int logn = ilog2(order);
+    NttOpts o;
+    SCCHK(upload(dc, a, na * sizeof(Fe), st));
+    o.in_limit = na;
+    SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, rt, false, o, st));
+    SCCHK(upload(dc, b, nb * sizeof(Fe), st));
+    o.in_limit = nb;
+    SCCHK(ntt_device((const Fe*)dc, (Fe*)db, logn, rt, false, o, st));
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3((unsigned)((order + 255) / 256)), dim3(256), 0, st, (const Fe*)da, (const Fe*)db, (Fe*)dc, order);
+    HIPCHK(hipGetLastError());
+    SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, root_inverse(rt, order), true, NttOpts{}, st));
+    return download(out, da, n_out * sizeof(Fe), st);
+}
+
+// ---- coset divide
+int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order, void* out, uint64_t n_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!is_pow2(order) || order < 2) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    if (na > order || nb > order || n_out > order || na == 0 || nb == 0) return fail(SC_ERR_BAD_ARG, "operand longer than the transform order");
+    Fe rt = fe_from(root), off = fe_from(offset);
+    SCCHK(check_root(rt, order));
+    if (fe_is_zero(off) || fe_ge_p(off)) return fail(SC_ERR_BAD_ARG, "bad coset offset");
+    hipStream_t st = g.stream;
+    void *da, *db, *dc;
+    SCCHK(scratch(1, order * sizeof(Fe), &da));
+    SCCHK(scratch(2, order * sizeof(Fe), &db));
+    SCCHK(scratch(3, order * sizeof(Fe), &dc));
+    const int logn = ilog2(order);
+    PowTables* pw;
+    SCCHK(get_pow(off, order, st, &pw));
+    NttOpts o;
+    o.coset = pw;
+    SCCHK(upload(dc, a, na * sizeof(Fe), st));
+    o.in_limit = na;
+    SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, rt, false, o, st));
+    SCCHK(upload(dc, b, nb * sizeof(Fe), st));
+    o.in_limit = nb;
+    SCCHK(ntt_device((const Fe*)dc, (Fe*)db, logn, rt, false, o, st));
+    SCCHK(pointwise_div_device((const Fe*)da, (const Fe*)db, (Fe*)dc, order, st));
+    SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, root_inverse(rt, order), true, NttOpts{}, st));
+    // unscale by offset^-1 (ntt.py:176)
+    Fe off_inv = from_mont(mont_inv(to_mont(off)));
+    PowTables* pinv;
+    SCCHK(get_pow(off_inv, n_out ? n_out : 1, st, &pinv));
+    if (n_out) {
+        hipLaunchKernelGGL(scale_pow_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, (const Fe*)da, (Fe*)db, n_out, pinv->lo, pinv->hi);
+        HIPCHK(hipGetLastError());
+    }
+    return download(out, db, n_out * sizeof(Fe), st);
+}
+
+// ---- fold
+int sc_fri_fold_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    return fold_device((const Fe*)d_in, N, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)d_out, pick_stream(stream));
+}
+int sc_fri_fold(const void* in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
+    void *a, *b;
+    SCCHK(scratch(1, N * sizeof(Fe), &a));
+    SCCHK(scratch(2, (N / 2) * sizeof(Fe), &b));
+    SCCHK(upload(a, in, N * sizeof(Fe), g.stream));
+    SCCHK(fold_device((const Fe*)a, N, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)b, g.stream));
+    return download(out, b, (N / 2) * sizeof(Fe), g.stream);
+}
+
+// ---- merkle
+int sc_merkle_build_dev(const void* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    return merkle_build_device((const Fe*)d_elems, N, root_out, tree, pick_stream(stream));
+}
+int sc_merkle_build(const void* elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
+    void* a;
+    SCCHK(scratch(1, N * sizeof(Fe), &a));
+    SCCHK(upload(a, elems, N * sizeof(Fe), g.stream));
+    return merkle_build_device((const Fe*)a, N, root_out, tree, g.stream);
+}
+int sc_merkle_commit(const void* elems, uint64_t N, uint8_t root_out[64]) { return sc_merkle_build(elems, N, root_out, nullptr); }
+
+int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree) return fail(SC_ERR_BAD_ARG, "null tree");
+    if (tree->N < 2) return fail(SC_ERR_BAD_ARG, "cannot open invalid index");
+    for (uint64_t i = 0; i < k; ++i) if (indices[i] >= tree->N) return fail(SC_ERR_BAD_ARG, "cannot open invalid index");
+    if (k == 0) return SC_OK;
+    const size_t idx_bytes = (k * 8 + 255) & ~255ull;
+    const size_t out_bytes = k * 64 * (size_t)tree->logN;
+    void* buf;
+    SCCHK(scratch(5, idx_bytes + out_bytes, &buf));
+    uint64_t* d_idx = (uint64_t*)buf;
+    uint64_t* d_out = (uint64_t*)((char*)buf + idx_bytes);
+    SCCHK(upload(d_idx, indices, k * 8, g.stream));
+    uint64_t total = k * (uint64_t)tree->logN * 4;
+    hipLaunchKernelGGL(merkle_open_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g.stream, tree->d_levels, tree->N, tree->logN, d_idx, k, d_out);
+    HIPCHK(hipGetLastError());
+    return download(paths_out, d_out, out_bytes, g.stream);
+}
+int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out) { return sc_merkle_open_batch(tree, &index, 1, path_out); }
+uint64_t sc_merkle_leaves(const sc_merkle_t* tree) { return tree ? tree->N : 0; }
+int sc_merkle_free(sc_merkle_t* tree) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!tree) return SC_OK;
+    hipStreamSynchronize(g.stream);
+    hipFree(tree->d_levels);
+    delete tree;
+    return SC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+"""FRI low-degree test -- host orchestration over device-resident codewords.
+
+Interface of reference code/fri.py:11-231 (`Fri(offset, omega, initial_domain_length, expansion_factor,
+num_colinearity_tests)` with num_rounds / sample_index / sample_indices / eval_domain / commit / query /
+prove / verify).  What moved to the GPU: the split-and-fold of fri.py:85, the Merkle commitment of every
+round (fri.py:71) and the authentication paths of the query phase (fri.py:108-111), served from trees
+that stay in HBM.  The Fiat-Shamir transcript (ip.py) stays on the host and is byte-identical, so alphas
+and query indices match the reference.
+"""
+from hashlib import blake2b
+
+from algebra import *
+from merkle import *
+from ip import *
+from ntt import *
+from univariate import *
+import starkcore as _sc
+from starkcore import DeviceCodeword, DeviceVector
+
+
+class Fri:
+    def __init__(self, offset, omega, initial_domain_length, expansion_factor, num_colinearity_tests):
+        self.offset = offset
+        self.omega = omega
+        self.domain_length = initial_domain_length
+        self.field = omega.field
+        self.expansion_factor = expansion_factor
+        self.num_colinearity_tests = num_colinearity_tests
+        assert(self.num_rounds() >= 1), "cannot do FRI with less than one round"
+
+    def num_rounds(self):
+        # halve while the codeword is longer than the expansion factor and 4x the number of tests (fri.py:22-28)
+        length, rounds = self.domain_length, 0
+        while length > self.expansion_factor and 4 * self.num_colinearity_tests < length:
+            length /= 2
+            rounds += 1
+        return rounds
+
+    def sample_index(byte_array, size):
+        acc = 0
+        for b in byte_array:
+            acc = (acc << 8) ^ int(b)
+        return acc % size
+
+    def sample_indices(self, seed, size, reduced_size, number):
+        assert(number <= reduced_size), f"cannot sample more indices than available in last codeword; requested: {number}, available: {reduced_size}"
+        assert(number <= 2 * reduced_size), "not enough entropy in indices wrt last codeword"
+        indices, taken, counter = [], set(), 0
+        while len(indices) < number:
+            # bytes(counter) is `counter` zero bytes (fri.py:44), not an encoding of the counter
+            index = Fri.sample_index(blake2b(seed + bytes(counter)).digest(), size)
+            counter += 1
+            if index % reduced_size not in taken:
+                taken.add(index % reduced_size)
+                indices.append(index)
+        return indices
+
+    def eval_domain(self):
+        return [self.offset * (self.omega ^ i) for i in range(self.domain_length)]
+
+    def _on_device(self, codeword):
+        if isinstance(codeword, DeviceCodeword):
+            return codeword
+        return DeviceCodeword.from_list(codeword, self.field)
+
+    def commit(self, codeword, proof_stream, round_index=0):
+        omega, offset = self.omega, self.offset
+        codeword = self._on_device(codeword)
+        codewords = []
+        rounds = self.num_rounds()
+        for r in range(rounds):
+            N = len(codeword)
+            assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
+            # Merkle root of this round's codeword; the tree stays in HBM for the query phase
+            proof_stream.push(codeword.tree().root)
+            if r == rounds - 1:
+                break
+            alpha = self.field.sample(proof_stream.prover_fiat_shamir())
+            codewords.append(codeword)
+            folded = DeviceVector(N // 2)
+            _sc._check(_sc.lib().sc_fri_fold_dev(codeword.vec.ptr, N, _sc.fe_bytes(alpha.value), _sc.fe_bytes(offset.value),
+                                                 _sc.fe_bytes(omega.value), folded.ptr, None))
+            codeword = DeviceCodeword(folded, self.field)
+            omega = omega ^ 2
+            offset = offset ^ 2
+        # the last codeword goes out in the clear, as a plain list (it is pickled into the transcript)
+        proof_stream.push(codeword.tolist())
+        codewords.append(codeword)
+        return codewords
+
+    def query(self, current_codeword, next_codeword, c_indices, proof_stream):
+        current_codeword = self._on_device(current_codeword)
+        next_codeword = self._on_device(next_codeword)
+        s = self.num_colinearity_tests
+        a_indices = [index for index in c_indices]
+        b_indices = [index + len(current_codeword) // 2 for index in c_indices]
+        ab = current_codeword.gather(a_indices + b_indices)
+        cs = next_codeword.gather(c_indices)
+        for i in range(s):
+            proof_stream.push((ab[i], ab[len(a_indices) + i], cs[i]))
+        ab_paths = current_codeword.tree().open_batch(a_indices[:s] + b_indices[:s])
+        c_paths = next_codeword.tree().open_batch(c_indices[:s])
+        for i in range(s):
+            proof_stream.push(ab_paths[i])
+            proof_stream.push(ab_paths[s + i])
+            proof_stream.push(c_paths[i])
+        return a_indices + b_indices
+
+    def prove(self, codeword, proof_stream):
+        assert(self.domain_length == len(codeword)), "initial codeword length does not match length of initial codeword"
+        codewords = self.commit(codeword, proof_stream)
+        top_level_indices = self.sample_indices(proof_stream.prover_fiat_shamir(), len(codewords[0]) // 2, len(codewords[-1]), self.num_colinearity_tests)
+        indices = [index for index in top_level_indices]
+        for i in range(len(codewords) - 1):
+            indices = [index % (len(codewords[i]) // 2) for index in indices]
+            self.query(codewords[i], codewords[i + 1], indices, proof_stream)
+        return top_level_indices
+
+    def _last_codeword_degree(self, last_codeword, last_omega, last_offset):
+        """Degree of the interpolant of the last codeword on its coset: intt + unscale (the route the
+        reference's fri.py:165-166 / docs describe) -- same unique polynomial as Lagrange at fri.py:164."""
+        coefficients = intt(last_omega, last_codeword)
+        poly = Polynomial(coefficients).scale(last_offset.inverse())
+        assert(fast_coset_evaluate(poly, last_offset, last_omega, len(last_codeword)) == last_codeword), "re-evaluated codeword does not match original!"
+        return poly.degree()
+
+    def verify(self, proof_stream, polynomial_values):
+        omega, offset = self.omega, self.offset
+        rounds = self.num_rounds()
+        roots, alphas = [], []
+        for r in range(rounds):
+            roots.append(proof_stream.pull())
+            alphas.append(self.field.sample(proof_stream.verifier_fiat_shamir()))
+        last_codeword = proof_stream.pull()
+        if roots[-1] != Merkle.commit(last_codeword):
+            print("last codeword is not well formed")
+            return False
+        degree = (len(last_codeword) // self.expansion_factor) - 1
+        last_omega, last_offset = omega, offset
+        for r in range(rounds - 1):
+            last_omega = last_omega ^ 2
+            last_offset = last_offset ^ 2
+        assert(last_omega.inverse() == last_omega ^ (len(last_codeword) - 1)), "omega does not have right order"
+        observed = self._last_codeword_degree(last_codeword, last_omega, last_offset)
+        if observed > degree:
+            print("last codeword does not correspond to polynomial of low enough degree")
+            print("observed degree:", observed)
+            print("but should be:", degree)
+            return False
+        top_level_indices = self.sample_indices(proof_stream.verifier_fiat_shamir(), self.domain_length >> 1,
+                                                self.domain_length >> (rounds - 1), self.num_colinearity_tests)
+        s = self.num_colinearity_tests
+        for r in range(0, rounds - 1):
+            half = self.domain_length >> (r + 1)
+            c_indices = [index % half for index in top_level_indices]
+            a_indices = c_indices
+            b_indices = [index + half for index in a_indices]
+            triples = [proof_stream.pull() for _ in range(s)]
+            for i, (ay, by, cy) in enumerate(triples):
+                if r == 0:
+                    polynomial_values += [(a_indices[i], ay), (b_indices[i], by)]
+                ax = offset * (omega ^ a_indices[i])
+                bx = offset * (omega ^ b_indices[i])
+                if test_colinearity([(ax, ay), (bx, by), (alphas[r], cy)]) == False:
+                    print("colinearity check failure")
+                    return False
+            for i, (ay, by, cy) in enumerate(triples):
+                if Merkle.verify(roots[r], a_indices[i], proof_stream.pull(), ay) == False:
+                    print("merkle authentication path verification fails for aa")
+                    return False
+                if Merkle.verify(roots[r], b_indices[i], proof_stream.pull(), by) == False:
+                    print("merkle authentication path verification fails for bb")
+                    return False
+                if Merkle.verify(roots[r + 1], c_indices[i], proof_stream.pull(), cy) == False:
+                    print("merkle authentication path verification fails for cc")
+                    return False
+            omega = omega ^ 2
+            offset = offset ^ 2
+        return True

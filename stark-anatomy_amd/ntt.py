@@ -1,0 +1,183 @@
+"""NTT-based polynomial arithmetic -- host shim over the HIP kernels (libstarkcore.so).
+
+Same callables, argument meaning, assertion messages and list-length conventions as the reference's
+code/ntt.py (ntt :3, intt :20, fast_multiply :32, fast_zerofier :66, fast_evaluate :82,
+fast_interpolate :102, fast_coset_evaluate :132, fast_coset_divide :137); the transforms, the coset
+scaling, the Hadamard product / pointwise division and the truncations run on the MI355X.
+
+`list[FieldElement]` in -> new `list[FieldElement]` out (arguments are never mutated).  The *_device
+variants take/return `DeviceCodeword` (data stays in HBM; no per-element marshalling) and are what
+fri.py / bench.py use for large domains.
+"""
+import ctypes
+
+from univariate import *
+import starkcore as _sc
+from starkcore import DeviceCodeword, DeviceVector
+
+_ROOT_ORDER_MSG = "supplied root does not have supplied order"
+_ROOT_PRIM_MSG = "supplied root is not primitive root of supplied order"
+
+
+def _pack(elements):
+    return b"".join(e.value.to_bytes(16, "little") for e in elements)
+
+
+def _unpack(raw, count, field):
+    frm = int.from_bytes
+    return [FieldElement(frm(raw[16 * i:16 * i + 16], "little"), field) for i in range(count)]
+
+
+def _check_root(primitive_root, root_order):
+    assert(primitive_root ^ root_order == primitive_root.field.one()), _ROOT_ORDER_MSG
+    assert(primitive_root ^ (root_order // 2) != primitive_root.field.one()), _ROOT_PRIM_MSG
+
+
+def _transform(primitive_root, values, inverse):
+    n = len(values)
+    field = values[0].field
+    if isinstance(values, DeviceCodeword):
+        out = DeviceVector(n)
+        _sc._check(_sc.lib().sc_ntt_dev(values.vec.ptr, out.ptr, n, _sc.fe_bytes(primitive_root.value), inverse, None))
+        return DeviceCodeword(out, field)
+    out = ctypes.create_string_buffer(16 * n)
+    _sc._check(_sc.lib().sc_ntt(_pack(values), out, n, _sc.fe_bytes(primitive_root.value), inverse))
+    return _unpack(out.raw, n, field)
+
+
+def ntt(primitive_root, values):
+    assert(len(values) & (len(values) - 1) == 0), "cannot compute ntt of non-power-of-two sequence"
+    if len(values) <= 1:
+        return values
+    field = values[0].field
+    assert(primitive_root ^ len(values) == field.one()), "primitive root must be nth root of unity, where n is len(values)"
+    assert(primitive_root ^ (len(values) // 2) != field.one()), "primitive root is not primitive nth root of unity, where n is len(values)"
+    return _transform(primitive_root, values, 0)
+
+
+def intt(primitive_root, values):
+    assert(len(values) & (len(values) - 1) == 0), "cannot compute intt of non-power-of-two sequence"
+    if len(values) == 1:
+        return values
+    field = values[0].field
+    # the reference runs ntt(root^-1, .) and so inherits its root checks (ntt.py:27-29, :10-11)
+    assert(primitive_root ^ len(values) == field.one()), "primitive root must be nth root of unity, where n is len(values)"
+    assert(primitive_root ^ (len(values) // 2) != field.one()), "primitive root is not primitive nth root of unity, where n is len(values)"
+    return _transform(primitive_root, values, 1)
+
+
+def _shrink_order(root, order, degree):
+    # smallest power-of-two transform that still holds `degree+1` coefficients (ntt.py:47-49, :155-157)
+    while degree < order // 2:
+        root = root ^ 2
+        order = order // 2
+    return root, order
+
+
+def fast_multiply(lhs, rhs, primitive_root, root_order):
+    _check_root(primitive_root, root_order)
+    if lhs.is_zero() or rhs.is_zero():
+        return Polynomial([])
+    field = lhs.coefficients[0].field
+    dl, dr = lhs.degree(), rhs.degree()
+    degree = dl + dr
+    if degree < 8:
+        return lhs * rhs
+    root, order = _shrink_order(primitive_root, root_order, degree)
+    out = ctypes.create_string_buffer(16 * (degree + 1))
+    _sc._check(_sc.lib().sc_poly_mul(_pack(lhs.coefficients[:dl + 1]), dl + 1, _pack(rhs.coefficients[:dr + 1]), dr + 1,
+                                     _sc.fe_bytes(root.value), order, out, degree + 1))
+    return Polynomial(_unpack(out.raw, degree + 1, field))
+
+
+def fast_zerofier(domain, primitive_root, root_order):
+    _check_root(primitive_root, root_order)
+    if len(domain) == 0:
+        return Polynomial([])
+    if len(domain) == 1:
+        return Polynomial([-domain[0], primitive_root.field.one()])
+    half = len(domain) // 2
+    return fast_multiply(fast_zerofier(domain[:half], primitive_root, root_order),
+                         fast_zerofier(domain[half:], primitive_root, root_order), primitive_root, root_order)
+
+
+def fast_evaluate(polynomial, domain, primitive_root, root_order):
+    _check_root(primitive_root, root_order)
+    if len(domain) == 0:
+        return []
+    if len(domain) == 1:
+        return [polynomial.evaluate(domain[0])]
+    half = len(domain) // 2
+    lower, upper = domain[:half], domain[half:]
+    lower_rem = polynomial % fast_zerofier(lower, primitive_root, root_order)
+    upper_rem = polynomial % fast_zerofier(upper, primitive_root, root_order)
+    return fast_evaluate(lower_rem, lower, primitive_root, root_order) + fast_evaluate(upper_rem, upper, primitive_root, root_order)
+
+
+def fast_interpolate(domain, values, primitive_root, root_order):
+    _check_root(primitive_root, root_order)
+    assert(len(domain) == len(values)), "cannot interpolate over domain of different length than values list"
+    if len(domain) == 0:
+        return Polynomial([])
+    if len(domain) == 1:
+        return Polynomial([values[0]])
+    half = len(domain) // 2
+    lower, upper = domain[:half], domain[half:]
+    lower_zerofier = fast_zerofier(lower, primitive_root, root_order)
+    upper_zerofier = fast_zerofier(upper, primitive_root, root_order)
+    # each half is interpolated against values divided by the OTHER half's zerofier there (ntt.py:121-125)
+    lower_offset = fast_evaluate(upper_zerofier, lower, primitive_root, root_order)
+    upper_offset = fast_evaluate(lower_zerofier, upper, primitive_root, root_order)
+    if not all(not v.is_zero() for v in lower_offset):
+        print("left_offset:", " ".join(str(v) for v in lower_offset))
+    lower_targets = [n / d for (n, d) in zip(values[:half], lower_offset)]
+    upper_targets = [n / d for (n, d) in zip(values[half:], upper_offset)]
+    lower_interpolant = fast_interpolate(lower, lower_targets, primitive_root, root_order)
+    upper_interpolant = fast_interpolate(upper, upper_targets, primitive_root, root_order)
+    return lower_interpolant * upper_zerofier + upper_interpolant * lower_zerofier
+
+
+def fast_coset_evaluate_device(polynomial, offset, generator, order):
+    """fast_coset_evaluate with the result left in HBM as a DeviceCodeword."""
+    coeffs = polynomial.coefficients
+    m = len(coeffs)
+    out = DeviceVector(order)
+    src = DeviceVector.from_bytes(_pack(coeffs)) if m else DeviceVector(1)
+    _sc._check(_sc.lib().sc_coset_evaluate_dev(src.ptr, m, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out.ptr, None))
+    _sc.synchronize()
+    return DeviceCodeword(out, offset.field)
+
+
+def fast_coset_evaluate(polynomial, offset, generator, order):
+    coeffs = polynomial.coefficients
+    m = len(coeffs)
+    if order <= 1 or m > order:
+        # degenerate shapes: follow the reference's own formula on the host
+        padded = polynomial.scale(offset).coefficients + [offset.field.zero()] * (order - m)
+        return ntt(generator, padded)
+    assert(order & (order - 1) == 0), "cannot compute ntt of non-power-of-two sequence"
+    field = offset.field
+    assert(generator ^ order == field.one()), "primitive root must be nth root of unity, where n is len(values)"
+    assert(generator ^ (order // 2) != field.one()), "primitive root is not primitive nth root of unity, where n is len(values)"
+    out = ctypes.create_string_buffer(16 * order)
+    _sc._check(_sc.lib().sc_coset_evaluate(_pack(coeffs), m, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out))
+    return _unpack(out.raw, order, field)
+
+
+def fast_coset_divide(lhs, rhs, offset, primitive_root, root_order):  # clean division only!
+    _check_root(primitive_root, root_order)
+    assert(not rhs.is_zero()), "cannot divide by zero polynomial"
+    if lhs.is_zero():
+        return Polynomial([])
+    dl, dr = lhs.degree(), rhs.degree()
+    assert(dr <= dl), "cannot divide by polynomial of larger degree"
+    field = lhs.coefficients[0].field
+    degree = max(dl, dr)
+    if degree < 8:
+        return lhs / rhs
+    root, order = _shrink_order(primitive_root, root_order, degree)
+    n_out = dl - dr + 1
+    out = ctypes.create_string_buffer(16 * n_out)
+    _sc._check(_sc.lib().sc_coset_divide(_pack(lhs.coefficients[:dl + 1]), dl + 1, _pack(rhs.coefficients[:dr + 1]), dr + 1,
+                                         _sc.fe_bytes(offset.value), _sc.fe_bytes(root.value), order, out, n_out))
+    return Polynomial(_unpack(out.raw, n_out, field))

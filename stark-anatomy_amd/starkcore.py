@@ -1,0 +1,287 @@
+"""ctypes binding of libstarkcore.so (include/starkcore.h) plus the device-resident codeword type.
+
+This is the ONLY path from the host modules (ntt.py, fri.py, merkle.py) to the GPU.  There is no CPU
+fallback: if the shared library is missing or no MI355X is visible, calls raise RuntimeError.
+"""
+import ctypes
+import os
+from collections.abc import Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libstarkcore.so")
+
+_u64 = ctypes.c_uint64
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+SC_ERR_NOT_POW2 = -2
+SC_ERR_ROOT_ORDER = -3
+SC_ERR_ROOT_NOT_PRIMITIVE = -4
+SC_ERR_DIV_ZERO = -5
+
+# every symbol include/starkcore.h declares: (restype, argtypes)
+SIGNATURES = {
+    "sc_device_count": (_int, []),
+    "sc_init": (_int, [_int]),
+    "sc_shutdown": (_int, []),
+    "sc_last_error": (ctypes.c_char_p, []),
+    "sc_synchronize": (_int, []),
+    "sc_set_tuning": (_int, [ctypes.c_char_p, _int]),
+    "sc_vec_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
+    "sc_vec_free": (_int, [_vp]),
+    "sc_vec_len": (_u64, [_vp]),
+    "sc_vec_ptr": (_vp, [_vp]),
+    "sc_vec_upload": (_int, [_vp, _u64, _vp, _u64]),
+    "sc_vec_download": (_int, [_vp, _u64, _vp, _u64]),
+    "sc_vec_gather": (_int, [_vp, _vp, _u64, _vp]),
+    "sc_ntt": (_int, [_vp, _vp, _u64, _vp, _int]),
+    "sc_ntt_dev": (_int, [_vp, _vp, _u64, _vp, _int, _vp]),
+    "sc_coset_evaluate": (_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
+    "sc_coset_evaluate_dev": (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
+    "sc_poly_mul": (_int, [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64]),
+    "sc_coset_divide": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64]),
+    "sc_pointwise_mul_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "sc_pointwise_div_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "sc_scale_dev": (_int, [_vp, _vp, _u64, _vp, _vp]),
+    "sc_fri_fold": (_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
+    "sc_fri_fold_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "sc_merkle_commit": (_int, [_vp, _u64, _vp]),
+    "sc_merkle_build": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp)]),
+    "sc_merkle_build_dev": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp), _vp]),
+    "sc_merkle_open": (_int, [_vp, _u64, _vp]),
+    "sc_merkle_open_batch": (_int, [_vp, _vp, _u64, _vp]),
+    "sc_merkle_leaves": (_u64, [_vp]),
+    "sc_merkle_free": (_int, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if the HIP extension was not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError("libstarkcore.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C stark-anatomy_amd/csrc` (the HIP extension is mandatory, there is no CPU fallback)")
+        l = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+class StarkCoreError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    """Map a negative return code to the exception the reference's `assert` would have raised."""
+    if rc == 0:
+        return
+    msg = lib().sc_last_error().decode(errors="replace")
+    if rc in (SC_ERR_NOT_POW2, SC_ERR_ROOT_ORDER, SC_ERR_ROOT_NOT_PRIMITIVE, SC_ERR_DIV_ZERO):
+        raise AssertionError(msg)
+    raise StarkCoreError("starkcore error %d: %s" % (rc, msg))
+
+
+def device_count():
+    return lib().sc_device_count()
+
+
+def init(device=-1):
+    _check(lib().sc_init(device))
+
+
+def set_tuning(key, value):
+    _check(lib().sc_set_tuning(key.encode(), int(value)))
+
+
+def synchronize():
+    _check(lib().sc_synchronize())
+
+
+def fe_bytes(v):
+    """int residue -> 16 little-endian bytes (the ABI's element layout)."""
+    return int(v).to_bytes(16, "little")
+
+
+def pack(values):
+    """iterable of ints -> packed bytes."""
+    return b"".join(int(v).to_bytes(16, "little") for v in values)
+
+
+def unpack(buf, count=None):
+    mv = bytes(buf)
+    if count is None:
+        count = len(mv) // 16
+    frm = int.from_bytes
+    return [frm(mv[16 * i:16 * i + 16], "little") for i in range(count)]
+
+
+# ------------------------------------------------------------------------------------------------
+class DeviceVector:
+    """Owner of an sc_vec_t (device-resident field elements)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        h = _vp()
+        _check(lib().sc_vec_alloc(self.n, ctypes.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_bytes(cls, data):
+        v = cls(len(data) // 16)
+        if v.n:
+            _check(lib().sc_vec_upload(v._h, 0, bytes(data), v.n))
+        return v
+
+    @classmethod
+    def from_ints(cls, values):
+        return cls.from_bytes(pack(values))
+
+    @property
+    def ptr(self):
+        return lib().sc_vec_ptr(self._h)
+
+    def to_bytes(self, offset=0, count=None):
+        count = self.n - offset if count is None else count
+        out = ctypes.create_string_buffer(16 * count if count else 16)
+        if count:
+            _check(lib().sc_vec_download(self._h, offset, out, count))
+        return out.raw[:16 * count]
+
+    def gather(self, indices):
+        k = len(indices)
+        if k == 0:
+            return []
+        idx = (ctypes.c_uint64 * k)(*[int(i) for i in indices])
+        out = ctypes.create_string_buffer(16 * k)
+        _check(lib().sc_vec_gather(self._h, idx, k, out))
+        return unpack(out.raw, k)
+
+    def free(self):
+        if self._h is not None and _lib is not None:
+            _lib.sc_vec_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MerkleTree:
+    """Owner of an sc_merkle_t: all levels resident in HBM, so `open` is a gather (code/merkle.py:16-27)."""
+
+    def __init__(self, handle, root, n):
+        self._h = handle
+        self.root = root
+        self.n = n
+        self.depth = n.bit_length() - 1
+
+    @classmethod
+    def from_device(cls, vec):
+        root = ctypes.create_string_buffer(64)
+        h = _vp()
+        _check(lib().sc_merkle_build_dev(vec.ptr, vec.n, root, ctypes.byref(h), None))
+        return cls(h, root.raw, vec.n)
+
+    @classmethod
+    def from_bytes(cls, data):
+        n = len(data) // 16
+        root = ctypes.create_string_buffer(64)
+        h = _vp()
+        _check(lib().sc_merkle_build(bytes(data), n, root, ctypes.byref(h)))
+        return cls(h, root.raw, n)
+
+    def open_batch(self, indices):
+        k = len(indices)
+        for i in indices:
+            assert 0 <= i < self.n, "cannot open invalid index"
+        if k == 0:
+            return []
+        idx = (ctypes.c_uint64 * k)(*[int(i) for i in indices])
+        out = ctypes.create_string_buffer(64 * self.depth * k)
+        _check(lib().sc_merkle_open_batch(self._h, idx, k, out))
+        raw = out.raw
+        d = self.depth
+        return [[raw[64 * (q * d + l):64 * (q * d + l + 1)] for l in range(d)] for q in range(k)]
+
+    def open(self, index):
+        return self.open_batch([index])[0]
+
+    def free(self):
+        if self._h is not None and _lib is not None:
+            _lib.sc_merkle_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceCodeword(Sequence):
+    """A list-like view of a device-resident codeword.
+
+    Behaves like the `list[FieldElement]` the reference passes around (len, indexing, iteration,
+    equality with lists) but keeps the data in HBM; `Fri` and `Merkle` recognise it and stay on the
+    device.  Elements are materialised as FieldElement only when asked for.
+    """
+
+    def __init__(self, vec, field):
+        self.vec = vec
+        self.field = field
+        self._tree = None
+        self._cache = None
+
+    # -- construction helpers
+    @classmethod
+    def from_list(cls, values, field):
+        return cls(DeviceVector.from_ints(v.value for v in values), field)
+
+    def __len__(self):
+        return self.vec.n
+
+    def _fe(self, v):
+        from algebra import FieldElement
+        return FieldElement(v, self.field)
+
+    def tolist(self):
+        if self._cache is None:
+            self._cache = [self._fe(v) for v in unpack(self.vec.to_bytes(), self.vec.n)]
+        return self._cache
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.tolist()[i]
+        if self._cache is not None:
+            return self._cache[i]
+        n = self.vec.n
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("codeword index out of range")
+        return self._fe(self.vec.gather([i])[0])
+
+    def gather(self, indices):
+        return [self._fe(v) for v in self.vec.gather(indices)]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __eq__(self, other):
+        if isinstance(other, DeviceCodeword):
+            return self.vec.to_bytes() == other.vec.to_bytes()
+        return self.tolist() == list(other)
+
+    __hash__ = None
+
+    def tree(self):
+        if self._tree is None:
+            self._tree = MerkleTree.from_device(self.vec)
+        return self._tree

@@ -3,7 +3,7 @@
 SURVEY.md §8(d): ``lo = splitmix64(seed + 2i)``, ``hi = splitmix64(seed + 2i + 1)``,
 ``x_i = (hi * 2**64 + lo) mod p``.  Mirrors the distribution the reference tests draw with
 ``field.sample(os.urandom(17))`` (code/test_ntt.py:12) but reproducibly, and identically in
-Python, numpy and C (oracle/stark_oracle.c: so_synth).
+Python, numpy and C (the test oracle has its own copy).
 
 Packed layout everywhere: one element = 16 bytes = two little-endian uint64 limbs (lo, hi),
 canonical residue in [0, p).

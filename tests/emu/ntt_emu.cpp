@@ -1,0 +1,82 @@
+// CPU emulation of the tiled NTT kernels: runs the SAME round body (csrc/ntt_tile.cuh) and the SAME
+// planner (csrc/ntt_plan.h) the HIP library uses, one workgroup at a time, one thread id at a time,
+// rounds separated exactly where the kernel has its barriers.  Lets the index/twiddle logic be checked
+// against the oracle in the CPU-only container.  Test infrastructure (built by tests/test_emu.py).
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../stark-anatomy_amd/csrc/ntt_plan.h"
+
+using namespace sc;
+
+static void fill_table(std::vector<Fe>& t, uint64_t count, Fe base_m, uint64_t step, Fe scale_m) {
+    t.resize(count ? count : 1);
+    for (uint64_t i = 0; i < count; ++i) t[i] = pow_table_entry(base_m, i, step, scale_m);
+}
+
+template <int LOGE>
+static void run_pass(const NttPassDesc& pd) {
+    const PassParams& P = pd.p;
+    std::vector<Fe> lds((size_t)1 << (P.logR + P.logC));
+    RoundSched rs = make_rounds(P.logR, LOGE);
+    for (uint32_t tile = 0; tile < pd.ntiles; ++tile)
+        for (int r = 0; r < rs.nrounds; ++r)
+            for (uint32_t tid = 0; tid < pd.threads; ++tid)
+                ntt_round_dispatch<LOGE>(P, rs.s[r], rs.sh[r], r == 0, tile, tid, lds.data());
+}
+
+extern "C" int emu_ntt(const uint64_t* in, uint64_t* out, int logn, const uint64_t* root, int inverse, uint64_t in_limit,
+                       const uint64_t* offset, int max_tile_log, int loge, int single_pass_max_log, int min_tiles_log, int max_col_log, int max_digit_log) {
+    const uint64_t n = 1ull << logn;
+    Fe r = Fe{root[0], root[1]};
+    Fe r_m = to_mont(r);
+    Fe scale_m = fe_mont_one();
+    if (inverse) {
+        r_m = mont_pow(r_m, n - 1);                       // root^-1 = root^(n-1)
+        scale_m = mont_inv(to_mont(Fe{n, 0}));            // n^-1
+    }
+    NttTuning tu;
+    tu.max_tile_log = max_tile_log; tu.loge = loge; tu.single_pass_max_log = single_pass_max_log;
+    tu.min_tiles_log = min_tiles_log; tu.max_col_log = max_col_log; tu.max_digit_log = max_digit_log;
+    const int m = plan_num_passes(logn, tu);
+    NttTables tb;
+    std::vector<Fe> mt, tl, th, ths, ol, oh;
+    tb.mt_log = logn < 12 ? logn : 12;
+    fill_table(mt, 1ull << (tb.mt_log - 1), r_m, n >> tb.mt_log, fe_mont_one());
+    fill_table(tl, n < 4096 ? n : 4096, r_m, 1, fe_mont_one());
+    fill_table(th, n > 4096 ? n >> 12 : 1, r_m, 4096, fe_mont_one());
+    fill_table(ths, n > 4096 ? n >> 12 : 1, r_m, 4096, scale_m);
+    tb.mt = mt.data(); tb.tl = tl.data(); tb.th = th.data(); tb.th_scaled = (inverse && m > 1) ? ths.data() : nullptr;
+    std::vector<Fe> work(n);
+    NttIo io;
+    io.in = (const Fe*)in; io.work = work.data(); io.out = (Fe*)out;
+    io.in_limit = in_limit;
+    if (offset) {
+        Fe o_m = to_mont(Fe{offset[0], offset[1]});
+        uint64_t cnt = in_limit < n ? in_limit : n;
+        fill_table(ol, 4096, o_m, 1, fe_mont_one());
+        fill_table(oh, (cnt >> 12) + 1, o_m, 4096, fe_mont_one());
+        io.ol = ol.data(); io.oh = oh.data();
+    }
+    io.scale_last = inverse && m == 1;
+    io.scale = scale_m;
+    NttPlanDesc d;
+    if (!plan_ntt(d, logn, tb, io, tu)) return -1;
+    for (int i = 0; i < d.npasses; ++i) {
+        switch (d.pass[i].loge) {
+            case 1: run_pass<1>(d.pass[i]); break;
+            case 2: run_pass<2>(d.pass[i]); break;
+            case 3: run_pass<3>(d.pass[i]); break;
+            case 4: run_pass<4>(d.pass[i]); break;
+            default: return -2;
+        }
+    }
+    return d.npasses;
+}
+
+extern "C" void emu_field(const uint64_t* a, const uint64_t* b, uint64_t* out /* 7 x 2 limbs */) {
+    Fe x{a[0], a[1]}, y{b[0], b[1]};
+    Fe r[7] = {fe_add(x, y), fe_sub(x, y), fe_mul(x, y), from_mont(mont_inv(to_mont(x))), fe_half(x), fe_neg(x), mont_mul(x, to_mont(y))};
+    memcpy(out, r, sizeof r);
+}

