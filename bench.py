@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2n", type=int, default=None, help="override the transform size")
-    ap.add_argument("--cpu-sample-log2n", type=int, default=14)
+    ap.add_argument("--cpu-sample-log2n", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,8 +94,11 @@ def main():
             r, order = r * r % P, order >> 1
         return r
 
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-null) HIP stream: the library launches on it and the timing events are recorded on it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     sptr = ctypes_void(stream.cuda_stream)
+    assert stream.cuda_stream != 0
 
     if world == 1:
         log2n = args.log2n or 20

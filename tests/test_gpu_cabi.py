@@ -181,15 +181,19 @@ def test_poly_mul_and_divide(sc):
         quo = ctypes.create_string_buffer(16 * lb)
         sc._check(lib.sc_coset_divide(out.raw, n_out, synth.pack_ints(a), la, sc.fe_bytes(po.GENERATOR), sc.fe_bytes(root), order, quo, lb))
         assert synth.unpack_ints(quo.raw) == b, (la, lb)
-    # a divisor that vanishes on the coset -> "divide by zero" (algebra.py:92)
+    # a divisor that vanishes on the coset -> "divide by zero" (algebra.py:92): (X - g) is zero at the first coset point g*w^0
     order = 16
     root = po.primitive_nth_root(order)
-    zero_at_offset = [(-po.GENERATOR) % P, 1] + [0] * 7 + [0]          # (X - g): zero at the first coset point
-    lhs = po.schoolbook_mul(zero_at_offset[:2], synth.synth_ints(5, 9))
+    divisor = [(-po.GENERATOR) % P, 1]
+    lhs = po.schoolbook_mul(divisor, synth.synth_ints(5, 9))
     quo = ctypes.create_string_buffer(16 * 9)
     with pytest.raises(AssertionError):
-        sc._check(lib.sc_coset_divide(synth.pack_ints(lhs), len(lhs), synth.pack_ints(zero_at_offset[:2] + [0] * 7 + [1]), 10,
-                                      sc.fe_bytes(po.GENERATOR), sc.fe_bytes(root), order, quo, 1))
+        sc._check(lib.sc_coset_divide(synth.pack_ints(lhs), len(lhs), synth.pack_ints(divisor), 2,
+                                      sc.fe_bytes(po.GENERATOR), sc.fe_bytes(root), order, quo, 9))
+    # and the library still works afterwards
+    sc._check(lib.sc_coset_divide(synth.pack_ints(lhs), len(lhs), synth.pack_ints(divisor), 2,
+                                  sc.fe_bytes(3), sc.fe_bytes(root), order, quo, 9))
+    assert synth.unpack_ints(quo.raw) == synth.synth_ints(5, 9)
 
 
 def test_golden_multiply_divide_via_cabi_sizes(sc):
