@@ -6,8 +6,8 @@
 namespace sc {
 
 struct NttTuning {
-    int max_tile_log = 12;   // LDS tile = 2^max_tile_log elements (64 KiB at 12)
-    int loge = 3;            // elements per thread = 2^loge
+    int max_tile_log = 11;   // LDS tile = 2^max_tile_log elements (32 KiB at 11); measured best 10-11 (tools/sweep.py)
+    int loge = 2;            // elements per thread = 2^loge; 2 measured best (occupancy beats register blocking here)
     int max_col_log = 6;     // at most 64 columns (1 KiB runs)
     int min_tiles_log = 10;  // shrink tiles until there are at least this many per pass (fill 256 CUs)
     int single_pass_max_log = 11;

@@ -233,16 +233,25 @@ class DeviceCodeword(Sequence):
     device.  Elements are materialised as FieldElement only when asked for.
     """
 
-    def __init__(self, vec, field):
+    def __init__(self, vec, field, elements=None):
         self.vec = vec
         self.field = field
         self._tree = None
-        self._cache = None
+        # index -> FieldElement.  Identity matters: the Fiat-Shamir transcript is pickle.dumps(objects)
+        # (code/ip.py:18-25) and pickle memoises by object identity; the reference pushes the SAME
+        # FieldElement object when a codeword entry appears twice (last codeword + query triple, or the `c`
+        # of one round and the `a`/`b` of the next: code/fri.py:91,104-105), so entries are created once.
+        self._elems = {}
+        self._full = None
+        if elements is not None:
+            self._full = elements
+            self._elems = None
 
     # -- construction helpers
     @classmethod
     def from_list(cls, values, field):
-        return cls(DeviceVector.from_ints(v.value for v in values), field)
+        values = list(values)
+        return cls(DeviceVector.from_ints(v.value for v in values), field, elements=values)
 
     def __len__(self):
         return self.vec.n
@@ -252,24 +261,33 @@ class DeviceCodeword(Sequence):
         return FieldElement(v, self.field)
 
     def tolist(self):
-        if self._cache is None:
-            self._cache = [self._fe(v) for v in unpack(self.vec.to_bytes(), self.vec.n)]
-        return self._cache
+        if self._full is None:
+            known = self._elems
+            ints = unpack(self.vec.to_bytes(), self.vec.n)
+            self._full = [known[i] if i in known else self._fe(v) for i, v in enumerate(ints)]
+            self._elems = None
+        return self._full
 
     def __getitem__(self, i):
         if isinstance(i, slice):
             return self.tolist()[i]
-        if self._cache is not None:
-            return self._cache[i]
         n = self.vec.n
         if i < 0:
             i += n
         if not 0 <= i < n:
             raise IndexError("codeword index out of range")
-        return self._fe(self.vec.gather([i])[0])
+        return self.gather([i])[0]
 
     def gather(self, indices):
-        return [self._fe(v) for v in self.vec.gather(indices)]
+        """Entries at `indices` (one D2H gather for the ones not materialised yet)."""
+        if self._full is not None:
+            return [self._full[i] for i in indices]
+        known = self._elems
+        missing = [i for i in dict.fromkeys(indices) if i not in known]
+        if missing:
+            for i, v in zip(missing, self.vec.gather(missing)):
+                known[i] = self._fe(v)
+        return [known[i] for i in indices]
 
     def __iter__(self):
         return iter(self.tolist())
