@@ -122,14 +122,14 @@ def main():
         n = 1 << log2n
         eng = ShardedNtt(log2n, nth_root(n), rank, world, dev)
         x = eng.synthetic_input(seed=1)
-        y = torch.empty_like(x)
+        y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
         z = torch.empty_like(x)
 
         def step():
             eng.forward(x, y)
             eng.inverse(y, z)
 
-        launches_per_step = eng.launches_per_transform * 2
+        launches_per_step = 2      # N > 1: roofline is reported per whole transform (local passes + twiddle + all-to-all)
         workload = "ntt_fwd_inv_2^%d_fourstep_%dgpu" % (log2n, world)
         total_n = n
         parallelism = "four-step, column-sharded, 1 all-to-all per transform"
@@ -168,7 +168,11 @@ def main():
         # algorithmic bytes per launch = 32 B/element/transform * n elements / passes-per-transform
         passes = launches_per_step // 2
         avg_launch_s = (ev_ms * 1e-3) / (args.steps * launches_per_step)
-        alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * (total_n / world) / passes
+        if world > 1:
+            passes = None
+            alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * (total_n / world)     # per rank, per transform
+        else:
+            alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * total_n / passes
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9
         out = {
             "metric": "ntt_field_elements_per_sec", "value": value, "unit": "field-elements/s", "n_gpus": world,
@@ -177,7 +181,7 @@ def main():
             "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
                        "passes_per_transform": passes, "roundtrip_bit_exact": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "ntt_pass_kernel", "avg_launch_us": avg_launch_s * 1e6,
+                         "traffic": None, "kernel": "ntt_pass_kernel" if world == 1 else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
                          "note": "VALU-bound 128-bit modmul; see DESIGN.md"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -62,6 +62,15 @@ int sc_vec_gather(const sc_vec_t* v, const uint64_t* indices, uint64_t k, void* 
 int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int inverse);
 int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2], int inverse, void* stream);
 
+/* ---- building blocks of the multi-GPU four-step NTT (no reference counterpart: the reference is single-process;
+ *      together they compute exactly ntt.py:3-18 on a domain sharded over ranks, see stark-anatomy_amd/sharded.py) */
+/* kind 0: d_in [len][batch] row-major, transform along axis 0 for every column, same layout out (natural order).
+ * kind 1: d_in [batch][len], transform every row, output TRANSPOSED d_out [len][batch].  root: primitive len-th root. */
+int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2], void* stream);
+/* d_data[r][c] *= root^((row_base + r) * (col_base + c)) * scale, root of order `order` (scale may be NULL = 1) */
+int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t row_base, uint64_t col_base, const uint64_t root[2], uint64_t order,
+                          const uint64_t scale[2], void* stream);
+
 /* ---- fast_coset_evaluate : code/ntt.py:132-135 (Polynomial.scale univariate.py:153-154 fused) -- */
 /* out[i] = sum_{j<m} coeffs[j] * (offset * generator^i)^j, i < order; m <= order. */
 int sc_coset_evaluate(const void* coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* out);

@@ -159,4 +159,119 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Batched transforms used by the multi-GPU four-step NTT (each rank runs them on its slab).
+//   BATCH_COLS  : data [len][batch] row-major, transform along axis 0 (stride = batch) for every column,
+//                 output in the same layout with natural order along axis 0.
+//   BATCH_ROWS_T: data [batch][len] (contiguous rows), transform every row, output TRANSPOSED [len][batch].
+// At most two passes each (len <= 2^(2*max_digit_log)); tables are those of a primitive len-th root.
+enum BatchKind { BATCH_COLS = 0, BATCH_ROWS_T = 1 };
+
+inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, const NttTables& tb,
+                         const Fe* in, Fe* work, Fe* out, const NttTuning& tu) {
+    if (loglen < 1 || loglen + logbatch > 34) return false;
+    const int m = (loglen <= tu.max_digit_log) ? 1 : 2;
+    if (loglen > 2 * tu.max_digit_log + 2) return false;
+    d.logn = loglen;
+    d.npasses = m;
+    d.digits[0] = (m == 1) ? loglen : (loglen + 1) / 2;
+    d.digits[1] = loglen - d.digits[0];
+    int tile_cap = tu.max_tile_log;
+    while (tile_cap > 6 && loglen + logbatch - tile_cap < tu.min_tiles_log) --tile_cap;
+    const uint64_t len = 1ull << loglen, batch = 1ull << logbatch;
+    for (int i = 0; i < m; ++i) {
+        NttPassDesc& pd = d.pass[i];
+        PassParams& p = pd.p;
+        p = PassParams{};
+        const int logR = d.digits[i];
+        const bool lastp = (i == m - 1);
+        const int logA = (i == 0) ? 0 : d.digits[0];
+        p.logR = logR;
+        p.in = (i == 0) ? in : work;
+        p.out = lastp ? out : work;
+        p.mt = tb.mt;
+        p.mt_shift = tb.mt_log - logR;
+        p.tl = tb.tl;
+        p.th = tb.th;
+        p.in_limit = ~0ull;
+        if (kind == BATCH_COLS) {
+            // [A][R][Blow * batch]: column pass; the last pass writes rows in natural order k = a + A*k_m
+            const int logBlow = loglen - logA - logR;       // untransformed lower digits of the transform axis
+            const int logB = logBlow + logbatch;
+            int logC = tile_cap - logR;
+            if (logC > logB) logC = logB;
+            if (logC > tu.max_col_log) logC = tu.max_col_log;
+            if (logC < 0) logC = 0;
+            p.logC = logC;
+            p.lo_log = logB - logC;
+            p.mid_log = logA;
+            p.in_lo = p.out_lo = 1ull << logC;
+            p.in_mid = 1ull << (logR + logB);
+            p.in_rs = 1ull << logB;
+            p.in_cs = p.out_cs = 1;
+            if (lastp && m == 2) {
+                p.out_mid = batch;                              // a = k_1 -> row k_1
+                p.out_rs = batch << logA;                       // k_2 -> row N_1 * k_2
+            } else {
+                p.out_mid = p.in_mid;
+                p.out_rs = p.in_rs;
+            }
+            p.rfast_load = 0;
+            p.tw_enable = lastp ? 0 : 1;
+            p.tw_col_shift = logbatch;
+            p.tw_scale = 1ull << logA;
+            pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
+        } else if (!lastp) {
+            // rows, first digit: [batch][R][B = N_2]: t_lo = column block, t_mid = (none), t_hi = batch row
+            const int logB = loglen - logR;
+            int logC = tile_cap - logR;
+            if (logC > logB) logC = logB;
+            if (logC > tu.max_col_log) logC = tu.max_col_log;
+            if (logC < 0) logC = 0;
+            p.logC = logC;
+            p.lo_log = logB - logC;
+            p.mid_log = 0;
+            p.in_lo = p.out_lo = 1ull << logC;
+            p.in_hi = p.out_hi = len;
+            p.in_rs = p.out_rs = 1ull << logB;
+            p.in_cs = p.out_cs = 1;
+            p.rfast_load = 0;
+            p.tw_enable = 1;
+            p.tw_scale = 1;
+            pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
+        } else {
+            // rows, last digit: C adjacent batch rows x R contiguous; output [k][batch row], k = k_1 + N_1 * k_2
+            int logC = tile_cap - logR;
+            if (logC > logbatch) logC = logbatch;
+            if (logC > tu.max_col_log) logC = tu.max_col_log;
+            if (logC < 0) logC = 0;
+            p.logC = logC;
+            p.lo_log = 0;
+            p.mid_log = logA;                                   // t_mid = k_1 (absent when m == 1)
+            p.in_rs = 1;
+            p.in_cs = len;
+            p.in_hi = len << logC;
+            p.in_mid = 1ull << logR;
+            p.out_cs = 1;
+            p.out_hi = 1ull << logC;
+            p.out_mid = batch;
+            p.out_rs = batch << logA;
+            p.rfast_load = 1;
+            p.tw_enable = 0;
+            pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
+        }
+        int loge = tu.loge;
+        const int logT = p.logR + p.logC;
+        if (loge > logT) loge = logT;
+        while (logT - loge > (loge >= 4 ? 8 : (loge == 3 ? 9 : 10))) ++loge;
+        if (loge > 4) return false;
+        if (kind == BATCH_ROWS_T && lastp && p.logR <= loge) loge = p.logR - 1;
+        if (loge < 1) return false;
+        pd.loge = loge;
+        pd.threads = 1u << (logT - loge);
+        pd.lds_bytes = (uint32_t)sizeof(Fe) << logT;
+    }
+    return true;
+}
+
 }  // namespace sc

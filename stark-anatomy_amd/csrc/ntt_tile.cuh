@@ -38,6 +38,7 @@ struct PassParams {
     int mt_shift;
     // four-step twiddle  w_n^(colidx * k * tw_scale), colidx = t_lo*C + c ; tl[e & 4095] * th[e >> 12]
     int tw_enable;
+    int tw_col_shift;          // colidx >>= tw_col_shift (batched column transforms: low column bits are the batch, not the transform)
     uint64_t tw_scale;
     const Fe* tl;
     const Fe* th;
@@ -167,7 +168,7 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
             const uint32_t k = bitrev32(r, logR);
             Fe v = x[i];
             if (P.tw_enable) {
-                const uint64_t colidx = ((uint64_t)t_lo << logC) | c;
+                const uint64_t colidx = (((uint64_t)t_lo << logC) | c) >> P.tw_col_shift;
                 const uint64_t e = colidx * (uint64_t)k * P.tw_scale;
                 v = mont_mul(v, pow2level(P.tl, P.th, e));
             }

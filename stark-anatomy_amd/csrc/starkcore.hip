@@ -97,6 +97,18 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const Fe* __restrict__ in
     out[i] = fe_add(fe_half(fe_add(a, b)), mont_mul(fe_sub(a, b), t));
 }
 
+// four-step outer twiddle on a rank's slab: data[r][c] *= w^((row_base + r) * (col_base + c)) [* scale]
+__global__ void __launch_bounds__(256) twiddle_matrix_kernel(Fe* __restrict__ data, uint64_t rows, int logcols, uint64_t row_base, uint64_t col_base,
+                                                             const Fe* __restrict__ tl, const Fe* __restrict__ th, int scale_enable, Fe scale_m) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (rows << logcols)) return;
+    uint64_t r = i >> logcols, c = i & ((1ull << logcols) - 1);
+    uint64_t e = (row_base + r) * (col_base + c);
+    Fe t = pow2level(tl, th, e);
+    if (scale_enable) t = mont_mul(t, scale_m);
+    data[i] = mont_mul(data[i], t);
+}
+
 __global__ void __launch_bounds__(256) gather_kernel(const Fe* __restrict__ v, const uint64_t* __restrict__ idx, uint64_t k, Fe* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) out[i] = v[idx[i]];
@@ -293,6 +305,20 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
     hipLaunchKernelGGL(ntt_pass_kernel<LOGE>, dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap);
 }
 
+int run_plan(const NttPlanDesc& d, hipStream_t st) {
+    for (int i = 0; i < d.npasses; ++i) {
+        switch (d.pass[i].loge) {
+            case 1: launch_pass<1>(d.pass[i], st); break;
+            case 2: launch_pass<2>(d.pass[i], st); break;
+            case 3: launch_pass<3>(d.pass[i], st); break;
+            case 4: launch_pass<4>(d.pass[i], st); break;
+            default: return fail(SC_ERR_UNSUPPORTED, "bad loge");
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return SC_OK;
+}
+
 struct NttOpts {
     uint64_t in_limit = ~0ull;
     const PowTables* coset = nullptr;
@@ -315,17 +341,7 @@ int ntt_device(const Fe* d_in, Fe* d_out, int logn, Fe root, bool inverse_scale,
     if (inverse_scale && m == 1) { io.scale_last = true; io.scale = mont_inv(to_mont(Fe{n, 0})); }
     NttPlanDesc d;
     if (!plan_ntt(d, logn, tb, io, g.tuning)) return fail(SC_ERR_UNSUPPORTED, "unsupported transform length");
-    for (int i = 0; i < d.npasses; ++i) {
-        switch (d.pass[i].loge) {
-            case 1: launch_pass<1>(d.pass[i], st); break;
-            case 2: launch_pass<2>(d.pass[i], st); break;
-            case 3: launch_pass<3>(d.pass[i], st); break;
-            case 4: launch_pass<4>(d.pass[i], st); break;
-            default: return fail(SC_ERR_UNSUPPORTED, "bad loge");
-        }
-        HIPCHK(hipGetLastError());
-    }
-    return SC_OK;
+    return run_plan(d, st);
 }
 
 Fe root_inverse(Fe root, uint64_t n) {   // root^-1 = root^(n-1) for an n-th root of unity
@@ -535,6 +551,52 @@ int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int in
     SCCHK(upload(a, in, n * sizeof(Fe), g.stream));
     SCCHK(ntt_any((const Fe*)a, (Fe*)b, n, fe_from(root), inverse != 0, NttOpts{}, g.stream));
     return download(out, b, n * sizeof(Fe), g.stream);
+}
+
+// ---- batched transforms + outer twiddle (building blocks of the multi-GPU four-step NTT)
+int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2], void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (!is_pow2(len) || !is_pow2(batch) || len < 2) return fail(SC_ERR_NOT_POW2, "batched ntt needs power-of-two length >= 2 and batch");
+    if (kind != 0 && kind != 1) return fail(SC_ERR_BAD_ARG, "kind must be 0 (columns) or 1 (rows, transposed output)");
+    Fe rt = fe_from(root);
+    SCCHK(check_root(rt, len));
+    const int loglen = ilog2(len), logbatch = ilog2(batch);
+    PlanTables* pt;
+    SCCHK(get_plan(rt, loglen, false, st, &pt));
+    NttTables tb;
+    tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
+    void* w;
+    SCCHK(scratch(0, len * batch * sizeof(Fe), &w));
+    NttPlanDesc d;
+    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)d_in, (Fe*)w, (Fe*)d_out, g.tuning))
+        return fail(SC_ERR_UNSUPPORTED, "unsupported batched transform shape");
+    if (d.npasses == 2 && kind == 0 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "two-pass column transform must be out of place");
+    if (kind == 1 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "transposing row transform must be out of place");
+    return run_plan(d, st);
+}
+
+int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t row_base, uint64_t col_base, const uint64_t root[2], uint64_t order,
+                          const uint64_t scale[2], void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (!is_pow2(cols) || !is_pow2(order) || order < 2) return fail(SC_ERR_NOT_POW2, "cols and order must be powers of two");
+    if ((row_base + rows - 1) * (col_base + cols - 1) >= order) return fail(SC_ERR_BAD_ARG, "twiddle exponent out of range");
+    Fe rt = fe_from(root);
+    SCCHK(check_root(rt, order));
+    PlanTables* pt;
+    SCCHK(get_plan(rt, ilog2(order), false, st, &pt));
+    int scale_enable = 0;
+    Fe scale_m = fe_mont_one();
+    if (scale && !(scale[0] == 1 && scale[1] == 0)) { scale_enable = 1; scale_m = to_mont(fe_from(scale)); }
+    uint64_t total = rows * cols;
+    if (!total) return SC_OK;
+    hipLaunchKernelGGL(twiddle_matrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (Fe*)d_data, rows, ilog2(cols), row_base, col_base,
+                       pt->tl, pt->th, scale_enable, scale_m);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
 }
 
 // ---- coset evaluate

@@ -36,6 +36,8 @@ SIGNATURES = {
     "sc_vec_gather": (_int, [_vp, _vp, _u64, _vp]),
     "sc_ntt": (_int, [_vp, _vp, _u64, _vp, _int]),
     "sc_ntt_dev": (_int, [_vp, _vp, _u64, _vp, _int, _vp]),
+    "sc_ntt_batch_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp]),
+    "sc_twiddle_matrix_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _u64, _vp, _vp]),
     "sc_coset_evaluate": (_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     "sc_coset_evaluate_dev": (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "sc_poly_mul": (_int, [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64]),

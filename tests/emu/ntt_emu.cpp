@@ -80,3 +80,32 @@ extern "C" void emu_field(const uint64_t* a, const uint64_t* b, uint64_t* out /*
     Fe r[7] = {fe_add(x, y), fe_sub(x, y), fe_mul(x, y), from_mont(mont_inv(to_mont(x))), fe_half(x), fe_neg(x), mont_mul(x, to_mont(y))};
     memcpy(out, r, sizeof r);
 }
+
+// batched transforms (multi-GPU building blocks): kind 0 = columns of [len][batch], kind 1 = rows of [batch][len] -> [len][batch]
+extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,
+                               int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log) {
+    const uint64_t len = 1ull << loglen, batch = 1ull << logbatch;
+    Fe r_m = to_mont(Fe{root[0], root[1]});
+    NttTuning tu;
+    tu.max_tile_log = max_tile_log; tu.loge = loge; tu.min_tiles_log = min_tiles_log; tu.max_col_log = max_col_log; tu.max_digit_log = max_digit_log;
+    NttTables tb;
+    std::vector<Fe> mt, tl, th;
+    tb.mt_log = loglen < 12 ? loglen : 12;
+    fill_table(mt, 1ull << (tb.mt_log - 1), r_m, len >> tb.mt_log, fe_mont_one());
+    fill_table(tl, len < 4096 ? len : 4096, r_m, 1, fe_mont_one());
+    fill_table(th, len > 4096 ? len >> 12 : 1, r_m, 4096, fe_mont_one());
+    tb.mt = mt.data(); tb.tl = tl.data(); tb.th = th.data();
+    std::vector<Fe> work(len * batch);
+    NttPlanDesc d;
+    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu)) return -1;
+    for (int i = 0; i < d.npasses; ++i) {
+        switch (d.pass[i].loge) {
+            case 1: run_pass<1>(d.pass[i]); break;
+            case 2: run_pass<2>(d.pass[i]); break;
+            case 3: run_pass<3>(d.pass[i]); break;
+            case 4: run_pass<4>(d.pass[i]); break;
+            default: return -2;
+        }
+    }
+    return d.npasses;
+}

@@ -102,3 +102,35 @@ def test_emu_coset_evaluate(emu, cfg):
     for offset in (po.GENERATOR, 2):
         out, _ = run_emu(emu, coeffs + bytes(16), logn, gen, in_limit=m, offset=offset, tile=tile, loge=loge, single=single, min_tiles=min_tiles, max_col=max_col)
         assert out == po.C.coset_evaluate(coeffs, m, offset, gen, n), cfg
+
+
+def _batched_expect(data, kind, loglen, logbatch, root):
+    """oracle: transform every column (kind 0) or every row with transposed output (kind 1)."""
+    import numpy as np
+    ln, bt = 1 << loglen, 1 << logbatch
+    a = np.frombuffer(data, dtype=np.uint64)
+    if kind == 0:
+        m = a.reshape(ln, bt, 2)
+        cols = [po.C.ntt(root, m[:, c, :].tobytes(), ln) for c in range(bt)]
+        out = np.stack([np.frombuffer(c, dtype=np.uint64).reshape(ln, 2) for c in cols], axis=1)      # [len][batch][2]
+    else:
+        m = a.reshape(bt, ln, 2)
+        rows = [po.C.ntt(root, m[r].tobytes(), ln) for r in range(bt)]
+        out = np.stack([np.frombuffer(r, dtype=np.uint64).reshape(ln, 2) for r in rows], axis=1)      # [len][batch][2]
+    return out.tobytes()
+
+
+@pytest.mark.parametrize("cfg", [(0, 3, 2, 6, 2, 0, 3, 8), (0, 6, 4, 8, 2, 0, 4, 3), (0, 7, 3, 9, 2, 0, 3, 4), (0, 12, 2, 11, 2, 4, 6, 8), (0, 5, 0, 6, 2, 0, 3, 8),
+                                 (1, 3, 2, 6, 2, 0, 3, 8), (1, 6, 4, 8, 2, 0, 4, 3), (1, 7, 3, 9, 3, 0, 3, 4), (1, 12, 2, 11, 2, 4, 6, 8), (1, 9, 1, 11, 2, 0, 6, 8),
+                                 (0, 11, 4, 11, 2, 10, 6, 8), (1, 11, 4, 11, 2, 10, 6, 8)])
+def test_emu_batched(emu, cfg):
+    kind, loglen, logbatch, tile, loge, min_tiles, max_col, digit = cfg
+    emu.emu_ntt_batched.restype = ctypes.c_int
+    emu.emu_ntt_batched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5
+    total = 1 << (loglen + logbatch)
+    data = synth.synth_packed(900 + loglen + 7 * kind, total).tobytes()
+    root = po.primitive_nth_root(1 << loglen)
+    out = ctypes.create_string_buffer(16 * total)
+    rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit)
+    assert rc > 0, rc
+    assert out.raw == _batched_expect(data, kind, loglen, logbatch, root), cfg

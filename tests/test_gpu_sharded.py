@@ -1,0 +1,107 @@
+"""Multi-GPU four-step NTT, GPU side: the batched HIP stages (column transforms, outer twiddle, transposed row
+transforms) driven by sharded.py for a SIMULATED world of ranks on one device -- the all-to-all is replaced by the
+equivalent tensor shuffle -- and compared with the single-GPU transform and the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import py_oracle as po
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import starkcore
+    assert starkcore.device_count() > 0
+    starkcore.init()
+    return starkcore
+
+
+def _simulate(sc, log2n, world, seed):
+    from sharded import ShardedNtt
+    dev = torch.device("cuda", 0)
+    n = 1 << log2n
+    root = po.primitive_nth_root(n)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        engs = [ShardedNtt(log2n, root, r, world, dev) for r in range(world)]
+        xs = [e.synthetic_input(seed) for e in engs]
+        n1, n2 = engs[0].n1, engs[0].n2
+
+        def run(srcs, R, C, rt, scale):
+            a = [e.stage_cols(s, R, C, rt, scale).clone() for e, s in zip(engs, srcs)]
+            outs = []
+            rw, cw = R // world, C // world
+            for h, e in enumerate(engs):
+                # what all_to_all_single delivers to rank h: from every rank g its rows [h*rw, (h+1)*rw)
+                recv = torch.stack([a[g][h * rw:(h + 1) * rw] for g in range(world)], dim=0).contiguous()
+                rows = e.assemble_rows(recv, R, C) if world > 1 else a[0]
+                dst = torch.empty((C, rw, 2), dtype=torch.int64, device=dev)
+                e.stage_rows(rows, dst, R, C, rt)
+                outs.append(dst)
+            return outs
+
+        ys = run(xs, n1, n2, root, 1)
+        zs = run(ys, n2, n1, engs[0].root_inv, engs[0].n_inv)
+    torch.cuda.synchronize()
+    full_in = synth.synth_packed(seed, n).tobytes()
+    got = torch.cat(ys, dim=1).reshape(n, 2).cpu().numpy().tobytes()
+    back = torch.cat(zs, dim=1).reshape(n, 2).cpu().numpy().tobytes()
+    return full_in, got, back, root
+
+
+@pytest.mark.parametrize("log2n,world", [(8, 1), (10, 2), (13, 4), (16, 8), (18, 8), (21, 2)])
+def test_sharded_simulated_world(sc, log2n, world):
+    full_in, got, back, root = _simulate(sc, log2n, world, seed=11)
+    n = 1 << log2n
+    assert got == po.C.ntt(root, full_in, n)
+    assert back == full_in
+
+
+def test_sharded_2p24_matches_single_gpu(sc):
+    """BASELINE target size: 2^24 over 8 (simulated) ranks == the single-GPU transform, and round trip."""
+    full_in, got, back, root = _simulate(sc, 24, 8, seed=12)
+    n = 1 << 24
+    x = sc.DeviceVector.from_bytes(full_in)
+    y = sc.DeviceVector(n)
+    sc._check(sc.lib().sc_ntt_dev(x.ptr, y.ptr, n, sc.fe_bytes(root), 0, None))
+    sc.synchronize()
+    assert y.to_bytes() == got
+    assert back == full_in
+
+
+def test_batched_entry_points_vs_oracle(sc):
+    dev = torch.device("cuda", 0)
+    lib = sc.lib()
+    for kind, loglen, logbatch in [(0, 5, 3), (0, 11, 4), (0, 12, 6), (1, 5, 3), (1, 11, 4), (1, 12, 6), (1, 8, 0), (0, 9, 0)]:
+        ln, bt = 1 << loglen, 1 << logbatch
+        host = synth.synth_packed(40 + loglen + kind, ln * bt)
+        src = torch.from_numpy(host.view(np.int64)).to(dev)
+        dst = torch.empty_like(src)
+        root = po.primitive_nth_root(ln)
+        sc._check(lib.sc_ntt_batch_dev(src.data_ptr(), dst.data_ptr(), ln, bt, kind, sc.fe_bytes(root), None))
+        sc.synchronize()
+        got = dst.cpu().numpy().view(np.uint64)
+        if kind == 0:
+            m = host.reshape(ln, bt, 2)
+            exp = np.stack([np.frombuffer(po.C.ntt(root, np.ascontiguousarray(m[:, c]).tobytes(), ln), dtype=np.uint64).reshape(ln, 2) for c in range(bt)], axis=1)
+        else:
+            m = host.reshape(bt, ln, 2)
+            exp = np.stack([np.frombuffer(po.C.ntt(root, m[r].tobytes(), ln), dtype=np.uint64).reshape(ln, 2) for r in range(bt)], axis=1)
+        assert got.reshape(-1).tobytes() == exp.tobytes(), (kind, loglen, logbatch)
+    # outer twiddle
+    rows, cols, order = 64, 32, 1 << 12
+    host = synth.synth_packed(77, rows * cols)
+    buf = torch.from_numpy(host.view(np.int64)).to(dev)
+    root = po.primitive_nth_root(order)
+    scale = 12345678901234567890
+    sc._check(lib.sc_twiddle_matrix_dev(buf.data_ptr(), rows, cols, 0, 32, sc.fe_bytes(root), order, sc.fe_bytes(scale), None))
+    sc.synchronize()
+    got = synth.unpack_ints(buf.cpu().numpy().tobytes())
+    ints = synth.unpack_ints(host.tobytes())
+    exp = [ints[r * cols + c] * pow(root, r * (32 + c), po.P) * scale % po.P for r in range(rows) for c in range(cols)]
+    assert got == exp
