@@ -47,6 +47,10 @@ int sc_synchronize(void);              /* wait for the library stream */
  * "single_pass_max_log","max_digit_log"}; clears cached plans */
 int sc_set_tuning(const char* key, int value);
 
+/* diagnostics: out[i] = op(a[i], b[i]) computed by the device field routines the kernels use.
+ * op 0: a*b*2^-128 (Montgomery product, b < p), 1: a+b, 2: a-b, 3: a*b, 4: a/2, 5: a^-1, 6: portable Montgomery product */
+int sc_field_selftest(int op, const void* a, const void* b, void* out, uint64_t n);
+
 /* ---- device vectors ----------------------------------------------------------------------- */
 int sc_vec_alloc(uint64_t n, sc_vec_t** out);
 int sc_vec_free(sc_vec_t* v);

@@ -39,8 +39,14 @@ SC_HD bool fe_is_zero(Fe a) { return (a.lo | a.hi) == 0; }
 SC_HD bool fe_eq(Fe a, Fe b) { return a.lo == b.lo && a.hi == b.hi; }
 SC_HD bool fe_ge_p(Fe a) { return a.hi > P_HI || (a.hi == P_HI && a.lo >= P_LO); }
 
+// dispatchers (defined at the end of this header): portable C on the host, hand-selected gfx950 instruction
+// sequences (field_asm.cuh) on the device unless SC_ASM_MUL / SC_ASM_ADDSUB are set to 0
+SC_HD Fe fe_add(Fe a, Fe b);
+SC_HD Fe fe_sub(Fe a, Fe b);
+SC_HD Fe mont_mul(Fe a, Fe b);
+
 // (a + b) mod p, a, b canonical.  2p > 2^128, so the carry out of bit 127 matters.
-SC_HD Fe fe_add(Fe a, Fe b) {
+SC_HD Fe fe_add_c(Fe a, Fe b) {
     uint64_t lo = a.lo + b.lo;
     uint64_t c0 = lo < a.lo;
     uint64_t hi = a.hi + b.hi;
@@ -55,7 +61,7 @@ SC_HD Fe fe_add(Fe a, Fe b) {
 }
 
 // (a - b) mod p
-SC_HD Fe fe_sub(Fe a, Fe b) {
+SC_HD Fe fe_sub_c(Fe a, Fe b) {
     uint64_t lo = a.lo - b.lo;
     uint64_t b0 = a.lo < b.lo;
     uint64_t hi = a.hi - b.hi;
@@ -86,7 +92,7 @@ SC_HD Fe fe_half(Fe a) {
 
 // Montgomery product a * b * 2^-128 mod p.  Requires a * b < 2^128 * p (e.g. a < 2^128, b < p).
 // Output canonical.
-SC_HD Fe mont_mul(Fe a, Fe b) {
+SC_HD Fe mont_mul_c(Fe a, Fe b) {
     u128 p00 = (u128)a.lo * b.lo, p01 = (u128)a.lo * b.hi, p10 = (u128)a.hi * b.lo, p11 = (u128)a.hi * b.hi;
     uint64_t t0 = (uint64_t)p00;
     u128 mid = (p00 >> 64) + (uint64_t)p01 + (uint64_t)p10;
@@ -150,4 +156,36 @@ SC_HD Fe mont_pow128(Fe base_m, uint64_t e_lo, uint64_t e_hi) {
 // xgcd-based Field.inverse (code/algebra.py:87-89).
 SC_HD Fe mont_inv(Fe a_m) { return mont_pow128(a_m, 0xFFFFFFFFFFFFFFFFull, P_HI - 1); }   // p - 2
 
+}  // namespace sc
+
+#ifndef SC_ASM_MUL
+#define SC_ASM_MUL 1
+#endif
+#ifndef SC_ASM_ADDSUB
+#define SC_ASM_ADDSUB 1
+#endif
+#include "field_asm.cuh"
+
+namespace sc {
+SC_HD Fe mont_mul(Fe a, Fe b) {
+#if defined(__HIP_DEVICE_COMPILE__) && SC_ASM_MUL
+    return mont_mul_asm(a, b);
+#else
+    return mont_mul_c(a, b);
+#endif
+}
+SC_HD Fe fe_add(Fe a, Fe b) {
+#if defined(__HIP_DEVICE_COMPILE__) && SC_ASM_ADDSUB
+    return fe_add_asm(a, b);
+#else
+    return fe_add_c(a, b);
+#endif
+}
+SC_HD Fe fe_sub(Fe a, Fe b) {
+#if defined(__HIP_DEVICE_COMPILE__) && SC_ASM_ADDSUB
+    return fe_sub_asm(a, b);
+#else
+    return fe_sub_c(a, b);
+#endif
+}
 }  // namespace sc

@@ -109,6 +109,23 @@ __global__ void __launch_bounds__(256) twiddle_matrix_kernel(Fe* __restrict__ da
     data[i] = mont_mul(data[i], t);
 }
 
+// diagnostics: elementwise field operations exactly as the kernels use them
+__global__ void __launch_bounds__(256) field_selftest_kernel(int op, const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe x = a[i], y = b[i], r;
+    switch (op) {
+        case 0: r = mont_mul(x, y); break;                 // x * y * 2^-128
+        case 1: r = fe_add(x, y); break;
+        case 2: r = fe_sub(x, y); break;
+        case 3: r = fe_mul(x, y); break;
+        case 4: r = fe_half(x); break;
+        case 5: r = from_mont(mont_inv(to_mont(x))); break;
+        default: r = mont_mul_c(x, y); break;               // portable reference implementation
+    }
+    out[i] = r;
+}
+
 __global__ void __launch_bounds__(256) gather_kernel(const Fe* __restrict__ v, const uint64_t* __restrict__ idx, uint64_t k, Fe* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) out[i] = v[idx[i]];
@@ -531,6 +548,22 @@ int sc_vec_gather(const sc_vec_t* v, const uint64_t* indices, uint64_t k, void* 
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, g.stream, v->d, d_idx, k, d_out);
     HIPCHK(hipGetLastError());
     return download(host_out, d_out, k * sizeof(Fe), g.stream);
+}
+
+// ---- diagnostics
+int sc_field_selftest(int op, const void* a, const void* b, void* out, uint64_t n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!n) return SC_OK;
+    void *da, *db, *dc;
+    SCCHK(scratch(1, n * sizeof(Fe), &da));
+    SCCHK(scratch(2, n * sizeof(Fe), &db));
+    SCCHK(scratch(3, n * sizeof(Fe), &dc));
+    SCCHK(upload(da, a, n * sizeof(Fe), g.stream));
+    SCCHK(upload(db, b, n * sizeof(Fe), g.stream));
+    hipLaunchKernelGGL(field_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, op, (const Fe*)da, (const Fe*)db, (Fe*)dc, n);
+    HIPCHK(hipGetLastError());
+    return download(out, dc, n * sizeof(Fe), g.stream);
 }
 
 // ---- ntt

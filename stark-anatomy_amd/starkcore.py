@@ -8,7 +8,7 @@ import os
 from collections.abc import Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libstarkcore.so")
+_LIB_PATH = os.environ.get("STARKCORE_LIB") or os.path.join(_HERE, "libstarkcore.so")   # override only for A/B experiments
 
 _u64 = ctypes.c_uint64
 _vp = ctypes.c_void_p
@@ -27,6 +27,7 @@ SIGNATURES = {
     "sc_last_error": (ctypes.c_char_p, []),
     "sc_synchronize": (_int, []),
     "sc_set_tuning": (_int, [ctypes.c_char_p, _int]),
+    "sc_field_selftest": (_int, [_int, _vp, _vp, _vp, _u64]),
     "sc_vec_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
     "sc_vec_free": (_int, [_vp]),
     "sc_vec_len": (_u64, [_vp]),

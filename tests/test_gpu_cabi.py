@@ -285,3 +285,31 @@ def test_device_vector_api(sc):
     sc._check(sc.lib().sc_scale_dev(v.ptr, out.ptr, n, sc.fe_bytes(po.GENERATOR), None))
     sc.synchronize()
     assert out.to_bytes() == C.scale(data, n, po.GENERATOR)
+
+
+def test_device_field_ops(sc):
+    """The device field routines (hand-selected gfx950 sequences in csrc/field_asm.cuh) vs exact integer arithmetic,
+    on edge operands and 2^16 random pairs; op 6 is the portable implementation of the same Montgomery product."""
+    lib = sc.lib()
+    R = 1 << 128
+    Rinv = pow(R, -1, P)
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 119), (1 << 119) - 1, (1 << 127), 407, (1 << 64) - 1, 1 << 64, (1 << 96) + 1, 0xCB800000 << 96, 511, 512]
+    a = [x for x in edge for _ in edge] + synth.synth_ints(31, 1 << 16)
+    b = [y for _ in edge for y in edge] + synth.synth_ints(32, 1 << 16)
+    # Montgomery product accepts any a < 2^128 (lazy inputs) with b < p
+    a_lazy = [R - 1, R - 2, P, P + 1, (1 << 127) + (1 << 126)] + [(v + P) % R if v + P < R else v for v in a[5:]]
+    n = len(a)
+    out = ctypes.create_string_buffer(16 * n)
+
+    def run(op, xs, ys):
+        sc._check(lib.sc_field_selftest(op, synth.pack_ints(xs), synth.pack_ints(ys), out, n))
+        return synth.unpack_ints(out.raw)
+
+    assert run(0, a, b) == [x * y * Rinv % P for x, y in zip(a, b)]
+    assert run(0, a_lazy, b) == [x * y * Rinv % P for x, y in zip(a_lazy, b)]
+    assert run(6, a_lazy, b) == [x * y * Rinv % P for x, y in zip(a_lazy, b)]
+    assert run(1, a, b) == [(x + y) % P for x, y in zip(a, b)]
+    assert run(2, a, b) == [(x - y) % P for x, y in zip(a, b)]
+    assert run(3, a, b) == [x * y % P for x, y in zip(a, b)]
+    assert run(4, a, b) == [x * pow(2, -1, P) % P for x in a]
+    assert run(5, a[:4096] + [1] * (n - 4096), b)[:4096] == [po.inv(x) for x in a[:4096]]
