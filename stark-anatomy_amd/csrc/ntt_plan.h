@@ -6,12 +6,13 @@
 namespace sc {
 
 struct NttTuning {
-    int max_tile_log = 11;   // LDS tile = 2^max_tile_log elements (32 KiB at 11); measured best 10-11 (tools/sweep.py)
+    int max_tile_log = 10;   // LDS tile = 2^max_tile_log elements (16 KiB at 10); measured best 9-10 (tools/sweep.py)
     int loge = 2;            // elements per thread = 2^loge; 2 measured best (occupancy beats register blocking here)
     int max_col_log = 6;     // at most 64 columns (1 KiB runs)
     int min_tiles_log = 10;  // shrink tiles until there are at least this many per pass (fill 256 CUs)
     int single_pass_max_log = 11;
     int max_digit_log = 8;   // passes = ceil(logn / max_digit_log)
+    int direct_tw_max_log = 24;  // build direct four-step twiddle tables up to 2^this entries per pass (0 = never)
 };
 
 struct NttTables {
@@ -20,6 +21,7 @@ struct NttTables {
     const Fe* tl = nullptr;  // tl[e] = root^e, e < min(n, 4096)
     const Fe* th = nullptr;  // th[h] = root^(4096 h), h < max(1, n/4096)
     const Fe* th_scaled = nullptr;  // th[h] * scale (n^-1 for the inverse transform); used by the FIRST pass's twiddle only
+    const Fe* twd[4] = {nullptr, nullptr, nullptr, nullptr};   // optional direct twiddle table per column pass (see PassParams::twd)
 };
 
 struct NttPassDesc {
@@ -115,6 +117,8 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
             p.rfast_load = 0;
             p.tw_enable = 1;
             p.tw_scale = 1ull << logA;
+            p.twd = tb.twd[i];
+            p.twd_stride = 1ull << logB;
             pd.ntiles = (uint32_t)(n >> (logR + logC));
         } else {
             // transposing pass: memory [k_1][k_2]..[k_{m-1}][j_m] -> natural k = k_1 + N_1 k_2 + ... ; C adjacent k_1 per tile

@@ -42,6 +42,10 @@ struct PassParams {
     uint64_t tw_scale;
     const Fe* tl;
     const Fe* th;
+    // optional direct table of the same twiddles: twd[k * twd_stride + colidx] = w_n^(colidx * k * tw_scale) [* n^-1];
+    // laid out like the pass's output tile, so the load coalesces exactly like the store (nullptr = two-level lookup)
+    const Fe* twd;
+    uint64_t twd_stride;
     // final constant multiply (Montgomery form), e.g. n^-1 for a single-pass inverse transform
     int scale_enable;
     Fe scale;
@@ -169,8 +173,12 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
             Fe v = x[i];
             if (P.tw_enable) {
                 const uint64_t colidx = (((uint64_t)t_lo << logC) | c) >> P.tw_col_shift;
-                const uint64_t e = colidx * (uint64_t)k * P.tw_scale;
-                v = mont_mul(v, pow2level(P.tl, P.th, e));
+                if (P.twd) {
+                    v = mont_mul(v, P.twd[(uint64_t)k * P.twd_stride + colidx]);
+                } else {
+                    const uint64_t e = colidx * (uint64_t)k * P.tw_scale;
+                    v = mont_mul(v, pow2level(P.tl, P.th, e));
+                }
             }
             if (P.scale_enable) v = mont_mul(v, P.scale);
             uint64_t j = (uint64_t)t_hi * P.out_hi + (uint64_t)t_mid * P.out_mid + (uint64_t)t_lo * P.out_lo + (uint64_t)k * P.out_rs + (uint64_t)c * P.out_cs;

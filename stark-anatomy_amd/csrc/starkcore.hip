@@ -45,6 +45,14 @@ __global__ void __launch_bounds__(256) pow_table_kernel(Fe* out, uint64_t count,
     if (i < count) out[i] = pow_table_entry(base_m, i, step, scale_m);
 }
 
+// direct four-step twiddle table for one column pass: out[k * B + b] = w^(b * k * scale_exp) [* n^-1 via th]
+__global__ void __launch_bounds__(256) twiddle_table_kernel(Fe* out, int logB, uint64_t count, uint64_t scale_exp, const Fe* __restrict__ tl, const Fe* __restrict__ th) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t k = i >> logB, b = i & ((1ull << logB) - 1);
+    out[i] = pow2level(tl, th, b * k * scale_exp);
+}
+
 // out = a * b (canonical in, canonical out)
 __global__ void __launch_bounds__(256) pointwise_mul_kernel(const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -161,6 +169,10 @@ struct PlanTables {      // power tables of one root of order n = 2^logn
     Fe* tl = nullptr;
     Fe* th = nullptr;
     Fe* th_ninv = nullptr;   // th * n^-1 (built on first inverse use)
+    // direct four-step twiddle tables per column pass for the plan's digit split, [0]: plain, [1]: first pass scaled by n^-1
+    Fe* twd[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    int twd_digits[4] = {0, 0, 0, 0};
+    int twd_passes = 0;
 };
 struct PowKey {
     uint64_t lo, hi, hi_count;
@@ -262,6 +274,7 @@ void free_plans() {
     for (auto& kv : g.plans) {
         hipFree(kv.second.mt); hipFree(kv.second.tl); hipFree(kv.second.th);
         if (kv.second.th_ninv) hipFree(kv.second.th_ninv);
+        for (int v = 0; v < 2; ++v) for (int i = 0; i < 4; ++i) if (kv.second.twd[v][i]) hipFree(kv.second.twd[v][i]);
     }
     g.plans.clear();
     for (auto& kv : g.pows) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
@@ -358,6 +371,41 @@ int ntt_device(const Fe* d_in, Fe* d_out, int logn, Fe root, bool inverse_scale,
     if (inverse_scale && m == 1) { io.scale_last = true; io.scale = mont_inv(to_mont(Fe{n, 0})); }
     NttPlanDesc d;
     if (!plan_ntt(d, logn, tb, io, g.tuning)) return fail(SC_ERR_UNSUPPORTED, "unsupported transform length");
+    if (d.npasses > 1 && g.tuning.direct_tw_max_log > 0) {
+        // direct twiddle tables (one coalesced load + one modmul per element instead of two loads + two modmuls);
+        // keyed by the digit split, rebuilt if the tuning changed it
+        bool same = pt->twd_passes == d.npasses;
+        for (int i = 0; same && i < d.npasses; ++i) same = pt->twd_digits[i] == d.digits[i];
+        if (!same) {
+            HIPCHK(hipDeviceSynchronize());
+            for (int v = 0; v < 2; ++v) for (int i = 0; i < 4; ++i) if (pt->twd[v][i]) { hipFree(pt->twd[v][i]); pt->twd[v][i] = nullptr; }
+            pt->twd_passes = d.npasses;
+            for (int i = 0; i < 4; ++i) pt->twd_digits[i] = (i < d.npasses) ? d.digits[i] : 0;
+        }
+        const int variant = inverse_scale ? 1 : 0;
+        bool built = false;
+        int logA = 0;
+        for (int i = 0; i + 1 < d.npasses; ++i) {
+            const int logR = d.digits[i], logB = logn - logA - logR;
+            const int logcount = logR + logB;
+            const bool scaled = (variant == 1 && i == 0);
+            Fe*& slot = pt->twd[scaled ? 1 : 0][i];
+            if (logcount <= g.tuning.direct_tw_max_log) {
+                if (!slot) {
+                    const uint64_t count = 1ull << logcount;
+                    HIPCHK(hipMalloc((void**)&slot, count * sizeof(Fe)));
+                    hipLaunchKernelGGL(twiddle_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, slot, logB, count, 1ull << logA,
+                                       pt->tl, scaled ? pt->th_ninv : pt->th);
+                    HIPCHK(hipGetLastError());
+                    built = true;
+                }
+                tb.twd[i] = slot;
+            }
+            logA += logR;
+        }
+        if (built) HIPCHK(hipStreamSynchronize(st));
+        if (!plan_ntt(d, logn, tb, io, g.tuning)) return fail(SC_ERR_UNSUPPORTED, "unsupported transform length");
+    }
     return run_plan(d, st);
 }
 
@@ -494,6 +542,7 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "min_tiles_log") g.tuning.min_tiles_log = value;
     else if (k == "single_pass_max_log") g.tuning.single_pass_max_log = value;
     else if (k == "max_digit_log") g.tuning.max_digit_log = value;
+    else if (k == "direct_tw_max_log") g.tuning.direct_tw_max_log = value;
     else if (k == "xcd_remap") g.xcd_remap = value;
     else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
     return SC_OK;

@@ -27,7 +27,7 @@ static void run_pass(const NttPassDesc& pd) {
 }
 
 extern "C" int emu_ntt(const uint64_t* in, uint64_t* out, int logn, const uint64_t* root, int inverse, uint64_t in_limit,
-                       const uint64_t* offset, int max_tile_log, int loge, int single_pass_max_log, int min_tiles_log, int max_col_log, int max_digit_log) {
+                       const uint64_t* offset, int max_tile_log, int loge, int single_pass_max_log, int min_tiles_log, int max_col_log, int max_digit_log, int direct_tw) {
     const uint64_t n = 1ull << logn;
     Fe r = Fe{root[0], root[1]};
     Fe r_m = to_mont(r);
@@ -63,6 +63,23 @@ extern "C" int emu_ntt(const uint64_t* in, uint64_t* out, int logn, const uint64
     io.scale = scale_m;
     NttPlanDesc d;
     if (!plan_ntt(d, logn, tb, io, tu)) return -1;
+    std::vector<Fe> twd[4];
+    if (direct_tw && d.npasses > 1) {
+        int logA = 0;
+        for (int i = 0; i + 1 < d.npasses; ++i) {
+            const int logR = d.digits[i], logB = logn - logA - logR;
+            const uint64_t count = 1ull << (logR + logB);
+            twd[i].resize(count);
+            const Fe* thp = (i == 0 && tb.th_scaled) ? tb.th_scaled : tb.th;
+            for (uint64_t q = 0; q < count; ++q) {
+                uint64_t k = q >> logB, b = q & ((1ull << logB) - 1);
+                twd[i][q] = pow2level(tb.tl, thp, b * k * (1ull << logA));
+            }
+            tb.twd[i] = twd[i].data();
+            logA += logR;
+        }
+        if (!plan_ntt(d, logn, tb, io, tu)) return -1;
+    }
     for (int i = 0; i < d.npasses; ++i) {
         switch (d.pass[i].loge) {
             case 1: run_pass<1>(d.pass[i]); break;

@@ -22,17 +22,17 @@ def emu():
     lib = ctypes.CDLL(so)
     lib.emu_ntt.restype = ctypes.c_int
     lib.emu_ntt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64,
-                            ctypes.c_void_p] + [ctypes.c_int] * 6
+                            ctypes.c_void_p] + [ctypes.c_int] * 7
     lib.emu_field.restype = None
     lib.emu_field.argtypes = [ctypes.c_void_p] * 3
     return lib
 
 
-def run_emu(lib, data, logn, root, inverse=0, in_limit=None, offset=None, tile=12, loge=3, single=11, min_tiles=10, max_col=6, digit=8):
+def run_emu(lib, data, logn, root, inverse=0, in_limit=None, offset=None, tile=12, loge=3, single=11, min_tiles=10, max_col=6, digit=8, direct=1):
     n = 1 << logn
     out = ctypes.create_string_buffer(16 * n)
     rc = lib.emu_ntt(data, out, logn, int(root).to_bytes(16, "little"), inverse, (1 << 64) - 1 if in_limit is None else in_limit,
-                     None if offset is None else int(offset).to_bytes(16, "little"), tile, loge, single, min_tiles, max_col, digit)
+                     None if offset is None else int(offset).to_bytes(16, "little"), tile, loge, single, min_tiles, max_col, digit, direct)
     assert rc > 0, rc
     return out.raw, rc
 
@@ -79,6 +79,11 @@ def test_emu_multi_pass(emu, cfg):
     assert npass >= 2
     assert out == po.C.ntt(root, data, n), cfg
     out, _ = run_emu(emu, data, logn, root, inverse=1, **kw)
+    assert out == po.C.intt(root, data, n), cfg
+    # two-level twiddle lookup instead of the direct tables
+    out, _ = run_emu(emu, data, logn, root, direct=0, **kw)
+    assert out == po.C.ntt(root, data, n), cfg
+    out, _ = run_emu(emu, data, logn, root, inverse=1, direct=0, **kw)
     assert out == po.C.intt(root, data, n), cfg
 
 
