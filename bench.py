@@ -203,7 +203,8 @@ def ntt_passes(log2n):
     """passes the library plans for a 2^log2n transform at default tuning (mirrors csrc/ntt_plan.h plan_num_passes)."""
     if log2n <= 11:
         return 1
-    return max(2, (log2n + 7) // 8)
+    digit = 10 if log2n <= 20 else 8
+    return max(2, (log2n + digit - 1) // digit)
 
 
 if __name__ == "__main__":

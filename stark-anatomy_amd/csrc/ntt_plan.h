@@ -6,14 +6,26 @@
 namespace sc {
 
 struct NttTuning {
-    int max_tile_log = 10;   // LDS tile = 2^max_tile_log elements (16 KiB at 10); measured best 9-10 (tools/sweep.py)
-    int loge = 2;            // elements per thread = 2^loge; 2 measured best (occupancy beats register blocking here)
-    int max_col_log = 6;     // at most 64 columns (1 KiB runs)
-    int min_tiles_log = 10;  // shrink tiles until there are at least this many per pass (fill 256 CUs)
+    // Defaults are the measured optimum on MI355X (tools/ab.py, profiles/): E = 4 elements per thread; up to 2^20 two
+    // passes of <= 2^10 points with 2^12-element tiles (4+ columns), above that three passes of <= 2^8 points with
+    // 2^11-element tiles.  A value of -1 means "choose by size".
+    int max_tile_log = -1;   // LDS tile = 2^max_tile_log elements
+    int loge = 2;            // elements per thread = 2^loge (occupancy beats register blocking: each modmul is a long dependent chain)
+    int max_col_log = -1;    // columns per tile (run length = 16 B << max_col_log)
+    int min_tiles_log = 8;   // shrink tiles (never below 4 columns) until there are at least this many per pass
     int single_pass_max_log = 11;
-    int max_digit_log = 8;   // passes = ceil(logn / max_digit_log)
-    int direct_tw_max_log = 24;  // build direct four-step twiddle tables up to 2^this entries per pass (0 = never)
+    int max_digit_log = -1;  // passes = ceil(logn / max_digit_log)
+    int direct_tw_max_log = 22;  // direct four-step twiddle tables up to 2^this entries per pass (bigger ones cost more HBM than they save)
 };
+
+inline NttTuning resolve_tuning(const NttTuning& in, int logn) {
+    NttTuning t = in;
+    const bool small = logn <= 20;
+    if (t.max_digit_log < 0) t.max_digit_log = small ? 10 : 8;
+    if (t.max_tile_log < 0) t.max_tile_log = small ? 12 : 11;
+    if (t.max_col_log < 0) t.max_col_log = small ? 4 : 6;
+    return t;
+}
 
 struct NttTables {
     const Fe* mt = nullptr;  // mt[e] = w_(2^mt_log)^e, e < 2^(mt_log-1)      (Montgomery form)
@@ -50,15 +62,17 @@ struct NttIo {
     Fe scale = Fe{0, 0};
 };
 
-inline int plan_num_passes(int logn, const NttTuning& tu) {
+inline int plan_num_passes(int logn, const NttTuning& tu_in) {
+    const NttTuning tu = resolve_tuning(tu_in, logn);
     if (logn <= tu.single_pass_max_log) return 1;
     const int m = (logn + tu.max_digit_log - 1) / tu.max_digit_log;
     return m < 2 ? 2 : m;
 }
 
 // Fill the pass descriptors for a length-2^logn transform.  Returns false if unsupported.
-inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo& io, const NttTuning& tu) {
+inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo& io, const NttTuning& tu_in) {
     if (logn < 1 || logn > 32) return false;
+    const NttTuning tu = resolve_tuning(tu_in, logn);
     d.logn = logn;
     const int m = plan_num_passes(logn, tu);
     if (m > 4) return false;
@@ -69,7 +83,12 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
     }
     const uint64_t n = 1ull << logn;
     int tile_cap = tu.max_tile_log;
-    while (tile_cap > 6 && logn - tile_cap < tu.min_tiles_log && m > 1) --tile_cap;
+    {
+        int maxdigit = 0;
+        for (int i = 0; i < m; ++i) maxdigit = d.digits[i] > maxdigit ? d.digits[i] : maxdigit;
+        const int floor_log = maxdigit + 2 < tu.max_tile_log ? maxdigit + 2 : tu.max_tile_log;    // keep >= 4 columns per tile
+        while (tile_cap > floor_log && logn - tile_cap < tu.min_tiles_log && m > 1) --tile_cap;
+    }
 
     int logA = 0;                         // log2 of the product of the digits already transformed
     for (int i = 0; i < m; ++i) {
@@ -172,8 +191,10 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
 enum BatchKind { BATCH_COLS = 0, BATCH_ROWS_T = 1 };
 
 inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, const NttTables& tb,
-                         const Fe* in, Fe* work, Fe* out, const NttTuning& tu) {
+                         const Fe* in, Fe* work, Fe* out, const NttTuning& tu_in) {
     if (loglen < 1 || loglen + logbatch > 34) return false;
+    NttTuning tu = resolve_tuning(tu_in, 24);
+    if (tu_in.max_digit_log < 0) tu.max_digit_log = 8;
     const int m = (loglen <= tu.max_digit_log) ? 1 : 2;
     if (loglen > 2 * tu.max_digit_log + 2) return false;
     d.logn = loglen;
@@ -181,7 +202,10 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
     d.digits[0] = (m == 1) ? loglen : (loglen + 1) / 2;
     d.digits[1] = loglen - d.digits[0];
     int tile_cap = tu.max_tile_log;
-    while (tile_cap > 6 && loglen + logbatch - tile_cap < tu.min_tiles_log) --tile_cap;
+    {
+        const int floor_log = d.digits[0] + 2 < tu.max_tile_log ? d.digits[0] + 2 : tu.max_tile_log;
+        while (tile_cap > floor_log && loglen + logbatch - tile_cap < tu.min_tiles_log) --tile_cap;
+    }
     const uint64_t len = 1ull << loglen, batch = 1ull << logbatch;
     for (int i = 0; i < m; ++i) {
         NttPassDesc& pd = d.pass[i];

@@ -371,7 +371,7 @@ int ntt_device(const Fe* d_in, Fe* d_out, int logn, Fe root, bool inverse_scale,
     if (inverse_scale && m == 1) { io.scale_last = true; io.scale = mont_inv(to_mont(Fe{n, 0})); }
     NttPlanDesc d;
     if (!plan_ntt(d, logn, tb, io, g.tuning)) return fail(SC_ERR_UNSUPPORTED, "unsupported transform length");
-    if (d.npasses > 1 && g.tuning.direct_tw_max_log > 0) {
+    if (d.npasses > 1 && g.tuning.direct_tw_max_log > 0) {   // tables bigger than the cap fall back to the two-level lookup
         // direct twiddle tables (one coalesced load + one modmul per element instead of two loads + two modmuls);
         // keyed by the digit split, rebuilt if the tuning changed it
         bool same = pt->twd_passes == d.npasses;
