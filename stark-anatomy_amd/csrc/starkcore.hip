@@ -200,6 +200,48 @@ struct Ctx {
 Ctx g;
 std::mutex g_mu;
 
+// Small caching allocator for the big short-lived device objects (vectors, Merkle trees): hipMalloc/hipFree of
+// hundreds of MiB cost more than the kernels that fill them.  Exact-size free lists, bounded total.
+std::multimap<size_t, void*> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_CAP = 8ull << 30;
+
+hipError_t pool_alloc(void** p, size_t bytes) {
+    auto it = g_pool.find(bytes);
+    if (it != g_pool.end()) {
+        *p = it->second;
+        g_pool.erase(it);
+        g_pool_bytes -= bytes;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !g_pool.empty()) {          // out of memory: drop the cache and retry
+        (void)hipDeviceSynchronize();
+        for (auto& kv : g_pool) (void)hipFree(kv.second);
+        g_pool.clear();
+        g_pool_bytes = 0;
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+void pool_free(void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes >= (1u << 16) && g_pool_bytes + bytes <= POOL_CAP) {
+        g_pool.emplace(bytes, p);
+        g_pool_bytes += bytes;
+    } else {
+        (void)hipFree(p);
+    }
+}
+
+void pool_clear() {
+    for (auto& kv : g_pool) (void)hipFree(kv.second);
+    g_pool.clear();
+    g_pool_bytes = 0;
+}
+
 int fail(int code, const std::string& msg) {
     g.err = msg;
     return code;
@@ -436,7 +478,8 @@ int download(void* h, const void* d, size_t bytes, hipStream_t st) {
 int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st) {
     if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
     uint64_t* levels = nullptr;
-    HIPCHK(hipMalloc((void**)&levels, (2 * N - 1) * 64));
+    const size_t tree_bytes = (2 * N - 1) * 64;
+    HIPCHK(pool_alloc((void**)&levels, tree_bytes));
     hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_elems, levels, N);
     uint64_t* cur = levels;
     uint64_t w = N;
@@ -448,15 +491,15 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
     }
     if (w > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, cur, w);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { hipFree(levels); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
     e = hipMemcpyAsync(root_out, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { hipFree(levels); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
     if (tree) {
         sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
         *tree = t;
     } else {
-        HIPCHK(hipFree(levels));
+        pool_free(levels, tree_bytes);
     }
     return SC_OK;
 }
@@ -517,6 +560,7 @@ int sc_shutdown(void) {
     if (!g.init) return SC_OK;
     hipDeviceSynchronize();
     free_plans();
+    pool_clear();
     for (auto& b : g.scratch) { if (b.p) hipFree(b.p); b = DevBuf{}; }
     if (g.stream) hipStreamDestroy(g.stream);
     g.stream = nullptr;
@@ -553,7 +597,7 @@ int sc_vec_alloc(uint64_t n, sc_vec_t** out) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     sc_vec* v = new sc_vec{nullptr, n};
-    hipError_t e = hipMalloc((void**)&v->d, (n ? n : 1) * sizeof(Fe));
+    hipError_t e = pool_alloc((void**)&v->d, (n ? n : 1) * sizeof(Fe));
     if (e != hipSuccess) { delete v; return fail(SC_ERR_HIP, hipGetErrorString(e)); }
     *out = v;
     return SC_OK;
@@ -562,7 +606,7 @@ int sc_vec_free(sc_vec_t* v) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!v) return SC_OK;
     hipStreamSynchronize(g.stream);
-    hipFree(v->d);
+    pool_free(v->d, (v->n ? v->n : 1) * sizeof(Fe));
     delete v;
     return SC_OK;
 }
@@ -875,7 +919,7 @@ int sc_merkle_free(sc_merkle_t* tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree) return SC_OK;
     hipStreamSynchronize(g.stream);
-    hipFree(tree->d_levels);
+    pool_free(tree->d_levels, (2 * tree->N - 1) * 64);
     delete tree;
     return SC_OK;
 }

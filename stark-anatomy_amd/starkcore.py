@@ -176,6 +176,17 @@ class DeviceVector:
             pass
 
 
+_struct_cache = {}
+
+
+def _digest_struct(count):
+    import struct
+    st = _struct_cache.get(count)
+    if st is None:
+        st = _struct_cache[count] = struct.Struct("64s" * count)
+    return st
+
+
 class MerkleTree:
     """Owner of an sc_merkle_t: all levels resident in HBM, so `open` is a gather (code/merkle.py:16-27)."""
 
@@ -209,9 +220,10 @@ class MerkleTree:
         idx = (ctypes.c_uint64 * k)(*[int(i) for i in indices])
         out = ctypes.create_string_buffer(64 * self.depth * k)
         _check(lib().sc_merkle_open_batch(self._h, idx, k, out))
-        raw = out.raw
+        # one C-level pass creates all the 64-byte digest objects (they end up, one by one, in the transcript)
         d = self.depth
-        return [[raw[64 * (q * d + l):64 * (q * d + l + 1)] for l in range(d)] for q in range(k)]
+        digests = _digest_struct(d * k).unpack_from(out)
+        return [list(digests[q * d:(q + 1) * d]) for q in range(k)]
 
     def open(self, index):
         return self.open_batch([index])[0]

@@ -320,11 +320,52 @@ def gen_pickle():
     dump("transcript.json", out)
 
 
+def gen_stark():
+    """Rescue-Prime parameters (data) + a seeded FastStark run (fast_stark.py:76-178 with os.urandom patched)."""
+    import fast_stark as ref_fast_stark
+    import rescue_prime as ref_rp
+    rp = ref_rp.RescuePrime()
+    params = {"p": str(rp.p), "m": rp.m, "N": rp.N, "alpha": rp.alpha, "alphainv": str(rp.alphainv),
+              "MDS": [[str(x.value) for x in row] for row in rp.MDS], "MDSinv": [[str(x.value) for x in row] for row in rp.MDSinv],
+              "round_constants": [str(c.value) for c in rp.round_constants]}
+    params["kat_hash"] = [[str(v), str(rp.hash(fe(v)).value)] for v in [1, 57322816861100832358702415967512842988, int(field.sample(b"0xdeadbeef").value)]]
+    dump("rescue_prime_params.json", params)
+
+    out = {"runs": []}
+    for seed, s_checks in [(7, 2), (11, 3)]:
+        rng = random.Random(seed)
+        ref_fast_stark.os.urandom = lambda k, rng=rng: bytes(rng.getrandbits(8) for _ in range(k))
+        ef, sec = 4, 2
+        input_element = field.sample(b"0xdeadbeef")
+        output_element = rp.hash(input_element)
+        stark = ref_fast_stark.FastStark(field, ef, s_checks, sec, rp.m, rp.N + 1)
+        tz, tzc, tzr = stark.preprocess()
+        trace = rp.trace(input_element)
+        air = rp.transition_constraints(stark.omicron)
+        boundary = rp.boundary_constraints(output_element)
+        t0 = time.time()
+        proof = stark.prove(trace, air, boundary, tz, tzc)
+        ok = stark.verify(proof, air, boundary, tzr)
+        bad = stark.verify(proof, air, rp.boundary_constraints(output_element + field.one()), tzr)
+        ps = ref_ip.ProofStream().deserialize(proof)
+        out["runs"].append({"urandom_seed": seed, "expansion_factor": ef, "num_colinearity_checks": s_checks, "security_level": sec,
+                            "input": str(input_element.value), "output": str(output_element.value),
+                            "omicron_domain_length": stark.omicron_domain_length, "fri_domain_length": stark.fri_domain_length,
+                            "zerofier_coeffs_sha256": sha_packed(tz.coefficients), "zerofier_root": tzr.hex(),
+                            "proof_len": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "num_objects": len(ps.objects),
+                            "first_roots": [o.hex() for o in ps.objects[:rp.m + 1]], "verifies": ok, "false_claim_verifies": bad})
+        print("fast stark seed", seed, "%.1fs" % (time.time() - t0), ok, bad, flush=True)
+    dump("fast_stark.json", out)
+
+
 if __name__ == "__main__":
     big = "--big" in sys.argv
-    if big:
+    if "--stark" in sys.argv:
+        gen_stark()
+    elif big:
         gen_ntt(True)
     else:
+        gen_stark()
         gen_field()
         gen_ntt(False)
         gen_poly()
