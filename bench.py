@@ -181,8 +181,9 @@ def main():
             "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
                        "passes_per_transform": passes, "roundtrip_bit_exact": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "ntt_pass_kernel" if world == 1 else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
-                         "note": "VALU-bound 128-bit modmul; see DESIGN.md"},
+                         "traffic": measured_traffic(log2n) if world == 1 else None, "kernel": "ntt_pass_kernel" if world == 1 else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
+                         "alg_bytes_per_launch": alg_bytes_per_launch,
+                         "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from profiles/ (PMC passes); kernel is VALU-bound (128-bit modmul), see DESIGN.md"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
@@ -192,6 +193,20 @@ def main():
         dist.destroy_process_group()
     if not ok:
         sys.exit("round trip mismatch")
+
+
+def measured_traffic(log2n):
+    """HBM bytes per ntt_pass_kernel launch from the committed rocprofv3 PMC runs (profiles/*/traffic.json), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json"))):
+        try:
+            rec = json.load(open(f)).get(str(log2n))
+            if rec:
+                best = rec["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
 
 
 def ctypes_void(v):
