@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=None, help="override the transform size")
     ap.add_argument("--cpu-sample-log2n", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the Fri.prove / LDE side measurements")
     args = ap.parse_args()
 
     import torch
@@ -185,6 +186,11 @@ def main():
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from profiles/ (PMC passes); kernel is VALU-bound (128-bit modmul), see DESIGN.md"},
         }
+        if not args.no_extras and world == 1:
+            try:
+                out["extras"] = extras(sc, lib)
+            except Exception as e:       # side measurements never invalidate the headline
+                out["extras"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
         print(json.dumps(out), flush=True)
@@ -193,6 +199,51 @@ def main():
         dist.destroy_process_group()
     if not ok:
         sys.exit("round trip mismatch")
+
+
+def extras(sc, lib):
+    """The other BASELINE.json configs, timed on the side (best of 3, device-resident inputs, library stream):
+    configs[2] LDE of 2^18 coefficients at blowup 8, configs[3] Fri.prove on a 2^22 codeword (ef 4, 40 checks)."""
+    import synth
+    from algebra import Field
+    from fri import Fri
+    from ip import ProofStream
+    GEN = 85408008396924667383611388730472331217
+    field = Field.main()
+    res = {}
+    # configs[2]: fast_coset_evaluate, 2^18 coefficients -> 2^21 values
+    m, order = 1 << 18, 1 << 21
+    om = field.primitive_nth_root(order)
+    coeffs = sc.DeviceVector.from_bytes(synth.synth_packed(5, m).tobytes())
+    outv = sc.DeviceVector(order)
+    best = None
+    for _ in range(4):
+        sc.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            sc._check(lib.sc_coset_evaluate_dev(coeffs.ptr, m, sc.fe_bytes(GEN), sc.fe_bytes(om.value), order, outv.ptr, None))
+        sc.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        best = dt if best is None or dt < best else best
+    res["lde_2p18_to_2p21"] = {"ms": best * 1e3, "alg_GBps": 16 * (m + order) / best / 1e9}
+    # configs[3]: Fri.prove, N = 2^22
+    N = 1 << 22
+    om = field.primitive_nth_root(N)
+    coeffs = sc.DeviceVector.from_bytes(synth.synth_packed(4002, N // 4).tobytes())
+    cwv = sc.DeviceVector(N)
+    sc._check(lib.sc_coset_evaluate_dev(coeffs.ptr, N // 4, sc.fe_bytes(GEN), sc.fe_bytes(om.value), N, cwv.ptr, None))
+    sc.synchronize()
+    fr = Fri(field.generator(), om, N, 4, 40)
+    best = None
+    for _ in range(3):
+        cw = sc.DeviceCodeword(cwv, field)
+        ps = ProofStream()
+        t0 = time.perf_counter()
+        fr.prove(cw, ps)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    res["fri_prove_2p22_ef4_s40"] = {"ms": best * 1e3, "rounds": fr.num_rounds(), "proof_objects": len(ps.objects)}
+    return res
 
 
 def measured_traffic(log2n):

@@ -168,17 +168,19 @@ __device__ __forceinline__ Fe fe_add_asm(Fe a, Fe b) {
 }
 
 __device__ __forceinline__ Fe fe_sub_asm(Fe a, Fe b) {
-    smask_t bw, c;
+    smask_t bw;
     uint32_t d0 = a_sub_co(lo32(a.lo), lo32(b.lo), bw);
     uint32_t d1 = a_subb(hi32(a.lo), hi32(b.lo), bw, bw);
     uint32_t d2 = a_subb(lo32(a.hi), lo32(b.hi), bw, bw);
     uint32_t d3 = a_subb(hi32(a.hi), hi32(b.hi), bw, bw);
-    // add p back where the subtraction borrowed
-    uint32_t e0 = a_add_co(d0, 1u, c);
-    uint32_t e1 = a_addc(d1, 0u, c, c);
-    uint32_t e2 = a_addc(d2, 0u, c, c);
-    uint32_t e3 = a_addc_last(d3, PH3, c);
-    uint32_t o0 = a_cnd(d0, e0, bw), o1 = a_cnd(d1, e1, bw), o2 = a_cnd(d2, e2, bw), o3 = a_cnd(d3, e3, bw);
+    // add p = [1, 0, 0, PH3] back where the subtraction borrowed: the borrow mask is the carry-in of limb 0 and
+    // selects PH3 for limb 3 (5 instructions instead of a full add chain + 4 selects)
+    smask_t c;
+    uint32_t ph = a_cnd(0u, PH3, bw);
+    uint32_t o0 = a_addc(d0, 0u, bw, c);
+    uint32_t o1 = a_addc(d1, 0u, c, c);
+    uint32_t o2 = a_addc(d2, 0u, c, c);
+    uint32_t o3 = a_addc_last(d3, ph, c);
     return Fe{((uint64_t)o1 << 32) | o0, ((uint64_t)o3 << 32) | o2};
 }
 
