@@ -133,6 +133,41 @@ def test_ntt_full_size_properties(sc, logn):
         assert yb == C.ntt(root, xin, n)            # the oracle still finishes in seconds here
 
 
+def test_ntt_four_pass_plan_2p25(sc):
+    """Largest plan shape (four passes, digits 7+6+6+6): round trip, and agreement with a different digit split."""
+    n = 1 << 25
+    root = po.primitive_nth_root(n)
+    x = sc.DeviceVector.from_bytes(packed(725, n))
+    y = sc.DeviceVector(n)
+    z = sc.DeviceVector(n)
+    lib = sc.lib()
+    sc._check(lib.sc_ntt_dev(x.ptr, y.ptr, n, sc.fe_bytes(root), 0, None))
+    sc._check(lib.sc_ntt_dev(y.ptr, z.ptr, n, sc.fe_bytes(root), 1, None))
+    sc.synchronize()
+    xin = x.to_bytes()
+    assert z.to_bytes() == xin
+    yb = y.to_bytes()
+    sc.set_tuning("max_digit_log", 9)          # three passes (9+8+8) instead of four
+    try:
+        sc._check(lib.sc_ntt_dev(x.ptr, z.ptr, n, sc.fe_bytes(root), 0, None))
+        sc.synchronize()
+        assert z.to_bytes() == yb
+    finally:
+        sc.set_tuning("max_digit_log", -1)
+    # spot check against the definition: X[1] = sum_j x_j root^j  (exact, on the host)
+    import numpy as np
+    a = np.frombuffer(xin, dtype=np.uint64).reshape(n, 2)
+    m = 1 << 12                                  # X[k] for k = n/m * t is a length-m DFT of the m-decimated sums
+    lo = a[:, 0].reshape(-1, m).astype(object).sum(axis=0)
+    hi = a[:, 1].reshape(-1, m).astype(object).sum(axis=0)
+    folded = [(int(l) + (int(h) << 64)) % P for l, h in zip(lo, hi)]       # s[r] = sum_q x[q*m + r]
+    rm = pow(root, n // m, P)
+    for t in (1, 5, m - 1):
+        expect = sum(v * pow(rm, (t * r) % m, P) for r, v in enumerate(folded)) % P
+        k = (n // m) * t
+        assert int.from_bytes(yb[16 * k:16 * k + 16], "little") == expect
+
+
 def test_ntt_errors(sc):
     data = packed(1, 8)
     with pytest.raises(AssertionError):
