@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--cpu-sample-log2n", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the Fri.prove / LDE side measurements")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU four-step code path (RCCL init, all-to-all) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -79,9 +80,11 @@ def main():
     sc.init(local_rank)
     lib = sc.lib()
 
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from sharded import ShardedNtt
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
@@ -101,7 +104,7 @@ def main():
     sptr = ctypes_void(stream.cuda_stream)
     assert stream.cuda_stream != 0
 
-    if world == 1:
+    if not sharded:
         log2n = args.log2n or 20
         n = 1 << log2n
         root = sc.fe_bytes(nth_root(n))
@@ -121,7 +124,7 @@ def main():
     else:
         log2n = args.log2n or (20 + (world.bit_length() - 1) + 1)     # 2^21 per GPU: 8 GPUs -> 2^24
         n = 1 << log2n
-        eng = ShardedNtt(log2n, nth_root(n), rank, world, dev)
+        eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True)
         x = eng.synthetic_input(seed=1)
         y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
         z = torch.empty_like(x)
@@ -136,8 +139,7 @@ def main():
         parallelism = "four-step, column-sharded, 1 all-to-all per transform"
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,8 +155,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
-    if world > 1:
-        import torch.distributed as dist
+    if sharded:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -169,7 +170,7 @@ def main():
         # algorithmic bytes per launch = 32 B/element/transform * n elements / passes-per-transform
         passes = launches_per_step // 2
         avg_launch_s = (ev_ms * 1e-3) / (args.steps * launches_per_step)
-        if world > 1:
+        if sharded:
             passes = None
             alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * (total_n / world)     # per rank, per transform
         else:
@@ -182,20 +183,19 @@ def main():
             "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
                        "passes_per_transform": passes, "roundtrip_bit_exact": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(log2n) if world == 1 else None, "kernel": "ntt_pass_kernel" if world == 1 else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
+                         "traffic": measured_traffic(log2n) if not sharded else None, "kernel": "ntt_pass_kernel" if not sharded else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from profiles/ (PMC passes); kernel is VALU-bound (128-bit modmul), see DESIGN.md"},
         }
-        if not args.no_extras and world == 1:
+        if not args.no_extras and not sharded:
             try:
                 out["extras"] = extras(sc, lib)
             except Exception as e:       # side measurements never invalidate the headline
                 out["extras"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    if sharded:
         dist.destroy_process_group()
     if not ok:
         sys.exit("round trip mismatch")

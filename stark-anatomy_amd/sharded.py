@@ -47,12 +47,13 @@ class HipEngine:
 
 
 class ShardedNtt:
-    def __init__(self, log2n, root, rank, world, device, engine=None, group=None):
+    def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False):
         assert world & (world - 1) == 0, "world size must be a power of two"
         self.log2n, self.n = log2n, 1 << log2n
         self.root = int(root)
         assert pow(self.root, self.n, P) == 1 and pow(self.root, self.n // 2, P) != 1, "root must be a primitive n-th root"
         self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.always_exchange = always_exchange     # run the all-to-all even for a world of one rank (exercises the RCCL path)
         self.n1 = 1 << ((log2n + 1) // 2)
         self.n2 = self.n // self.n1
         assert self.n2 >= world and self.n1 >= world, "domain too small to shard over this many ranks"
@@ -105,7 +106,7 @@ class ShardedNtt:
     def exchange(self, a, R, C):
         """(3) corner turn: rank h receives rows [h*R/G, (h+1)*R/G) of every rank's slab -> [R/G][C]."""
         G = self.world
-        if G == 1:
+        if G == 1 and not self.always_exchange:
             return a
         rw, cw = R // G, C // G
         recv = self._buf("recv", (G, rw, cw, 2))

@@ -105,3 +105,23 @@ def test_batched_entry_points_vs_oracle(sc):
     ints = synth.unpack_ints(host.tobytes())
     exp = [ints[r * cols + c] * pow(root, r * (32 + c), po.P) * scale % po.P for r in range(rows) for c in range(cols)]
     assert got == exp
+
+
+def test_bench_sharded_path_under_torchrun_one_rank():
+    """bench.py's N > 1 code path (RCCL process group, all_to_all_single on the bench stream, max-over-ranks timing,
+    JSON line) launched exactly like the driver launches it, with a world of one rank on this box's single GPU."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-sharded", "--log2n", "20", "--steps", "5", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["config"]["roundtrip_bit_exact"] is True and out["n_gpus"] == 1 and out["value"] > 0
+    assert "fourstep" in out["config"]["workload"]
