@@ -106,6 +106,8 @@ int sc_merkle_build(const void* elems, uint64_t N, uint8_t root_out[64], sc_merk
 int sc_merkle_build_dev(const void* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree, void* stream); /* sync (returns root) */
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */
 int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out /* k*64*log2 N */);
+/* opened elements AND their paths in one call: elems_out[i] = d_elems[indices[i]] (d_elems = the device vector the tree was built from) */
+int sc_merkle_query_dev(const sc_merkle_t* tree, const void* d_elems, const uint64_t* indices, uint64_t k, void* elems_out, uint8_t* paths_out);
 uint64_t sc_merkle_leaves(const sc_merkle_t* tree);
 int sc_merkle_free(sc_merkle_t* tree);
 

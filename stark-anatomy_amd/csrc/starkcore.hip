@@ -913,6 +913,34 @@ int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint6
     HIPCHK(hipGetLastError());
     return download(paths_out, d_out, out_bytes, g.stream);
 }
+// elements + authentication paths for k indices in one round trip (the FRI query phase, code/fri.py:98-113)
+int sc_merkle_query_dev(const sc_merkle_t* tree, const void* d_elems, const uint64_t* indices, uint64_t k, void* elems_out, uint8_t* paths_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_elems) return fail(SC_ERR_BAD_ARG, "null tree or vector");
+    for (uint64_t i = 0; i < k; ++i) if (indices[i] >= tree->N) return fail(SC_ERR_BAD_ARG, "cannot open invalid index");
+    if (k == 0) return SC_OK;
+    const size_t idx_bytes = (k * 8 + 255) & ~255ull;
+    const size_t el_bytes = (k * sizeof(Fe) + 255) & ~255ull;
+    const size_t path_bytes = k * 64 * (size_t)tree->logN;
+    void* buf;
+    SCCHK(scratch(5, idx_bytes + el_bytes + path_bytes + 256, &buf));
+    uint64_t* d_idx = (uint64_t*)buf;
+    Fe* d_el = (Fe*)((char*)buf + idx_bytes);
+    uint64_t* d_paths = (uint64_t*)((char*)buf + idx_bytes + el_bytes);
+    SCCHK(upload(d_idx, indices, k * 8, g.stream));
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, g.stream, (const Fe*)d_elems, d_idx, k, d_el);
+    if (tree->logN > 0) {
+        uint64_t total = k * (uint64_t)tree->logN * 4;
+        hipLaunchKernelGGL(merkle_open_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g.stream, tree->d_levels, tree->N, tree->logN, d_idx, k, d_paths);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(elems_out, d_el, k * sizeof(Fe), hipMemcpyDeviceToHost, g.stream));
+    if (path_bytes) HIPCHK(hipMemcpyAsync(paths_out, d_paths, path_bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return SC_OK;
+}
+
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out) { return sc_merkle_open_batch(tree, &index, 1, path_out); }
 uint64_t sc_merkle_leaves(const sc_merkle_t* tree) { return tree ? tree->N : 0; }
 int sc_merkle_free(sc_merkle_t* tree) {

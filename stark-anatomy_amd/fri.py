@@ -94,12 +94,11 @@ class Fri:
         s = self.num_colinearity_tests
         a_indices = [index for index in c_indices]
         b_indices = [index + len(current_codeword) // 2 for index in c_indices]
-        ab = current_codeword.gather(a_indices + b_indices)
-        cs = next_codeword.gather(c_indices)
+        # one round trip per codeword: opened entries and their authentication paths together
+        ab, ab_paths = current_codeword.query(a_indices[:s] + b_indices[:s])
+        cs, c_paths = next_codeword.query(c_indices[:s])
         for i in range(s):
-            proof_stream.push((ab[i], ab[len(a_indices) + i], cs[i]))
-        ab_paths = current_codeword.tree().open_batch(a_indices[:s] + b_indices[:s])
-        c_paths = next_codeword.tree().open_batch(c_indices[:s])
+            proof_stream.push((ab[i], ab[s + i], cs[i]))
         for i in range(s):
             proof_stream.push(ab_paths[i])
             proof_stream.push(ab_paths[s + i])
@@ -110,11 +109,37 @@ class Fri:
         assert(self.domain_length == len(codeword)), "initial codeword length does not match length of initial codeword"
         codewords = self.commit(codeword, proof_stream)
         top_level_indices = self.sample_indices(proof_stream.prover_fiat_shamir(), len(codewords[0]) // 2, len(codewords[-1]), self.num_colinearity_tests)
-        indices = [index for index in top_level_indices]
-        for i in range(len(codewords) - 1):
-            indices = [index % (len(codewords[i]) // 2) for index in indices]
-            self.query(codewords[i], codewords[i + 1], indices, proof_stream)
+        self._query_all(codewords, top_level_indices, proof_stream)
         return top_level_indices
+
+    def _query_all(self, codewords, top_level_indices, proof_stream):
+        """The query phase of fri.py:124-128 with ONE device round trip per codeword: everything a codeword has to open
+        (its a/b entries for its own round, the c entries of the previous round) is fetched together, then pushed in the
+        reference's order (per round: s triples, then 3*s paths as a, b, c)."""
+        s = self.num_colinearity_tests
+        rounds = len(codewords) - 1
+        per_round, indices = [], [index for index in top_level_indices]
+        for i in range(rounds):
+            indices = [index % (len(codewords[i]) // 2) for index in indices]
+            per_round.append(indices)
+        fetched = []
+        for j, cw in enumerate(codewords):
+            request = []
+            if j < rounds:
+                request += per_round[j][:s] + [index + len(cw) // 2 for index in per_round[j][:s]]
+            if j > 0:
+                request += per_round[j - 1][:s]
+            fetched.append(cw.query(request))
+        for i in range(rounds):
+            entries, paths = fetched[i]
+            next_entries, next_paths = fetched[i + 1]
+            c_at = 2 * s if i + 1 < rounds else 0
+            for t in range(s):
+                proof_stream.push((entries[t], entries[s + t], next_entries[c_at + t]))
+            for t in range(s):
+                proof_stream.push(paths[t])
+                proof_stream.push(paths[s + t])
+                proof_stream.push(next_paths[c_at + t])
 
     def _last_codeword_degree(self, last_codeword, last_omega, last_offset):
         """Degree of the interpolant of the last codeword on its coset: intt + unscale (the route the

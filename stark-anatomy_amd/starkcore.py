@@ -53,6 +53,7 @@ SIGNATURES = {
     "sc_merkle_build_dev": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
     "sc_merkle_open_batch": (_int, [_vp, _vp, _u64, _vp]),
+    "sc_merkle_query_dev": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "sc_merkle_leaves": (_u64, [_vp]),
     "sc_merkle_free": (_int, [_vp]),
 }
@@ -318,3 +319,29 @@ class DeviceCodeword(Sequence):
         if self._tree is None:
             self._tree = MerkleTree.from_device(self.vec)
         return self._tree
+
+    def query(self, indices):
+        """One device round trip: the entries at `indices` (identity-preserving, like gather) and one freshly created
+        authentication path per requested index (paths are new objects every time, as in the reference, which
+        recomputes them per Merkle.open call)."""
+        tree = self.tree()
+        k = len(indices)
+        if k == 0:
+            return [], []
+        idx = (ctypes.c_uint64 * k)(*[int(i) for i in indices])
+        d = tree.depth
+        elems = ctypes.create_string_buffer(16 * k)
+        paths = ctypes.create_string_buffer(64 * d * k if d else 64)
+        _check(lib().sc_merkle_query_dev(tree._h, self.vec.ptr, idx, k, elems, paths))
+        values = unpack(elems.raw, k)
+        out = []
+        if self._full is not None:
+            out = [self._full[i] for i in indices]
+        else:
+            known = self._elems
+            for i, v in zip(indices, values):
+                if i not in known:
+                    known[i] = self._fe(v)
+                out.append(known[i])
+        digests = _digest_struct(d * k).unpack_from(paths) if d else ()
+        return out, [list(digests[q * d:(q + 1) * d]) for q in range(k)]
