@@ -71,6 +71,11 @@ int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2]
 /* kind 0: d_in [len][batch] row-major, transform along axis 0 for every column, same layout out (natural order).
  * kind 1: d_in [batch][len], transform every row, output TRANSPOSED d_out [len][batch].  root: primitive len-th root. */
 int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2], void* stream);
+/* the same with the two fusions the sharded transform uses: kind 0 may multiply output (row r, column c) by
+ * outer_root^(r * (outer_col_base + c)) [* outer_order^-1 if outer_scale_ninv] in its store epilogue (outer_root NULL = off);
+ * kind 1 may read its input as [chunks][batch][len/chunks] (the layout all_to_all_single delivers) instead of [batch][len]. */
+int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2],
+                        const uint64_t outer_root[2], uint64_t outer_order, uint64_t outer_col_base, int outer_scale_ninv, uint64_t chunks, void* stream);
 /* d_data[r][c] *= root^((row_base + r) * (col_base + c)) * scale, root of order `order` (scale may be NULL = 1) */
 int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t row_base, uint64_t col_base, const uint64_t root[2], uint64_t order,
                           const uint64_t scale[2], void* stream);

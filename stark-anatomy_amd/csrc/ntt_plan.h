@@ -136,6 +136,7 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
             p.rfast_load = 0;
             p.tw_enable = 1;
             p.tw_scale = 1ull << logA;
+            p.tw_row_k = 1;
             p.twd = tb.twd[i];
             p.twd_stride = 1ull << logB;
             pd.ntiles = (uint32_t)(n >> (logR + logC));
@@ -190,8 +191,20 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
 // At most two passes each (len <= 2^(2*max_digit_log)); tables are those of a primitive len-th root.
 enum BatchKind { BATCH_COLS = 0, BATCH_ROWS_T = 1 };
 
+// Optional extras of the batched plans (multi-GPU four-step):
+//   outer_*  (BATCH_COLS): multiply output element (row r, column c) by w_n^(r * (outer_col_base + c)) [* scale folded into
+//            outer_th] in the store epilogue of the last pass -- the four-step twiddle between the two stages;
+//   chunks_log (BATCH_ROWS_T): the input is [2^chunks_log][batch][len / 2^chunks_log] (what all_to_all_single leaves behind)
+//            instead of [batch][len]; handled in the load addresses of the first pass, no reassembly copy.
+struct BatchExtras {
+    const Fe* outer_tl = nullptr;
+    const Fe* outer_th = nullptr;
+    uint64_t outer_col_base = 0;
+    int chunks_log = 0;
+};
+
 inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, const NttTables& tb,
-                         const Fe* in, Fe* work, Fe* out, const NttTuning& tu_in) {
+                         const Fe* in, Fe* work, Fe* out, const NttTuning& tu_in, const BatchExtras& ex = BatchExtras()) {
     if (loglen < 1 || loglen + logbatch > 34) return false;
     NttTuning tu = resolve_tuning(tu_in, 24);
     if (tu_in.max_digit_log < 0) tu.max_digit_log = 8;
@@ -248,6 +261,18 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
             p.tw_enable = lastp ? 0 : 1;
             p.tw_col_shift = logbatch;
             p.tw_scale = 1ull << logA;
+            p.tw_row_k = 1;
+            if (lastp && ex.outer_tl) {
+                // fused outer twiddle: natural output row = t_mid + N_1 * k (two passes) or k (one pass); column = local column
+                p.tw_enable = 1;
+                p.tw_col_shift = 0;
+                p.tw_scale = 1;
+                p.tw_col_base = ex.outer_col_base;
+                p.tw_row_k = 1ull << logA;
+                p.tw_row_mid = (m == 2) ? 1 : 0;
+                p.tl = ex.outer_tl;
+                p.th = ex.outer_th;
+            }
             pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
         } else if (!lastp) {
             // rows, first digit: [batch][R][B = N_2]: t_lo = column block, t_mid = (none), t_hi = batch row
@@ -263,9 +288,17 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
             p.in_hi = p.out_hi = len;
             p.in_rs = p.out_rs = 1ull << logB;
             p.in_cs = p.out_cs = 1;
+            if (ex.chunks_log) {
+                // element (b, j) of the row sits at chunk (j / cw), row b, offset (j % cw), cw = len / chunks
+                if (ex.chunks_log >= logR) return false;          // chunk boundaries must fall on whole rows of this pass
+                p.in_hi = len >> ex.chunks_log;                   // next batch row inside a chunk
+                p.in_split = logR - ex.chunks_log;
+                p.in_rs_hi = (len >> ex.chunks_log) << logbatch;  // next chunk
+            }
             p.rfast_load = 0;
             p.tw_enable = 1;
             p.tw_scale = 1;
+            p.tw_row_k = 1;
             pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
         } else {
             // rows, last digit: C adjacent batch rows x R contiguous; output [k][batch row], k = k_1 + N_1 * k_2
@@ -280,6 +313,14 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
             p.in_cs = len;
             p.in_hi = len << logC;
             p.in_mid = 1ull << logR;
+            if (ex.chunks_log && m == 1) {
+                // single (transposing) pass straight from the chunked layout
+                if (ex.chunks_log >= logR) return false;
+                p.in_cs = len >> ex.chunks_log;
+                p.in_hi = (len >> ex.chunks_log) << logC;
+                p.in_split = logR - ex.chunks_log;
+                p.in_rs_hi = (len >> ex.chunks_log) << logbatch;
+            }
             p.out_cs = 1;
             p.out_hi = 1ull << logC;
             p.out_mid = batch;

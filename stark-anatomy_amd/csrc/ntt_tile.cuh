@@ -31,6 +31,10 @@ struct PassParams {
     // tile id t -> (t_hi, t_mid, t_lo);  t_lo = t & (2^lo_log - 1), t_mid = (t >> lo_log) & (2^mid_log - 1)
     int lo_log, mid_log;
     uint64_t in_hi, in_mid, in_lo, in_rs, in_cs;      // element strides (units of Fe)
+    // optional split of the input row stride (chunked input left by the all-to-all of the multi-GPU four-step):
+    // row r contributes (r & (2^in_split - 1)) * in_rs + (r >> in_split) * in_rs_hi ; in_split = 0 disables the split
+    int in_split;
+    uint64_t in_rs_hi;
     uint64_t out_hi, out_mid, out_lo, out_rs, out_cs;
     int rfast_load;            // round 0 maps lanes along rows (transposing pass: in_rs == 1)
     // butterfly twiddles: mt[e << mt_shift] = w_R^e in Montgomery form, e < R/2
@@ -40,6 +44,9 @@ struct PassParams {
     int tw_enable;
     int tw_col_shift;          // colidx >>= tw_col_shift (batched column transforms: low column bits are the batch, not the transform)
     uint64_t tw_scale;
+    // generalisation used by the fused OUTER twiddle of the multi-GPU four-step: exponent =
+    //   (tw_col_base + colidx) * (k * tw_row_k + t_mid * tw_row_mid) * tw_scale      (defaults 0, 1, 0 give the plain form)
+    uint64_t tw_col_base, tw_row_k, tw_row_mid;
     const Fe* tl;
     const Fe* th;
     // optional direct table of the same twiddles: twd[k * twd_stride + colidx] = w_n^(colidx * k * tw_scale) [* n^-1];
@@ -125,7 +132,9 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
         const uint32_t rrem = rr[g], c = cc[g];
         const uint32_t r = ((rrem >> sh) << (sh + S)) | ((uint32_t)fi << sh) | (rrem & ((1u << sh) - 1u));
         if (first) {
-            uint64_t j = (uint64_t)t_hi * P.in_hi + (uint64_t)t_mid * P.in_mid + (uint64_t)t_lo * P.in_lo + (uint64_t)r * P.in_rs + (uint64_t)c * P.in_cs;
+            uint64_t j = (uint64_t)t_hi * P.in_hi + (uint64_t)t_mid * P.in_mid + (uint64_t)t_lo * P.in_lo + (uint64_t)c * P.in_cs;
+            if (P.in_split) j += (uint64_t)(r & ((1u << P.in_split) - 1u)) * P.in_rs + (uint64_t)(r >> P.in_split) * P.in_rs_hi;
+            else j += (uint64_t)r * P.in_rs;
             Fe v = fe_zero();
             if (j < P.in_limit) {
                 v = P.in[j];
@@ -172,11 +181,11 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
             const uint32_t k = bitrev32(r, logR);
             Fe v = x[i];
             if (P.tw_enable) {
-                const uint64_t colidx = (((uint64_t)t_lo << logC) | c) >> P.tw_col_shift;
+                const uint64_t colidx = ((((uint64_t)t_lo << logC) | c) >> P.tw_col_shift) + P.tw_col_base;
                 if (P.twd) {
                     v = mont_mul(v, P.twd[(uint64_t)k * P.twd_stride + colidx]);
                 } else {
-                    const uint64_t e = colidx * (uint64_t)k * P.tw_scale;
+                    const uint64_t e = colidx * ((uint64_t)k * P.tw_row_k + (uint64_t)t_mid * P.tw_row_mid) * P.tw_scale;
                     v = mont_mul(v, pow2level(P.tl, P.th, e));
                 }
             }

@@ -680,12 +680,16 @@ int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int in
 }
 
 // ---- batched transforms + outer twiddle (building blocks of the multi-GPU four-step NTT)
-int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2], void* stream) {
+int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2],
+                        const uint64_t outer_root[2], uint64_t outer_order, uint64_t outer_col_base, int outer_scale_ninv, uint64_t chunks, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     hipStream_t st = pick_stream(stream);
     if (!is_pow2(len) || !is_pow2(batch) || len < 2) return fail(SC_ERR_NOT_POW2, "batched ntt needs power-of-two length >= 2 and batch");
     if (kind != 0 && kind != 1) return fail(SC_ERR_BAD_ARG, "kind must be 0 (columns) or 1 (rows, transposed output)");
+    if (chunks == 0) chunks = 1;
+    if (!is_pow2(chunks) || (chunks > 1 && kind != 1)) return fail(SC_ERR_BAD_ARG, "chunked input is for kind 1 and needs a power-of-two chunk count");
+    if (outer_root && kind != 0) return fail(SC_ERR_BAD_ARG, "the outer twiddle belongs to the column stage (kind 0)");
     Fe rt = fe_from(root);
     SCCHK(check_root(rt, len));
     const int loglen = ilog2(len), logbatch = ilog2(batch);
@@ -693,14 +697,34 @@ int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch
     SCCHK(get_plan(rt, loglen, false, st, &pt));
     NttTables tb;
     tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
+    BatchExtras ex;
+    ex.chunks_log = ilog2(chunks);
+    if (outer_root) {
+        if (!is_pow2(outer_order) || outer_order < len * batch) return fail(SC_ERR_BAD_ARG, "outer twiddle order too small");
+        if ((len - 1) * (outer_col_base + batch - 1) >= outer_order) return fail(SC_ERR_BAD_ARG, "outer twiddle exponent out of range");
+        Fe ort = fe_from(outer_root);
+        SCCHK(check_root(ort, outer_order));
+        PlanTables* po;
+        SCCHK(get_plan(ort, ilog2(outer_order), outer_scale_ninv != 0, st, &po));
+        ex.outer_tl = po->tl;
+        ex.outer_th = outer_scale_ninv ? po->th_ninv : po->th;
+        ex.outer_col_base = outer_col_base;
+        // get_plan may have rehashed the map: re-fetch the inner tables
+        SCCHK(get_plan(rt, loglen, false, st, &pt));
+        tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
+    }
     void* w;
     SCCHK(scratch(0, len * batch * sizeof(Fe), &w));
     NttPlanDesc d;
-    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)d_in, (Fe*)w, (Fe*)d_out, g.tuning))
+    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)d_in, (Fe*)w, (Fe*)d_out, g.tuning, ex))
         return fail(SC_ERR_UNSUPPORTED, "unsupported batched transform shape");
     if (d.npasses == 2 && kind == 0 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "two-pass column transform must be out of place");
     if (kind == 1 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "transposing row transform must be out of place");
     return run_plan(d, st);
+}
+
+int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2], void* stream) {
+    return sc_ntt_batch_ex_dev(d_in, d_out, len, batch, kind, root, nullptr, 0, 0, 0, 1, stream);
 }
 
 int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t row_base, uint64_t col_base, const uint64_t root[2], uint64_t order,

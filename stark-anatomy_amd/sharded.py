@@ -45,6 +45,22 @@ class HipEngine:
     def twiddle(self, buf, rows, cols, row_base, col_base, root, order, scale):
         self.sc._check(self.lib.sc_twiddle_matrix_dev(buf.data_ptr(), rows, cols, row_base, col_base, _fe(root), order, _fe(scale), self.sptr))
 
+    # fused variants (one kernel sequence each; no separate twiddle pass, no reassembly copy)
+    def cols_ntt_twiddled(self, src, dst, length, batch, root, outer_root, order, col_base, scale_ninv):
+        rc = self.lib.sc_ntt_batch_ex_dev(src.data_ptr(), dst.data_ptr(), length, batch, 0, _fe(root), _fe(outer_root), order, col_base,
+                                          1 if scale_ninv else 0, 1, self.sptr)
+        if rc == -7:            # SC_ERR_UNSUPPORTED shape: caller falls back to the unfused steps
+            return False
+        self.sc._check(rc)
+        return True
+
+    def rows_ntt_t_chunked(self, src, dst, length, batch, chunks, root):
+        rc = self.lib.sc_ntt_batch_ex_dev(src.data_ptr(), dst.data_ptr(), length, batch, 1, _fe(root), None, 0, 0, 0, chunks, self.sptr)
+        if rc == -7:
+            return False
+        self.sc._check(rc)
+        return True
+
 
 class ShardedNtt:
     def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False):
@@ -128,9 +144,27 @@ class ShardedNtt:
         self.engine.rows_ntt_t(rows, dst, C, R // self.world, pow(root, R, P))
 
     def _transform(self, src, dst, R, C, root, scale):
-        a = self.stage_cols(src, R, C, root, scale)
-        rows = self.exchange(a, R, C)
-        self.stage_rows(rows, dst, R, C, root)
+        eng, G = self.engine, self.world
+        fused = hasattr(eng, "cols_ntt_twiddled")
+        cw, rw = C // G, R // G
+        # (1)+(2) column transforms with the outer twiddle in their store epilogue
+        a = None
+        if fused:
+            a = self._buf("a", (R, cw, 2))
+            if not eng.cols_ntt_twiddled(src, a, R, cw, pow(root, C, P), root, self.n, self.rank * cw, scale != 1):
+                a = None
+        if a is None:
+            a = self.stage_cols(src, R, C, root, scale)
+        # (3) corner turn
+        if G == 1 and not self.always_exchange:
+            self.stage_rows(a, dst, R, C, root)
+            return
+        recv = self._buf("recv", (G, rw, cw, 2))
+        dist.all_to_all_single(recv.view(-1), a.view(-1), group=self.group)
+        # (4) row transforms straight from the chunked layout the all-to-all left behind
+        if fused and eng.rows_ntt_t_chunked(recv, dst, C, rw, G, pow(root, R, P)):
+            return
+        self.stage_rows(self.assemble_rows(recv, R, C), dst, R, C, root)
 
     def forward(self, x_local, y_local):
         """x_local [n1][n2/G] -> y_local [n2][n1/G]  (column slab of X[k2*n1 + k1])."""

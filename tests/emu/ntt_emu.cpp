@@ -100,7 +100,8 @@ extern "C" void emu_field(const uint64_t* a, const uint64_t* b, uint64_t* out /*
 
 // batched transforms (multi-GPU building blocks): kind 0 = columns of [len][batch], kind 1 = rows of [batch][len] -> [len][batch]
 extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,
-                               int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log) {
+                               int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log,
+                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log) {
     const uint64_t len = 1ull << loglen, batch = 1ull << logbatch;
     Fe r_m = to_mont(Fe{root[0], root[1]});
     NttTuning tu;
@@ -113,8 +114,19 @@ extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int 
     fill_table(th, len > 4096 ? len >> 12 : 1, r_m, 4096, fe_mont_one());
     tb.mt = mt.data(); tb.tl = tl.data(); tb.th = th.data();
     std::vector<Fe> work(len * batch);
+    BatchExtras ex;
+    ex.chunks_log = chunks_log;
+    std::vector<Fe> otl, oth;
+    if (outer_root) {
+        Fe o_m = to_mont(Fe{outer_root[0], outer_root[1]});
+        const uint64_t on = 1ull << outer_logorder;
+        Fe sc_m = outer_ninv ? mont_inv(to_mont(Fe{on, 0})) : fe_mont_one();
+        fill_table(otl, on < 4096 ? on : 4096, o_m, 1, fe_mont_one());
+        fill_table(oth, on > 4096 ? on >> 12 : 1, o_m, 4096, sc_m);
+        ex.outer_tl = otl.data(); ex.outer_th = oth.data(); ex.outer_col_base = outer_col_base;
+    }
     NttPlanDesc d;
-    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu)) return -1;
+    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu, ex)) return -1;
     for (int i = 0; i < d.npasses; ++i) {
         switch (d.pass[i].loge) {
             case 1: run_pass<1>(d.pass[i]); break;

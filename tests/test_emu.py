@@ -8,6 +8,7 @@ import pytest
 
 from conftest import REPO
 from oracle import py_oracle as po
+P = po.P
 import synth
 
 EMU_DIR = os.path.join(REPO, "tests", "emu")
@@ -131,11 +132,39 @@ def _batched_expect(data, kind, loglen, logbatch, root):
 def test_emu_batched(emu, cfg):
     kind, loglen, logbatch, tile, loge, min_tiles, max_col, digit = cfg
     emu.emu_ntt_batched.restype = ctypes.c_int
-    emu.emu_ntt_batched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5
+    emu.emu_ntt_batched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5 + \
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
     total = 1 << (loglen + logbatch)
     data = synth.synth_packed(900 + loglen + 7 * kind, total).tobytes()
     root = po.primitive_nth_root(1 << loglen)
     out = ctypes.create_string_buffer(16 * total)
-    rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit)
+    rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, None, 0, 0, 0, 0)
     assert rc > 0, rc
-    assert out.raw == _batched_expect(data, kind, loglen, logbatch, root), cfg
+    expect = _batched_expect(data, kind, loglen, logbatch, root)
+    assert out.raw == expect, cfg
+    import numpy as np
+    ln, bt = 1 << loglen, 1 << logbatch
+    if kind == 0:
+        # fused outer twiddle: out[r][c] *= w^(r * (col_base + c)) [* order^-1]
+        ologn = loglen + logbatch + 2
+        w = po.primitive_nth_root(1 << ologn)
+        for col_base, ninv in ((0, 0), (bt * 3, 1)):
+            rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit,
+                                     w.to_bytes(16, "little"), ologn, col_base, ninv, 0)
+            assert rc > 0
+            ints = synth.unpack_ints(expect)
+            sc_ = pow(1 << ologn, P - 2, P) if ninv else 1
+            want = [ints[r * bt + c] * pow(w, r * (col_base + c), P) * sc_ % P for r in range(ln) for c in range(bt)]
+            assert synth.unpack_ints(out.raw) == want, (cfg, col_base)
+    else:
+        # chunked input [chunks][batch][len/chunks]
+        for chunks_log in (1, 2):
+            first_digit = loglen if loglen <= digit else (loglen + 1) // 2
+            if chunks_log >= first_digit or chunks_log > loglen - 1:
+                continue
+            ch = 1 << chunks_log
+            a = np.frombuffer(data, dtype=np.uint64).reshape(bt, ch, ln // ch, 2)
+            chunked = np.ascontiguousarray(a.transpose(1, 0, 2, 3)).tobytes()
+            rc = emu.emu_ntt_batched(chunked, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, None, 0, 0, 0, chunks_log)
+            assert rc > 0, (cfg, chunks_log)
+            assert out.raw == expect, (cfg, chunks_log)

@@ -21,7 +21,7 @@ def sc():
     return starkcore
 
 
-def _simulate(sc, log2n, world, seed):
+def _simulate(sc, log2n, world, seed, fused=True):
     from sharded import ShardedNtt
     dev = torch.device("cuda", 0)
     n = 1 << log2n
@@ -33,15 +33,22 @@ def _simulate(sc, log2n, world, seed):
         n1, n2 = engs[0].n1, engs[0].n2
 
         def run(srcs, R, C, rt, scale):
-            a = [e.stage_cols(s, R, C, rt, scale).clone() for e, s in zip(engs, srcs)]
-            outs = []
             rw, cw = R // world, C // world
+            a = []
+            for e, s_ in zip(engs, srcs):
+                buf = torch.empty((R, cw, 2), dtype=torch.int64, device=dev)
+                if fused and e.engine.cols_ntt_twiddled(s_, buf, R, cw, pow(rt, C, po.P), rt, n, e.rank * cw, scale != 1):
+                    a.append(buf)
+                else:
+                    a.append(e.stage_cols(s_, R, C, rt, scale).clone())
+            outs = []
             for h, e in enumerate(engs):
                 # what all_to_all_single delivers to rank h: from every rank g its rows [h*rw, (h+1)*rw)
                 recv = torch.stack([a[g][h * rw:(h + 1) * rw] for g in range(world)], dim=0).contiguous()
-                rows = e.assemble_rows(recv, R, C) if world > 1 else a[0]
                 dst = torch.empty((C, rw, 2), dtype=torch.int64, device=dev)
-                e.stage_rows(rows, dst, R, C, rt)
+                if not (fused and world > 1 and e.engine.rows_ntt_t_chunked(recv, dst, C, rw, world, pow(rt, R, po.P))):
+                    rows = e.assemble_rows(recv, R, C) if world > 1 else a[0]
+                    e.stage_rows(rows, dst, R, C, rt)
                 outs.append(dst)
             return outs
 
@@ -54,9 +61,10 @@ def _simulate(sc, log2n, world, seed):
     return full_in, got, back, root
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("log2n,world", [(8, 1), (10, 2), (13, 4), (16, 8), (18, 8), (21, 2)])
-def test_sharded_simulated_world(sc, log2n, world):
-    full_in, got, back, root = _simulate(sc, log2n, world, seed=11)
+def test_sharded_simulated_world(sc, log2n, world, fused):
+    full_in, got, back, root = _simulate(sc, log2n, world, seed=11, fused=fused)
     n = 1 << log2n
     assert got == po.C.ntt(root, full_in, n)
     assert back == full_in

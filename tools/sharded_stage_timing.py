@@ -39,6 +39,9 @@ for log2n, world in [(22, 2), (23, 4), (24, 8), (24, 1), (21, 1)]:
     rows = eng.assemble_rows(recv, R, C) if world > 1 else a
     res["rows_ntt_us"] = round(timeit(lambda: eng.engine.rows_ntt_t(rows, y, C, rw, pow(eng.root, R, P))), 1)
     res["sum_us"] = round(res["cols_ntt_us"] + res["twiddle_us"] + res["assemble_us"] + res["rows_ntt_us"], 1)
+    res["fused_cols_us"] = round(timeit(lambda: eng.engine.cols_ntt_twiddled(x, a, R, cw, pow(eng.root, C, P), eng.root, n, 0, False)), 1)
+    res["fused_rows_us"] = round(timeit(lambda: eng.engine.rows_ntt_t_chunked(recv, y, C, rw, world, pow(eng.root, R, P))), 1) if world > 1 else res["rows_ntt_us"]
+    res["fused_sum_us"] = round(res["fused_cols_us"] + res["fused_rows_us"], 1)
     lg = log2n - (world.bit_length() - 1)
     xs = sc.DeviceVector(1 << lg); ys = sc.DeviceVector(1 << lg)
     rt = sc.fe_bytes(nth_root(1 << lg))
