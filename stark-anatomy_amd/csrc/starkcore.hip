@@ -192,8 +192,6 @@ struct Ctx {
     std::map<PlanKey, PlanTables> plans;
     std::map<PowKey, PowTables> pows;
     DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
-    void* pinned = nullptr;
-    size_t pinned_bytes = 0;
     int xcd_remap = 1;
 };
 
