@@ -113,6 +113,13 @@ int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /*
 int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out /* k*64*log2 N */);
 /* opened elements AND their paths in one call: elems_out[i] = d_elems[indices[i]] (d_elems = the device vector the tree was built from) */
 int sc_merkle_query_dev(const sc_merkle_t* tree, const void* d_elems, const uint64_t* indices, uint64_t k, void* elems_out, uint8_t* paths_out);
+/* pieces for a tree sharded over ranks: copy of one level of a built tree (level 0 = leaf digests; (N >> level) * 64 bytes),
+ * a tree whose level 0 is given digests, and the fold of fri.py:85 on a rank's column slab [rows][cols] of the codeword
+ * viewed as a rows x R matrix (index i = row*R + col_base + col; the partner i + N/2 is row + rows/2 of the same slab) */
+int sc_merkle_level_copy_dev(const sc_merkle_t* tree, int level, void* d_out, void* stream);
+int sc_merkle_from_digests_dev(const void* d_digests, uint64_t count, uint8_t root_out[64], sc_merkle_t** tree, void* stream);
+int sc_fri_fold_slab_dev(const void* d_in, uint64_t rows, uint64_t cols, uint64_t R, uint64_t col_base, const uint64_t alpha[2], const uint64_t offset[2],
+                         const uint64_t omega[2], void* d_out, void* stream);
 uint64_t sc_merkle_leaves(const sc_merkle_t* tree);
 int sc_merkle_free(sc_merkle_t* tree);
 

@@ -134,6 +134,18 @@ __global__ void __launch_bounds__(256) field_selftest_kernel(int op, const Fe* _
     out[i] = r;
 }
 
+// the same fold on a column slab [rows][2^logcols] of the codeword viewed as a rows x R matrix (index i = row * R + col_base + col):
+// partner i + N/2 is row + rows/2 of the SAME slab, so the fold is local to the rank that owns the columns.
+__global__ void __launch_bounds__(256) fri_fold_slab_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, uint64_t half_rows, int logcols, uint64_t R,
+                                                            uint64_t col_base, const Fe* __restrict__ lo, const Fe* __restrict__ hi, Fe c_m) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (half_rows << logcols)) return;
+    uint64_t row = t >> logcols, col = t & ((1ull << logcols) - 1);
+    Fe a = in[t], b = in[t + (half_rows << logcols)];
+    Fe w = mont_mul(pow2level(lo, hi, row * R + col_base + col), c_m);
+    out[t] = fe_add(fe_half(fe_add(a, b)), mont_mul(fe_sub(a, b), w));
+}
+
 __global__ void __launch_bounds__(256) gather_kernel(const Fe* __restrict__ v, const uint64_t* __restrict__ idx, uint64_t k, Fe* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) out[i] = v[idx[i]];
@@ -473,14 +485,10 @@ int download(void* h, const void* d, size_t bytes, hipStream_t st) {
     return SC_OK;
 }
 
-int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st) {
-    if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
-    uint64_t* levels = nullptr;
-    const size_t tree_bytes = (2 * N - 1) * 64;
-    HIPCHK(pool_alloc((void**)&levels, tree_bytes));
-    hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_elems, levels, N);
+// finish a tree whose level 0 (the `width` digests at `levels`) is already in place
+int merkle_finish(uint64_t* levels, uint64_t width, hipStream_t st) {
     uint64_t* cur = levels;
-    uint64_t w = N;
+    uint64_t w = width;
     while (w > 2048) {
         uint64_t* nxt = cur + 8 * w;
         hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((w / 2 + 255) / 256)), dim3(256), 0, st, cur, nxt, w / 2);
@@ -488,6 +496,17 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
         w >>= 1;
     }
     if (w > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, cur, w);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st) {
+    if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
+    uint64_t* levels = nullptr;
+    const size_t tree_bytes = (2 * N - 1) * 64;
+    HIPCHK(pool_alloc((void**)&levels, tree_bytes));
+    hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_elems, levels, N);
+    (void)merkle_finish(levels, N, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
     e = hipMemcpyAsync(root_out, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
@@ -960,6 +979,56 @@ int sc_merkle_query_dev(const sc_merkle_t* tree, const void* d_elems, const uint
     HIPCHK(hipMemcpyAsync(elems_out, d_el, k * sizeof(Fe), hipMemcpyDeviceToHost, g.stream));
     if (path_bytes) HIPCHK(hipMemcpyAsync(paths_out, d_paths, path_bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    return SC_OK;
+}
+
+// ---- pieces of a Merkle tree that is sharded over ranks (stark-anatomy_amd/sharded.py: ShardedFri)
+int sc_merkle_level_copy_dev(const sc_merkle_t* tree, int level, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || level < 0 || level > tree->logN) return fail(SC_ERR_BAD_ARG, "no such tree level");
+    const uint64_t off = (level == 0) ? 0 : (2 * tree->N - (tree->N >> (level - 1)));
+    HIPCHK(hipMemcpyAsync(d_out, tree->d_levels + 8 * off, (tree->N >> level) * 64, hipMemcpyDeviceToDevice, pick_stream(stream)));
+    return SC_OK;
+}
+
+int sc_merkle_from_digests_dev(const void* d_digests, uint64_t count, uint8_t root_out[64], sc_merkle_t** tree, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (!is_pow2(count)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
+    uint64_t* levels = nullptr;
+    const size_t tree_bytes = (2 * count - 1) * 64;
+    HIPCHK(pool_alloc((void**)&levels, tree_bytes));
+    hipError_t e = hipMemcpyAsync(levels, d_digests, count * 64, hipMemcpyDeviceToDevice, st);
+    int rc = (e == hipSuccess) ? merkle_finish(levels, count, st) : fail(SC_ERR_HIP, hipGetErrorString(e));
+    if (rc == SC_OK) {
+        e = hipMemcpyAsync(root_out, levels + 8 * (2 * count - 2), 64, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(SC_ERR_HIP, hipGetErrorString(e));
+    }
+    if (rc != SC_OK) { pool_free(levels, tree_bytes); return rc; }
+    *tree = new sc_merkle{levels, count, ilog2(count)};
+    return SC_OK;
+}
+
+int sc_fri_fold_slab_dev(const void* d_in, uint64_t rows, uint64_t cols, uint64_t R, uint64_t col_base, const uint64_t alpha[2], const uint64_t offset[2],
+                         const uint64_t omega[2], void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (rows < 2 || !is_pow2(rows) || !is_pow2(cols) || !is_pow2(R) || col_base + cols > R) return fail(SC_ERR_BAD_ARG, "bad slab shape");
+    Fe off = fe_from(offset), om = fe_from(omega);
+    if (fe_is_zero(off) || fe_is_zero(om)) return fail(SC_ERR_DIV_ZERO, "divide by zero");
+    const uint64_t N = rows * R;
+    Fe winv = from_mont(mont_inv(to_mont(om)));
+    PowTables* pw;
+    SCCHK(get_pow(winv, N / 2, st, &pw));
+    Fe c_m = mont_mul(to_mont(fe_from(alpha)), mont_inv(to_mont(fe_add(off, off))));
+    const uint64_t total = (rows / 2) * cols;
+    hipLaunchKernelGGL(fri_fold_slab_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const Fe*)d_in, (Fe*)d_out, rows / 2, ilog2(cols), R, col_base,
+                       pw->lo, pw->hi, c_m);
+    HIPCHK(hipGetLastError());
     return SC_OK;
 }
 

@@ -192,3 +192,209 @@ def gather_natural(local, n_rows, n_cols, world, group=None):
     else:
         parts = [local]
     return torch.cat(parts, dim=1).reshape(n_rows * n_cols, 2)
+
+
+# =====================================================================================================================
+# FRI over the column-slab layout
+# =====================================================================================================================
+class HipFriEngine:
+    """Local FRI primitives on torch-owned slabs through the C-ABI (folds, Merkle trees, openings)."""
+
+    def __init__(self, device):
+        import ctypes
+        import starkcore as sc
+        self.sc, self.lib, self.device, self.ctypes = sc, sc.lib(), device, ctypes
+
+    class _Tree:
+        def __init__(self, tree, keep):
+            self.tree, self.keep, self.root = tree, keep, tree.root
+
+        def open(self, indices):
+            return self.tree.open_batch(list(indices))
+
+    def tree(self, elems):
+        """Merkle tree over a contiguous tensor of field elements [..., 2]."""
+        elems = elems.contiguous()
+        torch.cuda.current_stream(self.device).synchronize()
+        return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr(elems.data_ptr(), elems.numel() // 2), elems)
+
+    def level(self, tree, level):
+        count = tree.tree.n >> level
+        out = torch.empty((count, 8), dtype=torch.int64, device=self.device)
+        tree.tree.copy_level(level, out.data_ptr())
+        self.sc.synchronize()
+        return out
+
+    def tree_from_digests(self, digests):
+        digests = digests.contiguous()
+        torch.cuda.current_stream(self.device).synchronize()
+        return HipFriEngine._Tree(self.sc.MerkleTree.from_digests_ptr(digests.data_ptr(), digests.numel() // 8), digests)
+
+    def fold_slab(self, src, rows, cols, R, col_base, alpha, offset, omega):
+        dst = torch.empty((rows // 2, cols, 2), dtype=torch.int64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        self.sc._check(self.lib.sc_fri_fold_slab_dev(src.data_ptr(), rows, cols, R, col_base, _fe(alpha), _fe(offset), _fe(omega), dst.data_ptr(), None))
+        self.sc.synchronize()
+        return dst
+
+    def fold_full(self, src, N, alpha, offset, omega):
+        dst = torch.empty((N // 2, 2), dtype=torch.int64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        self.sc._check(self.lib.sc_fri_fold_dev(src.data_ptr(), N, _fe(alpha), _fe(offset), _fe(omega), dst.data_ptr(), None))
+        self.sc.synchronize()
+        return dst
+
+    def read(self, elems, flat_indices):
+        """values (Python ints) of elems.view(-1, 2)[flat_indices]"""
+        if len(flat_indices) == 0:
+            return []
+        idx = torch.tensor(list(flat_indices), dtype=torch.int64, device=elems.device)
+        got = elems.reshape(-1, 2)[idx].cpu().tolist()
+        m = (1 << 64) - 1
+        return [((hi & m) << 64) | (lo & m) for lo, hi in got]
+
+
+class ShardedFri:
+    """`Fri.prove` (reference code/fri.py:115-130) on a codeword that lives in the column-slab layout.
+
+    The codeword of length N = C*R is the row-major C x R matrix (index i = row*R + col); rank g owns the columns
+    [g*R/G, (g+1)*R/G) as a contiguous [C][R/G] tensor -- exactly what ShardedNtt.forward() leaves behind.  In this layout
+      * split-and-fold needs NO exchange: i and i + N/2 are rows `row` and `row + C/2` of the same columns;
+      * a Merkle commit needs ONE all-gather of C digests per rank: the bottom log2(R/G) levels are whole subtrees of the
+        rank's slab, the levels above are rebuilt (redundantly, identically) from the gathered sub-roots on every rank;
+      * when a fold leaves a single row (length R) the codeword is all-gathered once and the remaining rounds run locally.
+    Every rank drives the same Fiat-Shamir transcript (roots are replicated), so alphas and query indices agree without
+    any broadcast, and every rank ends up with the identical, reference-identical proof stream.
+    """
+
+    def __init__(self, fri, R, rank, world, device, engine=None, group=None):
+        self.fri, self.R, self.rank, self.world, self.device, self.group = fri, int(R), rank, world, device, group
+        assert R % world == 0 and fri.domain_length % R == 0
+        self.Rw = self.R // world
+        self.engine = engine if engine is not None else HipFriEngine(device)
+
+    # -- collectives ------------------------------------------------------------------------------
+    def _all_gather(self, t):
+        t = t.contiguous()
+        if self.world == 1:
+            return t.unsqueeze(0)
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        return torch.stack(parts, dim=0)
+
+    def _all_gather_object(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    # -- layers -----------------------------------------------------------------------------------
+    def _commit_sharded(self, slab, C):
+        eng, G, Rw = self.engine, self.world, self.Rw
+        local = eng.tree(slab)
+        sub_level = Rw.bit_length() - 1
+        sub = eng.level(local, sub_level)                                   # [C][8]: one sub-root per row
+        top_leaves = self._all_gather(sub).permute(1, 0, 2).contiguous()    # natural order: node (row, rank)
+        top = eng.tree_from_digests(top_leaves.reshape(C * G, 8))
+        return {"kind": "sharded", "slab": slab, "C": C, "local": local, "top": top, "root": top.root, "length": C * self.R, "cache": {}}
+
+    def _natural(self, slab, C):
+        """the whole codeword in natural order on every rank: [C][R/G] slabs -> [C*R]"""
+        return self._all_gather(slab).permute(1, 0, 2, 3).reshape(C * self.R, 2).contiguous()
+
+    def _open_raw(self, layer, indices):
+        """(values, paths) for global indices of one committed codeword; collective for sharded layers."""
+        eng = self.engine
+        if layer["kind"] == "local":
+            return eng.read(layer["vec"], indices), layer["tree"].open(indices) if layer["length"] > 1 else [[] for _ in indices]
+        R, Rw, G, g = self.R, self.Rw, self.world, self.rank
+        sub_level = Rw.bit_length() - 1
+        mine = [(pos, i) for pos, i in enumerate(indices) if (i % R) // Rw == g]
+        local_idx = [(i // R) * Rw + (i % R) % Rw for _, i in mine]
+        vals = eng.read(layer["slab"], local_idx)
+        bottoms = [p[:sub_level] for p in layer["local"].open(local_idx)] if mine else []
+        shared = self._all_gather_object([(pos, v, b) for (pos, _), v, b in zip(mine, vals, bottoms)])
+        values, bottom = [None] * len(indices), [None] * len(indices)
+        for part in shared:
+            for pos, v, b in part:
+                values[pos], bottom[pos] = v, b
+        tops = layer["top"].open([(i // R) * G + (i % R) // Rw for i in indices]) if layer["C"] * G > 1 else [[] for _ in indices]
+        return values, [list(b) + list(t) for b, t in zip(bottom, tops)]
+
+    def _open(self, layer, indices):
+        """entries as FieldElement objects (one object per index, reused) + fresh path objects per request"""
+        from algebra import FieldElement
+        values, paths = self._open_raw(layer, indices)
+        cache, out = layer["cache"], []
+        for i, v in zip(indices, values):
+            if i not in cache:
+                cache[i] = FieldElement(v, self.fri.field)
+            out.append(cache[i])
+        return out, paths
+
+    # -- the protocol -----------------------------------------------------------------------------
+    def prove(self, slab, proof_stream):
+        from algebra import FieldElement
+        fr, eng, field = self.fri, self.engine, self.fri.field
+        N, R, Rw = fr.domain_length, self.R, self.Rw
+        C = N // R
+        assert tuple(slab.shape) == (C, Rw, 2), "slab must be this rank's [C][R/G] columns"
+        omega, offset, rounds = fr.omega, fr.offset, fr.num_rounds()
+        layers, cur, full = [], slab, None
+        for r in range(rounds):
+            Nr = N >> r
+            assert(omega ^ (Nr - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
+            if full is None and C == 1:
+                full = self._natural(cur, 1)                # one row left: collect it everywhere, go local
+            if full is None:
+                layer = self._commit_sharded(cur, C)
+            else:
+                tree = eng.tree(full)
+                layer = {"kind": "local", "vec": full, "tree": tree, "root": tree.root, "length": Nr, "cache": {}}
+            layers.append(layer)
+            proof_stream.push(layer["root"])
+            if r == rounds - 1:
+                break
+            alpha = field.sample(proof_stream.prover_fiat_shamir())
+            if full is None:
+                cur = eng.fold_slab(cur, C, Rw, R, self.rank * Rw, alpha.value, offset.value, omega.value)
+                C //= 2
+            else:
+                full = eng.fold_full(full, Nr, alpha.value, offset.value, omega.value)
+            omega = omega ^ 2
+            offset = offset ^ 2
+        # last codeword in the clear (fri.py:91): natural order, plain list; its objects are reused by the last query round
+        last_layer = layers[-1]
+        last_vec = full if full is not None else self._natural(cur, C)
+        last_values = eng.read(last_vec, range(last_layer["length"]))
+        last_list = [FieldElement(v, field) for v in last_values]
+        last_layer["cache"] = dict(enumerate(last_list))
+        proof_stream.push(last_list)
+
+        s = fr.num_colinearity_tests
+        top_level_indices = fr.sample_indices(proof_stream.prover_fiat_shamir(), N // 2, len(last_list), s)
+        nq = len(layers) - 1
+        per_round, indices = [], [i for i in top_level_indices]
+        for i in range(nq):
+            indices = [index % (layers[i]["length"] // 2) for index in indices]
+            per_round.append(indices)
+        fetched = []
+        for j, layer in enumerate(layers):
+            request = []
+            if j < nq:
+                request += per_round[j][:s] + [index + layer["length"] // 2 for index in per_round[j][:s]]
+            if j > 0:
+                request += per_round[j - 1][:s]
+            fetched.append(self._open(layer, request))
+        for i in range(nq):
+            entries, paths = fetched[i]
+            next_entries, next_paths = fetched[i + 1]
+            c_at = 2 * s if i + 1 < nq else 0
+            for t in range(s):
+                proof_stream.push((entries[t], entries[s + t], next_entries[c_at + t]))
+            for t in range(s):
+                proof_stream.push(paths[t])
+                proof_stream.push(paths[s + t])
+                proof_stream.push(next_paths[c_at + t])
+        return top_level_indices

@@ -55,6 +55,9 @@ SIGNATURES = {
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
     "sc_merkle_open_batch": (_int, [_vp, _vp, _u64, _vp]),
     "sc_merkle_query_dev": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "sc_merkle_level_copy_dev": (_int, [_vp, _int, _vp, _vp]),
+    "sc_merkle_from_digests_dev": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp), _vp]),
+    "sc_fri_fold_slab_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
     "sc_merkle_leaves": (_u64, [_vp]),
     "sc_merkle_free": (_int, [_vp]),
 }
@@ -212,6 +215,26 @@ class MerkleTree:
         h = _vp()
         _check(lib().sc_merkle_build(bytes(data), n, root, ctypes.byref(h)))
         return cls(h, root.raw, n)
+
+    @classmethod
+    def from_device_ptr(cls, ptr, n):
+        """tree over n field elements at a raw device pointer (e.g. a torch tensor's storage)"""
+        root = ctypes.create_string_buffer(64)
+        h = _vp()
+        _check(lib().sc_merkle_build_dev(ptr, n, root, ctypes.byref(h), None))
+        return cls(h, root.raw, n)
+
+    @classmethod
+    def from_digests_ptr(cls, ptr, count):
+        """tree whose level 0 is `count` given 64-byte digests at a raw device pointer"""
+        root = ctypes.create_string_buffer(64)
+        h = _vp()
+        _check(lib().sc_merkle_from_digests_dev(ptr, count, root, ctypes.byref(h), None))
+        return cls(h, root.raw, count)
+
+    def copy_level(self, level, dst_ptr, stream=None):
+        """copy the (n >> level) digests of one level into caller-owned device memory"""
+        _check(lib().sc_merkle_level_copy_dev(self._h, level, dst_ptr, stream))
 
     def open_batch(self, indices):
         k = len(indices)

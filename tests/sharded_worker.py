@@ -71,5 +71,111 @@ def main():
     print("rank", rank, "ok")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "fri"):
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ShardedFri under gloo: local primitives served by the oracle, proof compared with the reference's golden hashes
+# ---------------------------------------------------------------------------------------------------------------------
+class OracleFriEngine:
+    class _Tree:
+        def __init__(self, levels, n):
+            self.levels, self.n, self.depth = levels, n, n.bit_length() - 1
+            self.root = levels[-64:]
+
+        def _node(self, level, idx):
+            off = 0 if level == 0 else 2 * self.n - (self.n >> (level - 1))
+            return self.levels[64 * (off + idx):64 * (off + idx + 1)]
+
+        def open(self, indices):
+            return [[self._node(l, (i >> l) ^ 1) for l in range(self.depth)] for i in indices]
+
+    def tree(self, elems):
+        data = elems.contiguous().numpy().tobytes()
+        n = len(data) // 16
+        return OracleFriEngine._Tree(po.C.merkle_tree(data, n), n)
+
+    def level(self, tree, level):
+        cnt = tree.n >> level
+        raw = b"".join(tree._node(level, i) for i in range(cnt))
+        return torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(cnt, 8).copy())
+
+    def tree_from_digests(self, digests):
+        import hashlib
+        raw = digests.contiguous().numpy().tobytes()
+        n = len(raw) // 64
+        level = [raw[64 * i:64 * (i + 1)] for i in range(n)]
+        allb = [raw]
+        while len(level) > 1:
+            level = [hashlib.blake2b(level[i] + level[i + 1]).digest() for i in range(0, len(level), 2)]
+            allb.append(b"".join(level))
+        return OracleFriEngine._Tree(b"".join(allb), n)
+
+    def read(self, elems, flat_indices):
+        a = elems.contiguous().numpy().view(np.uint64).reshape(-1, 2)
+        return [int(a[i, 0]) | (int(a[i, 1]) << 64) for i in flat_indices]
+
+    def fold_slab(self, src, rows, cols, R, col_base, alpha, offset, omega):
+        a = src.contiguous().numpy().view(np.uint64).reshape(rows, cols, 2)
+        out = np.empty((rows // 2, cols, 2), dtype=np.uint64)
+        inv2 = po.inv(2)
+        for row in range(rows // 2):
+            for col in range(cols):
+                i = row * R + col_base + col
+                t = alpha * po.inv(offset * pow(omega, i, P) % P) % P
+                x = int(a[row, col, 0]) | (int(a[row, col, 1]) << 64)
+                y = int(a[row + rows // 2, col, 0]) | (int(a[row + rows // 2, col, 1]) << 64)
+                v = inv2 * ((1 + t) * x + (1 - t) * y) % P
+                out[row, col, 0], out[row, col, 1] = v & ((1 << 64) - 1), v >> 64
+        return torch.from_numpy(out.view(np.int64))
+
+    def fold_full(self, src, N, alpha, offset, omega):
+        raw = po.C.fold(src.contiguous().numpy().tobytes(), N, alpha, offset, omega)
+        return torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(N // 2, 2).copy())
+
+
+def fri_main():
+    import hashlib
+    import json
+    from sharded import ShardedFri
+    from algebra import Field
+    from fri import Fri
+    from ip import ProofStream
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    golden = json.load(open(os.path.join(REPO, "tests", "golden", "fri.json")))
+    field = Field.main()
+    ok = True
+    for rec in golden["prove_synth"]:
+        logN = rec["logN"]
+        if logN > 10:
+            continue
+        N = 1 << logN
+        om = field.primitive_nth_root(N)
+        coeffs = synth.synth_packed(rec["coeff_seed"], N // 4).tobytes()
+        cw = np.frombuffer(po.C.coset_evaluate(coeffs, N // 4, po.GENERATOR, om.value, N), dtype=np.int64).reshape(N, 2)
+        for logR in ({6: (2, 3), 10: (3, 5, 8)}[logN]):
+            R = 1 << logR
+            if R < world:
+                continue
+            C, Rw = N // R, R // world
+            slab = torch.from_numpy(cw.reshape(C, R, 2)[:, rank * Rw:(rank + 1) * Rw, :].copy())
+            fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+            ps = ProofStream()
+            top = ShardedFri(fr, R, rank, world, torch.device("cpu"), engine=OracleFriEngine()).prove(slab, ps)
+            ser = ps.serialize()
+            good = (top == rec["top_level_indices"] and [o.hex() for o in ps.objects[:rec["num_rounds"]]] == rec["roots"]
+                    and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
+            if not good:
+                print("rank", rank, "MISMATCH logN", logN, "R", R, top == rec["top_level_indices"], len(ser), rec["serialized_len"], flush=True)
+            ok &= good
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+    print("rank", rank, "ok")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "fri":
+    fri_main()

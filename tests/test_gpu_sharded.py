@@ -133,3 +133,34 @@ def test_bench_sharded_path_under_torchrun_one_rank():
     out = json.loads(line)
     assert out["config"]["roundtrip_bit_exact"] is True and out["n_gpus"] == 1 and out["value"] > 0
     assert "fourstep" in out["config"]["workload"]
+
+
+def test_sharded_fri_hip_engine_matches_reference_proofs(sc):
+    """ShardedFri with the HIP engine (slab fold kernel, tree levels, tree from digests, openings) on one rank: the proof
+    must be byte-identical to the reference's golden Fri.prove for every slab shape (the multi-rank orchestration is
+    covered under gloo in tests/test_sharded_cpu.py)."""
+    import hashlib
+    from conftest import load_golden
+    from sharded import ShardedFri
+    from algebra import Field
+    from fri import Fri
+    from ip import ProofStream
+    dev = torch.device("cuda", 0)
+    field = Field.main()
+    g = load_golden("fri.json")
+    for rec in g["prove_synth"]:
+        N = 1 << rec["logN"]
+        om = field.primitive_nth_root(N)
+        coeffs = sc.DeviceVector.from_bytes(synth.synth_packed(rec["coeff_seed"], N // 4).tobytes())
+        cwv = sc.DeviceVector(N)
+        sc._check(sc.lib().sc_coset_evaluate_dev(coeffs.ptr, N // 4, sc.fe_bytes(po.GENERATOR), sc.fe_bytes(om.value), N, cwv.ptr, None))
+        sc.synchronize()
+        cw = torch.from_numpy(np.frombuffer(cwv.to_bytes(), dtype=np.int64).reshape(N, 2).copy()).to(dev)
+        for logR in sorted({1, 3, rec["logN"] // 2, rec["logN"] - 1, rec["logN"]}):
+            R = 1 << logR
+            fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+            ps = ProofStream()
+            top = ShardedFri(fr, R, 0, 1, dev).prove(cw.reshape(N // R, R, 2), ps)
+            ser = ps.serialize()
+            assert top == rec["top_level_indices"], (rec["logN"], R)
+            assert hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"], (rec["logN"], R)
