@@ -243,7 +243,63 @@ def extras(sc, lib):
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     res["fri_prove_2p22_ef4_s40"] = {"ms": best * 1e3, "rounds": fr.num_rounds(), "proof_objects": len(ps.objects)}
+    del cw, cwv, coeffs
+    # configs[4] on ONE GPU: the polynomial-core call census of FastStark.prove replayed at
+    # fri_domain_length 2^24, omicron_domain_length 2^22, 2 registers: 4 LDEs to 2^24, 2 coset divisions at 2^22,
+    # 3 Merkle commits of 2^24 leaves, Fri.prove on the combined codeword (17 rounds), 4 x 160 openings.
+    try:
+        res["stark_census_2p24_1gpu"] = stark_census(sc, lib, field, 24)
+    except Exception as e:
+        res["stark_census_2p24_1gpu"] = {"error": repr(e)}
     return res
+
+
+def stark_census(sc, lib, field, log_fri):
+    import ctypes
+    import synth
+    from fri import Fri
+    from ip import ProofStream
+    GEN = 85408008396924667383611388730472331217
+    Nf, No = 1 << log_fri, 1 << (log_fri - 2)
+    omega, omicron = field.primitive_nth_root(Nf), field.primitive_nth_root(No)
+    polys = [sc.DeviceVector.from_bytes(synth.synth_packed(60 + i, No // 2).tobytes()) for i in range(4)]
+    sc.synchronize()
+    t0 = time.perf_counter()
+    ps = ProofStream()
+    codewords = []
+    for i, pv in enumerate(polys):                       # 2 boundary quotients, randomizer, combination
+        cw = sc.DeviceVector(Nf)
+        sc._check(lib.sc_coset_evaluate_dev(pv.ptr, No // 2, sc.fe_bytes(GEN), sc.fe_bytes(omega.value), Nf, cw.ptr, None))
+        codewords.append(sc.DeviceCodeword(cw, field))
+        if i < 3:
+            ps.push(codewords[i].tree().root)
+    t_lde_commit = time.perf_counter() - t0
+    # 2 transition quotients: coset NTTs of numerator and zerofier, pointwise division, inverse NTT (device-resident core)
+    t1 = time.perf_counter()
+    a, b, q = sc.DeviceVector(No), sc.DeviceVector(No), sc.DeviceVector(No)
+    for i in range(2):
+        sc._check(lib.sc_coset_evaluate_dev(polys[i].ptr, No // 2, sc.fe_bytes(GEN), sc.fe_bytes(omicron.value), No, a.ptr, None))
+        sc._check(lib.sc_coset_evaluate_dev(polys[3].ptr, No // 4, sc.fe_bytes(GEN), sc.fe_bytes(omicron.value), No, b.ptr, None))
+        sc._check(lib.sc_pointwise_div_dev(a.ptr, b.ptr, q.ptr, No, None))
+        sc._check(lib.sc_ntt_dev(q.ptr, a.ptr, No, sc.fe_bytes(omicron.value), 1, None))
+    sc.synchronize()
+    t_div = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    fr = Fri(field.generator(), omega, Nf, 4, 40)
+    indices = fr.prove(codewords[3], ps)
+    t_fri = time.perf_counter() - t2
+    t3 = time.perf_counter()
+    dup = [i for i in indices] + [(i + 4) % Nf for i in indices]
+    quad = sorted(dup + [(i + Nf // 2) % Nf for i in dup])
+    for cw in codewords[:3]:
+        entries, paths = cw.query(quad)
+        for e, pth in zip(entries, paths):
+            ps.push(e)
+            ps.push(pth)
+    t_open = time.perf_counter() - t3
+    total = time.perf_counter() - t0
+    return {"ms": total * 1e3, "lde_and_commit_ms": t_lde_commit * 1e3, "coset_divide_ms": t_div * 1e3, "fri_prove_ms": t_fri * 1e3,
+            "openings_ms": t_open * 1e3, "fri_rounds": fr.num_rounds(), "proof_objects": len(ps.objects)}
 
 
 def measured_traffic(log2n):
