@@ -122,15 +122,44 @@ __device__ __forceinline__ uint32_t leaf_message(Fe x, uint64_t m[16]) {
     return nd;
 }
 
-__global__ void __launch_bounds__(256) merkle_leaf_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ digests, uint64_t N) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    uint64_t m[16], h[8];
-    uint32_t len = leaf_message(elems[i], m);
-    blake2b_single_block(m, len, h);
-    ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 8 * i);
+// LDS staging so that every global access of the tree kernels is a fully coalesced 16-byte-per-lane stream:
+// a thread's 128-byte message / 64-byte digest is strided across lanes in memory (8 resp. 4 separate partial-line
+// accesses per lane otherwise).  Slots are rotated by the owning thread id to keep the per-thread LDS accesses
+// at most 2-way bank-conflicted.
+__device__ __forceinline__ uint32_t msg_slot(uint32_t t, uint32_t k) { return (t << 3) | ((k + t) & 7u); }   // 16-byte slots
+__device__ __forceinline__ uint32_t dig_slot(uint32_t t, uint32_t k) { return (t << 2) | ((k + t) & 3u); }
+
+// write this workgroup's digests (h of thread t) to out[base .. base + n_here) with coalesced stores
+__device__ __forceinline__ void store_digests_coalesced(uint4* sm, const uint64_t h[8], bool active, uint64_t* __restrict__ out, uint64_t base, uint32_t n_here) {
+    const uint32_t t = threadIdx.x;
+    if (active) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = make_ulonglong2(h[2 * k], h[2 * k + 1]);
+        for (uint32_t k = 0; k < 4; ++k) {
+            uint4 v;
+            v.x = (uint32_t)h[2 * k]; v.y = (uint32_t)(h[2 * k] >> 32); v.z = (uint32_t)h[2 * k + 1]; v.w = (uint32_t)(h[2 * k + 1] >> 32);
+            sm[dig_slot(t, k)] = v;
+        }
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(out + 8 * base);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t q = j * 256u + t;           // 16-byte chunk index inside the workgroup's 16 KiB of digests
+        if (q < n_here * 4u) dst[q] = sm[dig_slot(q >> 2, q & 3u)];
+    }
+}
+
+__global__ void __launch_bounds__(256) merkle_leaf_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ digests, uint64_t N) {
+    __shared__ uint4 sm[256 * 4];
+    const uint64_t base = (uint64_t)blockIdx.x * 256u;
+    const uint32_t n_here = (uint32_t)((N - base) < 256u ? (N - base) : 256u);
+    const bool active = threadIdx.x < n_here;
+    uint64_t m[16], h[8];
+    if (active) {
+        uint32_t len = leaf_message(elems[base + threadIdx.x], m);
+        blake2b_single_block(m, len, h);
+    }
+    store_digests_coalesced(sm, h, active, digests, base, n_here);
 }
 
 __device__ __forceinline__ void merkle_node(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t i) {
@@ -144,10 +173,32 @@ __device__ __forceinline__ void merkle_node(const uint64_t* __restrict__ in, uin
     for (int k = 0; k < 4; ++k) o[k] = make_ulonglong2(h[2 * k], h[2 * k + 1]);
 }
 
-// one level: count parents from 2*count children
+// one level: count parents from 2*count children; a workgroup handles 256 consecutive parents
 __global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) merkle_node(in, out, i);
+    __shared__ uint4 sm[256 * 8];                     // 32 KiB: the workgroup's 256 messages of 128 bytes
+    const uint32_t t = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * 256u;
+    const uint32_t n_here = (uint32_t)((count - base) < 256u ? (count - base) : 256u);
+    const uint4* src = reinterpret_cast<const uint4*>(in + 16 * base);
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t q = j * 256u + t;              // coalesced: lane l reads chunk q of the 32 KiB block
+        if (q < n_here * 8u) sm[msg_slot(q >> 3, q & 7u)] = src[q];
+    }
+    __syncthreads();
+    const bool active = t < n_here;
+    uint64_t m[16], h[8];
+    if (active) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            uint4 v = sm[msg_slot(t, k)];
+            m[2 * k] = ((uint64_t)v.y << 32) | v.x;
+            m[2 * k + 1] = ((uint64_t)v.w << 32) | v.z;
+        }
+        blake2b_single_block(m, 128u, h);
+    }
+    __syncthreads();                                   // all messages consumed before the buffer is reused for digests
+    store_digests_coalesced(sm, h, active, out, base, n_here);
 }
 
 // finishes the tree from a level of `width` <= 2048 digests down to the root inside ONE workgroup

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Merkle tree build time vs leaf count on one GPU (best of 5) -- dev tool."""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd"))
+import starkcore as sc, synth
+sc.init(0)
+for logn in (12, 16, 20, 22, 24):
+    n = 1 << logn
+    v = sc.DeviceVector.from_bytes(synth.synth_packed(9, n).tobytes())
+    best = None
+    for _ in range(6):
+        t0 = time.perf_counter()
+        t = sc.MerkleTree.from_device(v)
+        dt = time.perf_counter() - t0
+        t.free()
+        best = dt if best is None or dt < best else best
+    print(json.dumps(dict(logn=logn, ms=round(best * 1e3, 3), gcompress_s=round((2 * n - 1) / best / 1e9, 2))), flush=True)
