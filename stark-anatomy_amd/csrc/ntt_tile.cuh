@@ -94,11 +94,13 @@ SC_HD Fe pow_table_entry(Fe base_m, uint64_t i, uint64_t step, Fe scale_m) {
 }
 
 // One round of one workgroup's tile, for thread `tid`: S radix-2 DIF stages on row bits [sh, sh+S).
-template <int LOGE, int S>
+// GLR / GLC >= 0 fix the tile geometry at compile time (the hot shapes get their own kernel instantiation: all the
+// index math below then folds into immediates); -1 = read it from P.
+template <int LOGE, int S, int GLR = -1, int GLC = -1>
 SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds) {
     constexpr int E = 1 << LOGE;
     constexpr int F = 1 << S;          // elements per butterfly group
-    const int logR = P.logR, logC = P.logC;
+    const int logR = (GLR >= 0) ? GLR : P.logR, logC = (GLC >= 0) ? GLC : P.logC;
     const uint32_t T = 1u << (logR + logC - LOGE);   // threads per workgroup
     const bool last = (sh == 0);
 
@@ -199,13 +201,32 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
 }
 
 // dispatch on the (runtime) number of stages in this round
-template <int LOGE>
+template <int LOGE, int GLR = -1, int GLC = -1>
 SC_HD void ntt_round_dispatch(const PassParams& P, int s, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds) {
-    if constexpr (LOGE >= 4) { if (s == 4) { ntt_round<LOGE, 4>(P, sh, first, tile, tid, lds); return; } }
-    if constexpr (LOGE >= 3) { if (s == 3) { ntt_round<LOGE, 3>(P, sh, first, tile, tid, lds); return; } }
-    if constexpr (LOGE >= 2) { if (s == 2) { ntt_round<LOGE, 2>(P, sh, first, tile, tid, lds); return; } }
-    ntt_round<LOGE, 1>(P, sh, first, tile, tid, lds);
+    if constexpr (LOGE >= 4) { if (s == 4) { ntt_round<LOGE, 4, GLR, GLC>(P, sh, first, tile, tid, lds); return; } }
+    if constexpr (LOGE >= 3) { if (s == 3) { ntt_round<LOGE, 3, GLR, GLC>(P, sh, first, tile, tid, lds); return; } }
+    if constexpr (LOGE >= 2) { if (s == 2) { ntt_round<LOGE, 2, GLR, GLC>(P, sh, first, tile, tid, lds); return; } }
+    ntt_round<LOGE, 1, GLR, GLC>(P, sh, first, tile, tid, lds);
 }
+
+// Fully unrolled round schedule for a compile-time geometry (short round first, like make_rounds()): every `sh` is a
+// constant, so row/LDS indices become base + immediate.  SYNC() is the workgroup barrier (no-op in the CPU emulation,
+// which runs one round for all threads at a time instead).
+template <int LOGE, int GLR, int GLC, int ROUND = 0>
+struct FixedRounds {
+    static constexpr int NR = (GLR + LOGE - 1) / LOGE;
+    static constexpr int S = (ROUND == 0) ? (GLR - LOGE * (NR - 1)) : LOGE;
+    static constexpr int DONE = (ROUND == 0) ? 0 : (GLR - LOGE * (NR - 1)) + LOGE * (ROUND - 1);
+    static constexpr int SH = GLR - DONE - S;
+    template <class Sync>
+    SC_HD static void run(const PassParams& P, uint32_t tile, uint32_t tid, Fe* lds, Sync sync) {
+        ntt_round<LOGE, S, GLR, GLC>(P, SH, ROUND == 0, tile, tid, lds);
+        if constexpr (ROUND + 1 < NR) {
+            sync();
+            FixedRounds<LOGE, GLR, GLC, ROUND + 1>::run(P, tile, tid, lds, sync);
+        }
+    }
+};
 
 // Round schedule shared by the kernel and the CPU emulation: the short round (if any) goes first.
 struct RoundSched {

@@ -40,6 +40,16 @@ __global__ void __launch_bounds__(PassThreads<LOGE>::value) ntt_pass_kernel(cons
     }
 }
 
+// the same kernel with the tile geometry fixed at compile time (hot shapes of the default plans)
+template <int LOGE, int GLR, int GLC>
+__global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed(const PassParams P, uint32_t ntiles, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Fe* lds = reinterpret_cast<Fe*>(smem_raw);
+    uint32_t tile = blockIdx.x;
+    if (xcd_remap) tile = (blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3);
+    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, [] { __syncthreads(); });
+}
+
 __global__ void __launch_bounds__(256) pow_table_kernel(Fe* out, uint64_t count, Fe base_m, uint64_t step, Fe scale_m) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = pow_table_entry(base_m, i, step, scale_m);
@@ -205,6 +215,7 @@ struct Ctx {
     std::map<PowKey, PowTables> pows;
     DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
     int xcd_remap = 1;
+    int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
 };
 
 Ctx g;
@@ -384,6 +395,19 @@ int get_pow(Fe base, uint64_t count, hipStream_t st, PowTables** out) {
 template <int LOGE>
 void launch_pass(const NttPassDesc& pd, hipStream_t st) {
     int remap = (g.xcd_remap && pd.ntiles >= 16 && (pd.ntiles & 7u) == 0) ? 1 : 0;
+    if constexpr (LOGE == 2) {
+        // hot shapes of the default plans get geometry-specialised instantiations
+        if (g.fixed_shapes) {
+            const int lr = pd.p.logR, lc = pd.p.logC;
+#define SC_FIXED(LR, LC)                                                                                                             \
+            if (lr == LR && lc == LC) {                                                                                              \
+                hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap); \
+                return;                                                                                                              \
+            }
+            SC_FIXED(8, 3) SC_FIXED(7, 4) SC_FIXED(10, 2) SC_FIXED(6, 5)
+#undef SC_FIXED
+        }
+    }
     hipLaunchKernelGGL(ntt_pass_kernel<LOGE>, dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap);
 }
 
@@ -605,6 +629,7 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "max_digit_log") g.tuning.max_digit_log = value;
     else if (k == "direct_tw_max_log") g.tuning.direct_tw_max_log = value;
     else if (k == "xcd_remap") g.xcd_remap = value;
+    else if (k == "fixed_shapes") g.fixed_shapes = value;
     else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
     return SC_OK;
 }

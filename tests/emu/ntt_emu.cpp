@@ -15,10 +15,28 @@ static void fill_table(std::vector<Fe>& t, uint64_t count, Fe base_m, uint64_t s
     for (uint64_t i = 0; i < count; ++i) t[i] = pow_table_entry(base_m, i, step, scale_m);
 }
 
+// geometry-specialised path (FixedRounds): on the CPU each round must finish for all threads before the next starts,
+// so the per-round bodies are invoked directly with the same compile-time schedule the kernel unrolls
+template <int LOGE, int GLR, int GLC, int ROUND = 0>
+static void run_fixed_rounds(const NttPassDesc& pd, uint32_t tile, Fe* lds) {
+    using FR = FixedRounds<LOGE, GLR, GLC, ROUND>;
+    for (uint32_t tid = 0; tid < pd.threads; ++tid) ntt_round<LOGE, FR::S, GLR, GLC>(pd.p, FR::SH, ROUND == 0, tile, tid, lds);
+    if constexpr (ROUND + 1 < FR::NR) run_fixed_rounds<LOGE, GLR, GLC, ROUND + 1>(pd, tile, lds);
+}
+
 template <int LOGE>
 static void run_pass(const NttPassDesc& pd) {
     const PassParams& P = pd.p;
     std::vector<Fe> lds((size_t)1 << (P.logR + P.logC));
+    if constexpr (LOGE == 2) {
+#define EMU_FIXED(LR, LC)                                                                                   \
+        if (P.logR == LR && P.logC == LC) {                                                                 \
+            for (uint32_t tile = 0; tile < pd.ntiles; ++tile) run_fixed_rounds<2, LR, LC>(pd, tile, lds.data()); \
+            return;                                                                                         \
+        }
+        EMU_FIXED(8, 3) EMU_FIXED(7, 4) EMU_FIXED(10, 2) EMU_FIXED(6, 5)
+#undef EMU_FIXED
+    }
     RoundSched rs = make_rounds(P.logR, LOGE);
     for (uint32_t tile = 0; tile < pd.ntiles; ++tile)
         for (int r = 0; r < rs.nrounds; ++r)

@@ -21,7 +21,7 @@ def sc():
     assert starkcore.device_count() > 0, "no GPU visible: the HIP path is mandatory for these tests"
     starkcore.init()
     yield starkcore
-    for k, v in (("max_tile_log", -1), ("loge", 2), ("max_col_log", -1), ("min_tiles_log", 8), ("single_pass_max_log", 11), ("max_digit_log", -1), ("xcd_remap", 1), ("direct_tw_max_log", 22)):
+    for k, v in (("max_tile_log", -1), ("loge", 2), ("max_col_log", -1), ("min_tiles_log", 8), ("single_pass_max_log", 11), ("max_digit_log", -1), ("xcd_remap", 1), ("direct_tw_max_log", 22), ("fixed_shapes", 1)):
         starkcore.set_tuning(k, v)
 
 
@@ -74,12 +74,12 @@ def test_ntt_big_golden(sc):
 
 TUNINGS = [dict(max_tile_log=12, loge=3, max_digit_log=8), dict(max_tile_log=11, loge=3, max_digit_log=8, max_col_log=6), dict(max_tile_log=10, loge=2), dict(max_tile_log=12, loge=3, max_col_log=4),
            dict(max_tile_log=12, loge=3, min_tiles_log=0), dict(max_tile_log=9, loge=2, max_digit_log=5), dict(max_tile_log=12, loge=3, xcd_remap=0),
-           dict(max_tile_log=12, loge=3, single_pass_max_log=12), dict(direct_tw_max_log=0), dict(direct_tw_max_log=16, max_tile_log=11)]
+           dict(max_tile_log=12, loge=3, single_pass_max_log=12), dict(direct_tw_max_log=0), dict(direct_tw_max_log=16, max_tile_log=11), dict(fixed_shapes=0)]
 
 
 @pytest.mark.parametrize("tune", TUNINGS)
 def test_ntt_tunings_agree_with_oracle(sc, tune):
-    defaults = dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22)
+    defaults = dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1)
     defaults.update(tune)
     for k, v in defaults.items():
         sc.set_tuning(k, v)
@@ -91,7 +91,7 @@ def test_ntt_tunings_agree_with_oracle(sc, tune):
             assert gpu_ntt(sc, data, n, root) == C.ntt(root, data, n), (tune, logn)
             assert gpu_ntt(sc, data, n, root, 1) == C.intt(root, data, n), (tune, logn)
     finally:
-        for k, v in dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22).items():
+        for k, v in dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1).items():
             sc.set_tuning(k, v)
 
 

@@ -13,13 +13,12 @@ def nth_root(n):
 sc.init(0); lib = sc.lib(); dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream); sptr = ctypes.c_void_p(stream.cuda_stream)
 tag = os.environ.get("STARKCORE_LIB", "default")
-cfgs = [dict(), dict(loge=1), dict(loge=1, max_tile_log=11), dict(loge=2, max_tile_log=11), dict(loge=2, max_tile_log=12, max_col_log=5), dict(loge=1, max_tile_log=12, max_col_log=4),
-        dict(loge=2, max_digit_log=8, max_tile_log=11, max_col_log=6), dict(loge=2, max_digit_log=8, max_tile_log=10, max_col_log=6), dict(loge=2, direct_tw_max_log=24), dict(loge=2, direct_tw_max_log=0), dict(xcd_remap=0)]
+cfgs = [dict(), dict(fixed_shapes=0), dict(fixed_shapes=1), dict(fixed_shapes=0), dict(fixed_shapes=1)]
 for log2n in (20, 22, 24):
     n = 1 << log2n; root = sc.fe_bytes(nth_root(n))
     x = torch.from_numpy(synth.synth_packed(1, n).view(np.int64)).to(dev); y = torch.empty_like(x)
     for cfg in cfgs:
-        for k, v in dict(max_digit_log=-1, max_col_log=-1, max_tile_log=-1, loge=2, min_tiles_log=8, direct_tw_max_log=22, xcd_remap=1).items(): sc.set_tuning(k, v)
+        for k, v in dict(max_digit_log=-1, max_col_log=-1, max_tile_log=-1, loge=2, min_tiles_log=8, direct_tw_max_log=22, xcd_remap=1, fixed_shapes=1).items(): sc.set_tuning(k, v)
         for k, v in cfg.items(): sc.set_tuning(k, v)
         f = lambda: sc._check(lib.sc_ntt_dev(x.data_ptr(), y.data_ptr(), n, root, 0, sptr))
         for _ in range(3): f()
