@@ -404,7 +404,7 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
                 hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap); \
                 return;                                                                                                              \
             }
-            SC_FIXED(8, 3) SC_FIXED(7, 4) SC_FIXED(10, 2) SC_FIXED(6, 5)
+            SC_FIXED(8, 3) SC_FIXED(7, 4) SC_FIXED(10, 2) SC_FIXED(6, 5) SC_FIXED(9, 3) SC_FIXED(8, 4)
 #undef SC_FIXED
         }
     }

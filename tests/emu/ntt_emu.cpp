@@ -34,7 +34,7 @@ static void run_pass(const NttPassDesc& pd) {
             for (uint32_t tile = 0; tile < pd.ntiles; ++tile) run_fixed_rounds<2, LR, LC>(pd, tile, lds.data()); \
             return;                                                                                         \
         }
-        EMU_FIXED(8, 3) EMU_FIXED(7, 4) EMU_FIXED(10, 2) EMU_FIXED(6, 5)
+        EMU_FIXED(8, 3) EMU_FIXED(7, 4) EMU_FIXED(10, 2) EMU_FIXED(6, 5) EMU_FIXED(9, 3) EMU_FIXED(8, 4)
 #undef EMU_FIXED
     }
     RoundSched rs = make_rounds(P.logR, LOGE);

@@ -68,7 +68,8 @@ MULTI = [(6, 4, 1, 2, 0, 2, 8), (8, 6, 2, 3, 0, 3, 8), (10, 7, 2, 4, 0, 3, 8), (
          (16, 12, 3, 11, 10, 6, 8), (17, 12, 3, 11, 10, 6, 8), (12, 6, 2, 3, 0, 2, 4), (15, 7, 2, 3, 0, 3, 4), (9, 4, 1, 2, 0, 1, 3), (18, 10, 3, 11, 10, 6, 8),
          (12, 5, 1, 2, 0, 2, 3), (11, 6, 2, 3, 0, 2, 3), (16, 7, 2, 3, 0, 3, 4),
          # shapes with geometry-specialised kernel instantiations (logR, logC) = (8,3), (7,4), (6,5), (10,2)
-         (16, 11, 2, 11, 0, 6, 8), (14, 11, 2, 11, 0, 6, 8), (12, 11, 2, 11, 0, 6, 8), (20, 12, 2, 11, 8, 4, 10)]
+         (16, 11, 2, 11, 0, 6, 8), (14, 11, 2, 11, 0, 6, 8), (12, 11, 2, 11, 0, 6, 8), (20, 12, 2, 11, 8, 4, 10),
+         (18, 12, 2, 11, 8, 4, 10), (16, 12, 2, 11, 8, 4, 10)]
 
 
 @pytest.mark.parametrize("cfg", MULTI)
