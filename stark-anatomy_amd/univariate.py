@@ -70,11 +70,23 @@ class Polynomial:
     def __sub__(self, other):
         return self.__add__(-other)
 
+    # operands at least this long go through the GPU transform instead of the schoolbook loop (same coefficients,
+    # same list length; the threshold stays above fast_multiply's own "degree < 8 -> lhs * rhs" fallback)
+    FAST_MUL_MIN_LEN = 32
+
     def __mul__(self, other):
         if self.coefficients == [] or other.coefficients == []:
             return Polynomial([])
         field = self.coefficients[0].field
         p = field.p
+        if min(len(self.coefficients), len(other.coefficients)) >= Polynomial.FAST_MUL_MIN_LEN and p == Field.P_MAIN:
+            # Polynomial.__mul__ dominates MPolynomial.evaluate_symbolic (fast_stark.py:109-110) at scale; the product is
+            # the same polynomial, so only the time changes
+            from ntt import fast_multiply
+            full_len = len(self.coefficients) + len(other.coefficients) - 1
+            order = 1 << max(1, (full_len - 1).bit_length())
+            product = fast_multiply(self, other, field.primitive_nth_root(order), order).coefficients
+            return Polynomial(product + [field.zero()] * (full_len - len(product)))
         b = [c.value for c in other.coefficients]
         out = [0] * (len(self.coefficients) + len(b) - 1)
         for i, c in enumerate(self.coefficients):
