@@ -28,9 +28,17 @@ def _unpack(raw, count, field):
     return [FieldElement(frm(raw[16 * i:16 * i + 16], "little"), field) for i in range(count)]
 
 
+_verified_roots = set()       # (p, root, order) triples that already passed the two assertions below
+
+
 def _check_root(primitive_root, root_order):
+    key = (primitive_root.field.p, primitive_root.value, root_order)
+    if key in _verified_roots:
+        return
     assert(primitive_root ^ root_order == primitive_root.field.one()), _ROOT_ORDER_MSG
     assert(primitive_root ^ (root_order // 2) != primitive_root.field.one()), _ROOT_PRIM_MSG
+    if len(_verified_roots) < 4096:
+        _verified_roots.add(key)
 
 
 def _transform(primitive_root, values, inverse):
