@@ -98,15 +98,28 @@ def fast_multiply(lhs, rhs, primitive_root, root_order):
     return Polynomial(_unpack(out.raw, degree + 1, field))
 
 
+# The reference recomputes the zerofier of every sub-domain at every node of fast_evaluate / fast_interpolate
+# (ntt.py:92-93, :115-116); the polynomials are the same each time, so they are remembered per call tree.
+_zerofier_memo = {}
+
+
 def fast_zerofier(domain, primitive_root, root_order):
     _check_root(primitive_root, root_order)
     if len(domain) == 0:
         return Polynomial([])
     if len(domain) == 1:
         return Polynomial([-domain[0], primitive_root.field.one()])
+    key = (primitive_root.value, root_order, tuple(d.value for d in domain))
+    hit = _zerofier_memo.get(key)
+    if hit is not None:
+        return hit
     half = len(domain) // 2
-    return fast_multiply(fast_zerofier(domain[:half], primitive_root, root_order),
-                         fast_zerofier(domain[half:], primitive_root, root_order), primitive_root, root_order)
+    result = fast_multiply(fast_zerofier(domain[:half], primitive_root, root_order),
+                           fast_zerofier(domain[half:], primitive_root, root_order), primitive_root, root_order)
+    if len(_zerofier_memo) >= 8192:
+        _zerofier_memo.clear()
+    _zerofier_memo[key] = result
+    return result
 
 
 def fast_evaluate(polynomial, domain, primitive_root, root_order):
