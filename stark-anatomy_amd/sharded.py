@@ -45,6 +45,10 @@ class HipEngine:
     def twiddle(self, buf, rows, cols, row_base, col_base, root, order, scale):
         self.sc._check(self.lib.sc_twiddle_matrix_dev(buf.data_ptr(), rows, cols, row_base, col_base, _fe(root), order, _fe(scale), self.sptr))
 
+    def scale_powers(self, src, dst, count, factor):
+        """dst[j] = src[j] * factor^j (Polynomial.scale, code/univariate.py:153-154)"""
+        self.sc._check(self.lib.sc_scale_dev(src.data_ptr(), dst.data_ptr(), count, _fe(factor), self.sptr))
+
     # fused variants (one kernel sequence each; no separate twiddle pass, no reassembly copy)
     def cols_ntt_twiddled(self, src, dst, length, batch, root, outer_root, order, col_base, scale_ninv):
         rc = self.lib.sc_ntt_batch_ex_dev(src.data_ptr(), dst.data_ptr(), length, batch, 0, _fe(root), _fe(outer_root), order, col_base,
@@ -165,6 +169,28 @@ class ShardedNtt:
         if fused and eng.rows_ntt_t_chunked(recv, dst, C, rw, G, pow(root, R, P)):
             return
         self.stage_rows(self.assemble_rows(recv, R, C), dst, R, C, root)
+
+    def coset_evaluate(self, coeffs, offset, y_local):
+        """Sharded fast_coset_evaluate (code/ntt.py:132-135): `coeffs` [m][2] is the WHOLE coefficient vector, replicated on
+        every rank (it is only 1/blowup of the domain); each rank scales it by offset^j, keeps the columns of its slab,
+        zero-pads to n1 rows and runs forward().  y_local [n2][n1/G] receives this rank's slab of the codeword on
+        { offset * root^i }."""
+        m = coeffs.shape[0]
+        R, C, G = self.n1, self.n2, self.world
+        assert m <= self.n and tuple(coeffs.shape) == (m, 2)
+        cw = C // G
+        scaled = self._buf("lde_scaled", (m, 2))
+        self._run(lambda: self.engine.scale_powers(coeffs.contiguous(), scaled, m, int(offset)))
+        x = self._buf("lde_x", (R, cw, 2))
+        x.zero_()
+        full_rows, rest = divmod(m, C)                          # coefficient j sits at row j // C, column j % C
+        lo = self.rank * cw
+        if full_rows:
+            x[:full_rows] = scaled[:full_rows * C].view(full_rows, C, 2)[:, lo:lo + cw]
+        if rest > lo:
+            take = min(rest - lo, cw)
+            x[full_rows, :take] = scaled[full_rows * C + lo:full_rows * C + lo + take]
+        self.forward(x, y_local)
 
     def forward(self, x_local, y_local):
         """x_local [n1][n2/G] -> y_local [n2][n1/G]  (column slab of X[k2*n1 + k1])."""

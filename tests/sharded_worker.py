@@ -34,6 +34,10 @@ class OracleEngine:
         for r in range(batch):
             out[:, r, :] = np.frombuffer(po.C.ntt(root, np.ascontiguousarray(a[r]).tobytes(), length), dtype=np.uint64).reshape(length, 2)
 
+    def scale_powers(self, src, dst, count, factor):
+        raw = po.C.scale(src.contiguous().numpy().tobytes(), count, factor)
+        dst.copy_(torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(count, 2).copy()))
+
     def twiddle(self, buf, rows, cols, row_base, col_base, root, order, scale):
         a = self._np(buf).reshape(rows, cols, 2)
         for r in range(rows):
@@ -64,6 +68,13 @@ def main():
         ok &= got_in == full_in
         ok &= got == po.C.ntt(root, full_in, n)
         ok &= torch.equal(z, x)
+        # sharded LDE: replicated coefficients (ragged length), coset offset = generator
+        for m in (n // 4, n // 8 + 3, 1):
+            coeffs = synth.synth_packed(9, m)
+            lde = torch.empty(eng.local_shape(False), dtype=torch.int64)
+            eng.coset_evaluate(torch.from_numpy(coeffs.view(np.int64).copy()), po.GENERATOR, lde)
+            got_lde = gather_natural(lde, eng.n2, eng.n1, world).numpy().tobytes()
+            ok &= got_lde == po.C.coset_evaluate(coeffs.tobytes(), m, po.GENERATOR, root, n)
     dist.barrier()
     dist.destroy_process_group()
     if not ok:

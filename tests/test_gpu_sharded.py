@@ -164,3 +164,32 @@ def test_sharded_fri_hip_engine_matches_reference_proofs(sc):
             ser = ps.serialize()
             assert top == rec["top_level_indices"], (rec["logN"], R)
             assert hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"], (rec["logN"], R)
+
+
+def test_sharded_lde_then_sharded_fri_one_rank(sc):
+    """The whole sharded polynomial core on one rank with the HIP engines: coefficients -> ShardedNtt.coset_evaluate
+    (slab codeword) -> ShardedFri.prove, against the reference's golden proof for that LDE (tests/golden/fri.json)."""
+    import hashlib
+    from conftest import load_golden
+    from sharded import ShardedNtt, ShardedFri
+    from algebra import Field
+    from fri import Fri
+    from ip import ProofStream
+    dev = torch.device("cuda", 0)
+    field = Field.main()
+    rec = [r for r in load_golden("fri.json")["prove_synth"] if r["logN"] == 12][0]
+    N = 1 << rec["logN"]
+    om = field.primitive_nth_root(N)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        eng = ShardedNtt(rec["logN"], om.value, 0, 1, dev)
+        coeffs = torch.from_numpy(synth.synth_packed(rec["coeff_seed"], N // 4).view(np.int64).copy()).to(dev)
+        slab = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
+        eng.coset_evaluate(coeffs, po.GENERATOR, slab)
+    torch.cuda.synchronize()
+    assert hashlib.sha256(slab.cpu().numpy().tobytes()).hexdigest() == rec["codeword_sha256"]       # world 1: slab == natural order
+    fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+    ps = ProofStream()
+    top = ShardedFri(fr, eng.n1, 0, 1, dev).prove(slab, ps)
+    assert top == rec["top_level_indices"]
+    assert hashlib.sha256(ps.serialize()).hexdigest() == rec["serialized_sha256"]
