@@ -179,7 +179,7 @@ def main():
         out = {
             "metric": "ntt_field_elements_per_sec", "value": value, "unit": "field-elements/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u128 (2x64-bit limbs, Montgomery constants)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u128", "data": "synthetic",
             "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
                        "passes_per_transform": passes, "roundtrip_bit_exact": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
