@@ -90,7 +90,7 @@ class ShardedNtt:
             self.stream = None
         self.engine = engine
         self._bufs = {}
-        self.launches_per_transform = None
+        self._a2a_single = True
 
     # -- helpers ---------------------------------------------------------------------------------
     def local_shape(self, forward_input=True):
@@ -133,8 +133,20 @@ class ShardedNtt:
             return a
         rw, cw = R // G, C // G
         recv = self._buf("recv", (G, rw, cw, 2))
-        dist.all_to_all_single(recv.view(-1), a.view(-1), group=self.group)
+        self._all_to_all(recv, a)
         return self.assemble_rows(recv, R, C)
+
+    def _all_to_all(self, recv, a):
+        """recv[g'] <- rows [rank*rw, (rank+1)*rw) of rank g's slab.  One collective; the list form is only a fallback for
+        backends without all_to_all_single."""
+        if self._a2a_single:
+            try:
+                dist.all_to_all_single(recv.view(-1), a.view(-1), group=self.group)
+                return
+            except (RuntimeError, NotImplementedError):
+                self._a2a_single = False
+        G = self.world
+        dist.all_to_all(list(recv.view(G, -1).unbind(0)), list(a.view(G, -1).unbind(0)), group=self.group)
 
     def assemble_rows(self, recv, R, C):
         G = self.world
@@ -164,7 +176,7 @@ class ShardedNtt:
             self.stage_rows(a, dst, R, C, root)
             return
         recv = self._buf("recv", (G, rw, cw, 2))
-        dist.all_to_all_single(recv.view(-1), a.view(-1), group=self.group)
+        self._all_to_all(recv, a)
         # (4) row transforms straight from the chunked layout the all-to-all left behind
         if fused and eng.rows_ntt_t_chunked(recv, dst, C, rw, G, pow(root, R, P)):
             return
