@@ -348,3 +348,52 @@ def test_device_field_ops(sc):
     assert run(3, a, b) == [x * y % P for x, y in zip(a, b)]
     assert run(4, a, b) == [x * pow(2, -1, P) % P for x in a]
     assert run(5, a[:4096] + [1] * (n - 4096), b)[:4096] == [po.inv(x) for x in a[:4096]]
+
+
+def test_sharded_merkle_and_fold_primitives(sc):
+    """sc_merkle_query_dev, sc_merkle_level_copy_dev, sc_merkle_from_digests_dev, sc_fri_fold_slab_dev against the oracle."""
+    import numpy as np
+    lib = sc.lib()
+    N = 1 << 12
+    data = packed(1500, N)
+    levels = C.merkle_tree(data, N)
+    vec = sc.DeviceVector.from_bytes(data)
+    cw = sc.DeviceCodeword(vec, None)
+    tree = cw.tree()
+    # query: elements + paths in one call
+    idxs = [0, 1, 77, N // 2, N - 1, 77]
+    k = len(idxs)
+    arr = (ctypes.c_uint64 * k)(*idxs)
+    el = ctypes.create_string_buffer(16 * k)
+    pa = ctypes.create_string_buffer(64 * 12 * k)
+    sc._check(lib.sc_merkle_query_dev(tree._h, vec.ptr, arr, k, el, pa))
+    assert el.raw == b"".join(data[16 * i:16 * i + 16] for i in idxs)
+    assert [pa.raw[64 * 12 * q:64 * 12 * (q + 1)] for q in range(k)] == [b"".join(C.merkle_open(data, N, i)) for i in idxs]
+    # level copy: level l of the tree == the oracle's level l
+    for level in (0, 3, 11, 12):
+        cnt = N >> level
+        out = sc.DeviceVector(cnt * 4)                       # 64 bytes per digest = 4 elements of 16 bytes
+        tree.copy_level(level, out.ptr)
+        sc.synchronize()
+        off = 0 if level == 0 else 2 * N - (N >> (level - 1))
+        assert out.to_bytes() == levels[64 * off:64 * (off + cnt)], level
+    # tree from digests: feeding level 4 of the tree reproduces the same root and upper paths
+    cnt = N >> 4
+    lvl = sc.DeviceVector(cnt * 4)
+    tree.copy_level(4, lvl.ptr)
+    sc.synchronize()
+    top = sc.MerkleTree.from_digests_ptr(lvl.ptr, cnt)
+    assert top.root == tree.root == levels[-64:]
+    assert top.open(5) == C.merkle_open(data, N, 5 << 4)[4:]
+    # slab fold == natural fold restricted to the slab's columns
+    R, cols, col_base = 64, 16, 32
+    rows = N // R
+    alpha, omega = synth.synth_ints(88, 1)[0], po.primitive_nth_root(N)
+    full = np.frombuffer(data, dtype=np.uint64).reshape(rows, R, 2)
+    slab = np.ascontiguousarray(full[:, col_base:col_base + cols, :])
+    src = sc.DeviceVector.from_bytes(slab.tobytes())
+    dst = sc.DeviceVector(rows // 2 * cols)
+    sc._check(lib.sc_fri_fold_slab_dev(src.ptr, rows, cols, R, col_base, sc.fe_bytes(alpha), sc.fe_bytes(po.GENERATOR), sc.fe_bytes(omega), dst.ptr, None))
+    sc.synchronize()
+    want = np.frombuffer(C.fold(data, N, alpha, po.GENERATOR, omega), dtype=np.uint64).reshape(rows // 2, R, 2)[:, col_base:col_base + cols, :]
+    assert dst.to_bytes() == np.ascontiguousarray(want).tobytes()
