@@ -8,30 +8,40 @@ import pickle
 from hashlib import shake_256
 
 
+def _challenge(objects, num_bytes):
+    """SHAKE-256 of the pickled transcript prefix (default pickle protocol: the bytes are part of the protocol)."""
+    return shake_256(pickle.dumps(objects)).digest(num_bytes)
+
+
 class ProofStream:
+    """An append-only list of proof objects plus the verifier's read cursor."""
+
     def __init__(self):
         self.objects = []
         self.read_index = 0
 
+    # -- prover side
     def push(self, obj):
         self.objects.append(obj)
-
-    def pull(self):
-        assert(self.read_index < len(self.objects)), "ProofStream: cannot pull object; queue empty."
-        obj = self.objects[self.read_index]
-        self.read_index += 1
-        return obj
 
     def serialize(self):
         return pickle.dumps(self.objects)
 
     def prover_fiat_shamir(self, num_bytes=32):
-        return shake_256(self.serialize()).digest(num_bytes)
+        # the prover hashes everything sent so far
+        return _challenge(self.objects, num_bytes)
+
+    # -- verifier side
+    def deserialize(self, bb):
+        stream = ProofStream()
+        stream.objects = pickle.loads(bb)
+        return stream
+
+    def pull(self):
+        assert(self.read_index < len(self.objects)), "ProofStream: cannot pull object; queue empty."
+        self.read_index += 1
+        return self.objects[self.read_index - 1]
 
     def verifier_fiat_shamir(self, num_bytes=32):
-        return shake_256(pickle.dumps(self.objects[:self.read_index])).digest(num_bytes)
-
-    def deserialize(self, bb):
-        ps = ProofStream()
-        ps.objects = pickle.loads(bb)
-        return ps
+        # the verifier hashes only what it has read so far
+        return _challenge(self.objects[:self.read_index], num_bytes)
