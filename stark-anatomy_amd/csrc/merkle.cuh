@@ -201,6 +201,60 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __res
     store_digests_coalesced(sm, h, active, out, base, n_here);
 }
 
+// Fused subtree kernel: a workgroup owns 256 consecutive nodes of level `lvl0` and climbs up to `nlev` further levels of
+// THEIR subtree through LDS (256 -> 128 -> ... ), writing every level to its place in the tree (all levels are kept for
+// openings).  LEAVES = true: level lvl0 = 0 and its digests are hashed here from the field elements; false: the 256 nodes
+// are read from the tree.  One launch replaces up to nlev + 1 dependent launches (each a few microseconds of pure latency).
+//   levels : base of the tree; level l starts at digest offset level_off(l) = (l == 0 ? 0 : 2N - (N >> (l-1)))
+//   N      : number of leaves of the tree (power of two), width0 = N >> lvl0 nodes at the start level (multiple of 256)
+template <bool LEAVES>
+__global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev) {
+    __shared__ uint4 cur[256 * 4];                    // this level's digests of the subtree (16 KiB)
+    const uint32_t t = threadIdx.x;
+    const uint64_t wg = blockIdx.x;
+    auto level_off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
+    uint64_t h[8];
+    if (LEAVES) {
+        uint64_t m[16];
+        uint32_t len = leaf_message(elems[wg * 256u + t], m);
+        blake2b_single_block(m, len, h);
+    } else {
+        const ulonglong2* s = reinterpret_cast<const ulonglong2*>(levels + 8 * (level_off(lvl0) + wg * 256u + t));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ulonglong2 v = s[k]; h[2 * k] = v.x; h[2 * k + 1] = v.y; }
+    }
+    uint32_t width = 256;
+    for (int l = 0;; ++l) {
+        // publish this level: LDS for the next level, global for the tree (level lvl0 of a non-leaf launch is already there)
+        if (t < width) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                uint4 v;
+                v.x = (uint32_t)h[2 * k]; v.y = (uint32_t)(h[2 * k] >> 32); v.z = (uint32_t)h[2 * k + 1]; v.w = (uint32_t)(h[2 * k + 1] >> 32);
+                cur[dig_slot(t, k)] = v;
+            }
+        }
+        __syncthreads();
+        if (LEAVES || l > 0) {
+            uint4* dst = reinterpret_cast<uint4*>(levels + 8 * (level_off(lvl0 + l) + wg * width));
+            for (uint32_t q = t; q < width * 4u; q += 256u) dst[q] = cur[dig_slot(q >> 2, q & 3u)];     // coalesced
+        }
+        if (l == nlev) break;
+        width >>= 1;
+        if (t < width) {
+            uint64_t m[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                uint4 v = cur[dig_slot(2 * t + (k >> 2), k & 3u)];
+                m[2 * k] = ((uint64_t)v.y << 32) | v.x;
+                m[2 * k + 1] = ((uint64_t)v.w << 32) | v.z;
+            }
+            blake2b_single_block(m, 128u, h);
+        }
+        __syncthreads();                               // everyone has read `cur` before it is overwritten
+    }
+}
+
 // finishes the tree from a level of `width` <= 2048 digests down to the root inside ONE workgroup
 // (levels are written once and read only after the barrier, so L1 cannot hold a stale copy).
 __global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint64_t width) {

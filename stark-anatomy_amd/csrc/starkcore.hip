@@ -509,28 +509,42 @@ int download(void* h, const void* d, size_t bytes, hipStream_t st) {
     return SC_OK;
 }
 
-// finish a tree whose level 0 (the `width` digests at `levels`) is already in place
-int merkle_finish(uint64_t* levels, uint64_t width, hipStream_t st) {
-    uint64_t* cur = levels;
-    uint64_t w = width;
+// Climb from level `lvl` (already in the tree, `N >> lvl` nodes) to the root.  Wide levels: fused 8-level subtree launches
+// while at least 256 nodes remain per workgroup; then the single-workgroup tail.
+int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
+    const int logN = ilog2(N);
+    uint64_t w = N >> lvl;
     while (w > 2048) {
-        uint64_t* nxt = cur + 8 * w;
-        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((w / 2 + 255) / 256)), dim3(256), 0, st, cur, nxt, w / 2);
-        cur = nxt;
-        w >>= 1;
+        int nlev = 8;
+        if (nlev > logN - lvl) nlev = logN - lvl;
+        hipLaunchKernelGGL((merkle_subtree_kernel<false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
+        lvl += nlev;
+        w >>= nlev;
     }
-    if (w > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, cur, w);
+    if (w > 1) {
+        const uint64_t off = (lvl == 0) ? 0 : (2 * N - (N >> (lvl - 1)));
+        hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, levels + 8 * off, w);
+    }
     HIPCHK(hipGetLastError());
     return SC_OK;
 }
+
+// finish a tree whose level 0 (the `width` digests at `levels`) is already in place
+int merkle_finish(uint64_t* levels, uint64_t width, hipStream_t st) { return merkle_climb(levels, width, 0, st); }
 
 int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st) {
     if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
     uint64_t* levels = nullptr;
     const size_t tree_bytes = (2 * N - 1) * 64;
     HIPCHK(pool_alloc((void**)&levels, tree_bytes));
-    hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_elems, levels, N);
-    (void)merkle_finish(levels, N, st);
+    if (N >= 256) {
+        int nlev = ilog2(N) < 8 ? ilog2(N) : 8;                  // leaves + up to 8 levels of every 256-leaf subtree in one launch
+        hipLaunchKernelGGL((merkle_subtree_kernel<true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev);
+        (void)merkle_climb(levels, N, nlev, st);
+    } else {
+        hipLaunchKernelGGL(merkle_leaf_kernel, dim3(1), dim3(256), 0, st, d_elems, levels, N);
+        (void)merkle_climb(levels, N, 0, st);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
     e = hipMemcpyAsync(root_out, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
