@@ -509,22 +509,30 @@ int download(void* h, const void* d, size_t bytes, hipStream_t st) {
     return SC_OK;
 }
 
-// Climb from level `lvl` (already in the tree, `N >> lvl` nodes) to the root.  Wide levels: fused 8-level subtree launches
-// while at least 256 nodes remain per workgroup; then the single-workgroup tail.
+// Climb from level `lvl` (already in the tree, `N >> lvl` nodes) to the root.  Levels wider than FUSE_MAX_W nodes are
+// throughput-bound: one fully occupied launch per level.  Below that the chain of dependent launches is pure latency:
+// fused 8-level subtree launches (most threads idle on the upper levels, which is fine there), then the one-workgroup tail.
+// Measured (tools/merkle_timing.py): fusing everything halves the throughput of a 2^24-leaf tree but wins below 2^17.
+constexpr uint64_t FUSE_MAX_W = 1ull << 17;
+
 int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
     const int logN = ilog2(N);
     uint64_t w = N >> lvl;
+    auto off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
     while (w > 2048) {
-        int nlev = 8;
-        if (nlev > logN - lvl) nlev = logN - lvl;
-        hipLaunchKernelGGL((merkle_subtree_kernel<false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
-        lvl += nlev;
-        w >>= nlev;
+        if (w > FUSE_MAX_W) {
+            hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((w / 2 + 255) / 256)), dim3(256), 0, st, levels + 8 * off(lvl), levels + 8 * off(lvl + 1), w / 2);
+            lvl += 1;
+            w >>= 1;
+        } else {
+            int nlev = 8;
+            if (nlev > logN - lvl) nlev = logN - lvl;
+            hipLaunchKernelGGL((merkle_subtree_kernel<false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
+            lvl += nlev;
+            w >>= nlev;
+        }
     }
-    if (w > 1) {
-        const uint64_t off = (lvl == 0) ? 0 : (2 * N - (N >> (lvl - 1)));
-        hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, levels + 8 * off, w);
-    }
+    if (w > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, levels + 8 * off(lvl), w);
     HIPCHK(hipGetLastError());
     return SC_OK;
 }
@@ -537,10 +545,13 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
     uint64_t* levels = nullptr;
     const size_t tree_bytes = (2 * N - 1) * 64;
     HIPCHK(pool_alloc((void**)&levels, tree_bytes));
-    if (N >= 256) {
+    if (N >= 256 && N <= FUSE_MAX_W) {
         int nlev = ilog2(N) < 8 ? ilog2(N) : 8;                  // leaves + up to 8 levels of every 256-leaf subtree in one launch
         hipLaunchKernelGGL((merkle_subtree_kernel<true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev);
         (void)merkle_climb(levels, N, nlev, st);
+    } else if (N > FUSE_MAX_W) {
+        hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N);
+        (void)merkle_climb(levels, N, 0, st);
     } else {
         hipLaunchKernelGGL(merkle_leaf_kernel, dim3(1), dim3(256), 0, st, d_elems, levels, N);
         (void)merkle_climb(levels, N, 0, st);
