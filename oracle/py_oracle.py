@@ -110,6 +110,9 @@ def schoolbook_divmod(num, den):
         c = rem[dr] * lead_inv % P
         shift = dr - dd
         quo[shift] = c
+        # the reference subtracts Polynomial([0]*shift+[c]) * denominator (univariate.py:93-95): a list of shift+len(den)
+        # entries, so a denominator with trailing zeros lengthens the remainder list
+        rem += [0] * (shift + len(den) - len(rem))
         for j in range(dd + 1):
             rem[shift + j] = (rem[shift + j] - c * den[j]) % P
     return quo, rem

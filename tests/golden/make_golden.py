@@ -202,6 +202,12 @@ def gen_poly():
     for i, (m, f) in enumerate([(0, 2), (1, 2), (9, field.generator().value), (9, 0)]):
         c = fes(1300 + i, m)
         out["scale"].append({"seed": 1300 + i, "m": m, "factor": str(f), "out": vals(Polynomial(c).scale(fe(f)).coefficients)})
+    # schoolbook divide (univariate.py:80-97) incl. operands carrying trailing zeros: the LIST LENGTHS are part of the contract
+    out["divmod"] = []
+    for a, b in [([1], [1, 0]), ([1, 2, 3], [1, 1, 0, 0]), ([0, 0, 5, 0], [2, 0]), ([1, 2, 3, 4, 0, 0], [3, 1, 0]), ([5, 4, 3, 2, 1], [7, 1]),
+                 ([1, 2], [1, 2, 3]), ([], [1]), ([0, 0], [4]), ([field.p - 1, 1 << 64, 12345], [field.p - 2, 9])]:
+        q, r = Polynomial.divide(Polynomial([fe(v) for v in a]), Polynomial([fe(v) for v in b]))
+        out["divmod"].append({"num": [str(v) for v in a], "den": [str(v) for v in b], "quo": vals(q.coefficients), "rem": vals(r.coefficients)})
     dump("poly.json", out)
 
 
@@ -362,6 +368,8 @@ if __name__ == "__main__":
     big = "--big" in sys.argv
     if "--stark" in sys.argv:
         gen_stark()
+    elif "--poly" in sys.argv:
+        gen_poly()
     elif big:
         gen_ntt(True)
     else:

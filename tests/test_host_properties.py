@@ -1,0 +1,101 @@
+"""Property tests (hypothesis) of the host mirror modules against the Python oracle on random small inputs: coefficient
+values AND list lengths must agree, including zero / trailing-zero / empty operands.  CPU only."""
+import hashlib
+
+from hypothesis import given, settings, strategies as st
+
+from oracle import py_oracle as po
+from algebra import Field, FieldElement
+from univariate import Polynomial
+from merkle import Merkle
+from fri import Fri
+
+field = Field.main()
+P = po.P
+residue = st.one_of(st.integers(min_value=0, max_value=P - 1), st.sampled_from([0, 1, P - 1, 1 << 64, (1 << 119) + 1]))
+coeffs = st.lists(st.one_of(residue, st.just(0)), min_size=0, max_size=12)
+
+
+def poly(c):
+    return Polynomial([FieldElement(v, field) for v in c])
+
+
+def trim(c):
+    c = list(c)
+    while c and c[-1] == 0:
+        c.pop()
+    return c
+
+
+def vals(p):
+    return [x.value for x in p.coefficients]
+
+
+@settings(max_examples=150, deadline=None)
+@given(coeffs, coeffs)
+def test_mul_add_sub_match_oracle(a, b):
+    assert vals(poly(a) * poly(b)) == po.schoolbook_mul(a, b)
+    assert vals(poly(a) + poly(b)) == po.poly_add(a, b)
+    assert poly(a).degree() == po.degree(a)
+    assert (poly(a) - poly(a)).is_zero()
+
+
+@settings(max_examples=150, deadline=None)
+@given(coeffs, coeffs.filter(lambda c: any(v != 0 for v in c)))
+def test_divmod_matches_oracle(a, b):
+    q, r = Polynomial.divide(poly(a), poly(b))
+    oq, orr = po.schoolbook_divmod(a, b)
+    assert vals(q) == oq
+    assert vals(r) == orr
+    # Polynomial.__eq__ indexes by len(self.coefficients) (univariate.py:59-64, kept bug-compatible), so compare trimmed lists
+    assert trim(vals(q * poly(b) + r)) == trim(a)
+    assert r.degree() < poly(b).degree() or r.is_zero()
+
+
+@settings(max_examples=100, deadline=None)
+@given(coeffs, residue)
+def test_scale_and_evaluate(a, x):
+    assert vals(poly(a).scale(FieldElement(x, field))) == po.scale(a, x)
+    assert poly(a).evaluate(FieldElement(x, field)).value == po.evaluate(a, x)
+    assert (FieldElement(x, field) ^ 5).value == pow(x, 5, P)
+    if x:
+        assert (FieldElement(x, field).inverse() * FieldElement(x, field)).value == 1
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(min_value=0, max_value=5), st.data())
+def test_merkle_raw_digest_helpers(logn, data):
+    n = 1 << logn
+    leafs = [hashlib.blake2b(bytes([i, 7])).digest() for i in range(n)]
+    root = Merkle.commit_(leafs)
+    if n >= 2:
+        i = data.draw(st.integers(min_value=0, max_value=n - 1))
+        path = Merkle.open_(i, leafs)
+        assert len(path) == logn and Merkle.verify_(root, i, path, leafs[i])
+        j = data.draw(st.integers(min_value=0, max_value=n - 1))
+        if j != i:
+            assert not Merkle.verify_(root, j, path, leafs[i])
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.binary(min_size=1, max_size=40), st.integers(min_value=3, max_value=9), st.integers(min_value=1, max_value=16))
+def test_sample_indices_properties(seed, log_reduced, number):
+    reduced = 1 << log_reduced
+    size = reduced << 3
+    number = min(number, reduced)
+    fr = Fri(field.generator(), field.primitive_nth_root(256), 256, 4, 17)
+    idx = fr.sample_indices(seed, size, reduced, number)
+    assert len(idx) == number and all(0 <= i < size for i in idx)
+    assert len({i % reduced for i in idx}) == number          # distinct after folding to the last codeword (fri.py:47)
+    assert idx == fr.sample_indices(seed, size, reduced, number)
+
+
+def test_divmod_golden_oracle_and_host():
+    """Reference outputs of Polynomial.divide (univariate.py:80-97), list lengths included, for operands with trailing zeros."""
+    from conftest import load_golden
+    for rec in load_golden("poly.json")["divmod"]:
+        a, b = [int(v) for v in rec["num"]], [int(v) for v in rec["den"]]
+        want_q, want_r = [int(v) for v in rec["quo"]], [int(v) for v in rec["rem"]]
+        assert po.schoolbook_divmod(a, b) == (want_q, want_r)
+        q, r = Polynomial.divide(poly(a), poly(b))
+        assert (vals(q), vals(r)) == (want_q, want_r)
