@@ -45,7 +45,7 @@ const char* sc_last_error(void);
 int sc_synchronize(void);              /* wait for the library stream */
 /* tuning knobs for experiments (defaults are the measured optimum; -1 = choose by size where applicable): key in
  * {"max_tile_log","loge","max_col_log","min_tiles_log","single_pass_max_log","max_digit_log","direct_tw_max_log",
- *  "xcd_remap","fixed_shapes"}.  Plans are re-derived on the next call; results never depend on the tuning. */
+ *  "xcd_remap","fixed_shapes","merkle_big_nlev"}.  Plans are re-derived on the next call; results never depend on the tuning. */
 int sc_set_tuning(const char* key, int value);
 
 /* diagnostics: out[i] = op(a[i], b[i]) computed by the device field routines the kernels use.

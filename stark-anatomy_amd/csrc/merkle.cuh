@@ -17,7 +17,19 @@ __device__ __constant__ const uint64_t B2_IV[8] = {
     0x6A09E667F3BCC908ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull, 0xA54FF53A5F1D36F1ull,
     0x510E527FADE682D1ull, 0x9B05688C2B3E6C1Full, 0x1F83D9ABFB41BD6Bull, 0x5BE0CD19137E2179ull};
 
-__device__ __forceinline__ uint64_t rotr64(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
+// 64-bit rotate right on the 32-bit halves: two v_alignbit_b32 (4 issue cycles each).  The compiler's expansion of the i64
+// shift/or idiom is ~3.4 instructions (64-bit shifts included) per rotation -- see profiles/r01/merkle_pmc.md.
+template <int R> __device__ __forceinline__ uint64_t rotr64c(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (R == 32) return ((uint64_t)lo << 32) | hi;
+    if (R < 32) {
+        uint32_t nl = __builtin_amdgcn_alignbit(hi, lo, R), nh = __builtin_amdgcn_alignbit(lo, hi, R);
+        return ((uint64_t)nh << 32) | nl;
+    }
+    uint32_t nl = __builtin_amdgcn_alignbit(lo, hi, R - 32), nh = __builtin_amdgcn_alignbit(hi, lo, R - 32);
+    return ((uint64_t)nh << 32) | nl;
+}
+#define rotr64(x, r) rotr64c<r>(x)
 
 #define B2_G(a, b, c, d, x, y)                   \
     do {                                         \

@@ -216,6 +216,7 @@ struct Ctx {
     DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
     int xcd_remap = 1;
     int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
+    int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)
 };
 
 Ctx g;
@@ -510,9 +511,11 @@ int download(void* h, const void* d, size_t bytes, hipStream_t st) {
 }
 
 // Climb from level `lvl` (already in the tree, `N >> lvl` nodes) to the root.  Levels wider than FUSE_MAX_W nodes are
-// throughput-bound: one fully occupied launch per level.  Below that the chain of dependent launches is pure latency:
-// fused 8-level subtree launches (most threads idle on the upper levels, which is fine there), then the one-workgroup tail.
-// Measured (tools/merkle_timing.py): fusing everything halves the throughput of a 2^24-leaf tree but wins below 2^17.
+// throughput-bound: launches that fuse merkle_big_nlev (2) levels -- a workgroup's 256 -> 128 -> 64 nodes keep every active
+// wave full, and the intermediate levels are not re-read from HBM.  Below FUSE_MAX_W the chain of dependent launches is pure
+// latency: fused 8-level subtree launches (most threads idle on the upper levels, which is fine there), then the
+// one-workgroup tail.  Measured (tools/merkle_timing.py, profiles/r01/merkle_timing.txt): at 2^24 leaves 2 fused levels
+// 2.09 ms, 1 level per launch 2.46 ms, 4 levels 2.50 ms, 8 levels 4.5 ms.
 constexpr uint64_t FUSE_MAX_W = 1ull << 17;
 
 int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
@@ -520,7 +523,14 @@ int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
     uint64_t w = N >> lvl;
     auto off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
     while (w > 2048) {
-        if (w > FUSE_MAX_W) {
+        if (w > FUSE_MAX_W && g.merkle_big_nlev > 0 && (w >> g.merkle_big_nlev) >= 2048) {
+            // whole waves retire as the subtree narrows (256 -> 128 -> 64 nodes: 4, 2, 1 full waves), no lane is wasted and
+            // the intermediate levels are never re-read from HBM
+            const int nlev = g.merkle_big_nlev;
+            hipLaunchKernelGGL((merkle_subtree_kernel<false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
+            lvl += nlev;
+            w >>= nlev;
+        } else if (w > FUSE_MAX_W) {
             hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((w / 2 + 255) / 256)), dim3(256), 0, st, levels + 8 * off(lvl), levels + 8 * off(lvl + 1), w / 2);
             lvl += 1;
             w >>= 1;
@@ -549,6 +559,9 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
         int nlev = ilog2(N) < 8 ? ilog2(N) : 8;                  // leaves + up to 8 levels of every 256-leaf subtree in one launch
         hipLaunchKernelGGL((merkle_subtree_kernel<true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev);
         (void)merkle_climb(levels, N, nlev, st);
+    } else if (N > FUSE_MAX_W && g.merkle_big_nlev > 0) {
+        hipLaunchKernelGGL((merkle_subtree_kernel<true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, g.merkle_big_nlev);
+        (void)merkle_climb(levels, N, g.merkle_big_nlev, st);
     } else if (N > FUSE_MAX_W) {
         hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N);
         (void)merkle_climb(levels, N, 0, st);
@@ -655,6 +668,7 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "direct_tw_max_log") g.tuning.direct_tw_max_log = value;
     else if (k == "xcd_remap") g.xcd_remap = value;
     else if (k == "fixed_shapes") g.fixed_shapes = value;
+    else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);
     else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
     return SC_OK;
 }

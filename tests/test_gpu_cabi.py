@@ -283,7 +283,7 @@ def test_merkle(sc):
     root = ctypes.create_string_buffer(64)
     sc._check(lib.sc_merkle_commit(synth.pack_ints(vals), len(vals), root))
     assert root.raw == po.merkle_commit(vals)
-    for logn in (12, 16, 20):
+    for logn in (12, 16, 18, 19, 20):             # 18..20: the wide-level launches that fuse two levels
         N = 1 << logn
         data = packed(1100 + logn, N)
         tree = sc.MerkleTree.from_bytes(data)

@@ -5,14 +5,19 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd"))
 import starkcore as sc, synth
 sc.init(0)
+nlevs = [int(a) for a in sys.argv[1:]] or [None]        # optional: values of the "merkle_big_nlev" tuning to compare
 for logn in (12, 16, 20, 22, 24):
     n = 1 << logn
     v = sc.DeviceVector.from_bytes(synth.synth_packed(9, n).tobytes())
-    best = None
-    for _ in range(6):
-        t0 = time.perf_counter()
-        t = sc.MerkleTree.from_device(v)
-        dt = time.perf_counter() - t0
-        t.free()
-        best = dt if best is None or dt < best else best
-    print(json.dumps(dict(logn=logn, ms=round(best * 1e3, 3), gcompress_s=round((2 * n - 1) / best / 1e9, 2))), flush=True)
+    for nl in nlevs:
+        if nl is not None:
+            sc.set_tuning("merkle_big_nlev", nl)
+        best, root = None, None
+        for _ in range(6):
+            t0 = time.perf_counter()
+            t = sc.MerkleTree.from_device(v)
+            dt = time.perf_counter() - t0
+            root = t.root.hex()[:16]
+            t.free()
+            best = dt if best is None or dt < best else best
+        print(json.dumps(dict(logn=logn, big_nlev=nl, ms=round(best * 1e3, 3), gcompress_s=round((2 * n - 1) / best / 1e9, 2), root=root)), flush=True)
