@@ -12,6 +12,7 @@
 
 #include "../../include/starkcore.h"
 #include "merkle.cuh"
+#include "polytree.cuh"
 #include "ntt_plan.h"
 
 using namespace sc;
@@ -351,7 +352,7 @@ int get_plan(Fe root, int logn, bool need_ninv, hipStream_t st, PlanTables** out
     auto it = g.plans.find(key);
     bool built = false;
     if (it == g.plans.end()) {
-        if (g.plans.size() >= 64) { HIPCHK(hipDeviceSynchronize()); free_plans(); }
+        if (g.plans.size() >= 256) { HIPCHK(hipDeviceSynchronize()); free_plans(); }
         const uint64_t n = 1ull << logn;
         Fe rm = to_mont(root);
         PlanTables t;
@@ -611,6 +612,262 @@ int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStrea
     HIPCHK(hipMemcpyAsync(&hflag, fl, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (hflag) return fail(SC_ERR_DIV_ZERO, "divide by zero");
+    return SC_OK;
+}
+
+
+// ============================================================================ subproduct tree (polytree.cuh)
+
+// primitive 2^logn-th root the tree's internal transforms use: Field.primitive_nth_root (algebra.py:104-111), i.e. the
+// order-2^119 constant squared 119 - logn times.  The results of sc_polytree_* do not depend on which roots are used.
+Fe canonical_root(int logn) {
+    static Fe cache[120];
+    static bool have[120] = {false};
+    if (!have[logn]) {
+        Fe r = to_mont(Fe{0xb5038f9c18f6f7d1ull, 0x4040fbed12ee470full});
+        for (int i = 119; i > logn; --i) r = mont_mul(r, r);
+        cache[logn] = from_mont(r);
+        have[logn] = true;
+    }
+    return cache[logn];
+}
+
+// c * R^j (mod p) for c = (2^logn)^-1: the constant a pointwise kernel multiplies by to apply the inverse transform's n^-1
+// and cancel the R^-1 factors of its j Montgomery products
+Fe ninv_scaled(int logn, int j) {
+    Fe c = from_mont(mont_inv(to_mont(Fe{1ull << logn, 0})));
+    for (int i = 0; i < j; ++i) c = to_mont(c);
+    return c;
+}
+
+inline unsigned pt_blocks(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+// transform along axis 0 of a [2^loglen][2^logbatch] array (natural order, out != in); the inverse uses root^-1 and does NOT
+// scale by n^-1 (the pointwise kernel in front of it does)
+int ntt_cols(const Fe* in, Fe* out, int loglen, int logbatch, bool inverse, hipStream_t st) {
+    const uint64_t len = 1ull << loglen, B = 1ull << logbatch;
+    if (loglen == 0) {
+        if (in != out) HIPCHK(hipMemcpyAsync(out, in, B * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+        return SC_OK;
+    }
+    Fe rt = canonical_root(loglen);
+    if (inverse) rt = root_inverse(rt, len);
+    if (logbatch == 0) return ntt_device(in, out, loglen, rt, false, NttOpts(), st);
+    PlanTables* pt;
+    SCCHK(get_plan(rt, loglen, false, st, &pt));
+    NttTables tb;
+    tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
+    void* w;
+    SCCHK(scratch(0, len * B * sizeof(Fe), &w));
+    NttPlanDesc d;
+    if (plan_batched(d, BATCH_COLS, loglen, logbatch, tb, in, (Fe*)w, out, g.tuning)) return run_plan(d, st);
+    // columns longer than the batched plans take (only the top few levels of a big tree, a handful of columns each)
+    void *a, *b;
+    SCCHK(scratch(1, len * sizeof(Fe), &a));
+    SCCHK(scratch(2, len * sizeof(Fe), &b));
+    for (uint64_t c = 0; c < B; ++c) {
+        hipLaunchKernelGGL(pt_col_gather_kernel, dim3(pt_blocks(len)), dim3(256), 0, st, in, len, B, c, (Fe*)a);
+        SCCHK(ntt_device((const Fe*)a, (Fe*)b, loglen, rt, false, NttOpts(), st));
+        hipLaunchKernelGGL(pt_col_scatter_kernel, dim3(pt_blocks(len)), dim3(256), 0, st, (const Fe*)b, len, B, c, out);
+    }
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+}  // namespace
+
+struct sc_polytree {
+    uint64_t k, K;
+    int L;
+    Fe* zc;        // (L+1) levels of K entries: level l at zc + l*K, [2^l][K >> l], monic top coefficient implicit
+    Fe* zf;        // L levels of 2K entries: level l at zf + l*2K, [2^(l+1)][K >> l] = transforms of level l at twice its size
+    Fe* invg_f;    // size-2K transform of rev(Z)^-1 mod y^K (built by the first evaluation)
+    size_t zc_bytes, zf_bytes;
+};
+
+namespace {
+
+// small RAII holder for pool temporaries
+struct PoolTmp {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~PoolTmp() { if (p) pool_free(p, bytes); }
+    int get(size_t b) {
+        bytes = b;
+        HIPCHK(pool_alloc(&p, b));
+        return SC_OK;
+    }
+    Fe* fe() const { return (Fe*)p; }
+};
+
+int polytree_build(const Fe* d_points, uint64_t k, sc_polytree** out, hipStream_t st) {
+    if (k == 0) return fail(SC_ERR_BAD_ARG, "empty domain");
+    int L = 0;
+    while ((1ull << L) < k) ++L;
+    if (L > 30) return fail(SC_ERR_UNSUPPORTED, "domain too large");
+    const uint64_t K = 1ull << L;
+    sc_polytree* t = new sc_polytree{k, K, L, nullptr, nullptr, nullptr, (size_t)(L + 1) * K * sizeof(Fe), (size_t)(L ? L : 1) * 2 * K * sizeof(Fe)};
+    hipError_t e = pool_alloc((void**)&t->zc, t->zc_bytes);
+    if (e == hipSuccess) e = pool_alloc((void**)&t->zf, t->zf_bytes);
+    if (e != hipSuccess) {
+        if (t->zc) pool_free(t->zc, t->zc_bytes);
+        delete t;
+        return fail(SC_ERR_HIP, hipGetErrorString(e));
+    }
+    auto cleanup = [&](int rc) { pool_free(t->zc, t->zc_bytes); pool_free(t->zf, t->zf_bytes); delete t; return rc; };
+    PoolTmp buf, buf2;
+    int rc = buf.get(2 * K * sizeof(Fe));
+    if (rc == SC_OK) rc = buf2.get(K * sizeof(Fe));
+    if (rc != SC_OK) return cleanup(rc);
+    hipLaunchKernelGGL(pt_leaves_kernel, dim3(pt_blocks(K)), dim3(256), 0, st, d_points, k, t->zc, K);
+    for (int l = 0; l < L && rc == SC_OK; ++l) {
+        const uint64_t B = K >> l;
+        Fe* zcl = t->zc + (uint64_t)l * K;
+        Fe* zfl = t->zf + (uint64_t)l * 2 * K;
+        hipLaunchKernelGGL(pt_expand_kernel, dim3(pt_blocks(2 * K)), dim3(256), 0, st, (const Fe*)zcl, buf.fe(), K, B, (uint64_t)1);
+        rc = ntt_cols(buf.fe(), zfl, l + 1, L - l, false, st);
+        if (rc != SC_OK) break;
+        hipLaunchKernelGGL(pt_mul_pairs_kernel, dim3(pt_blocks(K)), dim3(256), 0, st, (const Fe*)zfl, buf2.fe(), K, ninv_scaled(l + 1, 2));
+        rc = ntt_cols(buf2.fe(), zcl + K, l + 1, L - l - 1, true, st);
+        if (rc != SC_OK) break;
+        hipLaunchKernelGGL(pt_sub_one_kernel, dim3(pt_blocks(B / 2)), dim3(256), 0, st, zcl + K, B / 2);
+    }
+    if (rc == SC_OK && hipGetLastError() != hipSuccess) rc = fail(SC_ERR_HIP, "polytree build launch failed");
+    if (rc == SC_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(SC_ERR_HIP, "polytree build failed");
+    if (rc != SC_OK) return cleanup(rc);
+    *out = t;
+    return SC_OK;
+}
+
+// rev(Z)^-1 mod y^K by Newton iteration (h <- h (2 - G h), precision doubling), kept as its size-2K transform
+int polytree_inverse_series(sc_polytree* t, hipStream_t st) {
+    if (t->invg_f || t->L == 0) return SC_OK;
+    const uint64_t K = t->K;
+    const int L = t->L;
+    PoolTmp G, h, H, T;
+    SCCHK(G.get(K * sizeof(Fe)));
+    SCCHK(h.get(2 * K * sizeof(Fe)));
+    SCCHK(H.get(2 * K * sizeof(Fe)));
+    SCCHK(T.get(2 * K * sizeof(Fe)));
+    hipLaunchKernelGGL(pt_rev_monic_kernel, dim3(pt_blocks(K)), dim3(256), 0, st, (const Fe*)(t->zc + (uint64_t)L * K), G.fe(), K);
+    const Fe one{1, 0};
+    HIPCHK(hipMemcpyAsync(h.p, &one, sizeof(Fe), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                    // `one` is a stack temporary
+    for (int lm = 0; lm < L; ++lm) {                      // m = 2^lm known coefficients -> 2m
+        const int logn = lm + 2;
+        const uint64_t n = 1ull << logn, m = 1ull << lm;
+        Fe rt = canonical_root(logn);
+        NttOpts o;
+        o.in_limit = m;
+        SCCHK(ntt_device(h.fe(), H.fe(), logn, rt, false, o, st));
+        o.in_limit = 2 * m;
+        SCCHK(ntt_device(G.fe(), T.fe(), logn, rt, false, o, st));
+        hipLaunchKernelGGL(pt_newton_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, H.fe(), (const Fe*)T.fe(), n, ninv_scaled(logn, 3));
+        SCCHK(ntt_device(H.fe(), h.fe(), logn, root_inverse(rt, n), false, NttOpts(), st));
+    }
+    Fe* f = nullptr;
+    HIPCHK(pool_alloc((void**)&f, 2 * K * sizeof(Fe)));
+    NttOpts o;
+    o.in_limit = K;
+    int rc = ntt_device(h.fe(), f, L + 1, canonical_root(L + 1), false, o, st);
+    if (rc == SC_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(SC_ERR_HIP, "inverse series failed");
+    if (rc != SC_OK) { pool_free(f, 2 * K * sizeof(Fe)); return rc; }
+    t->invg_f = f;
+    return SC_OK;
+}
+
+// values of the polynomial d_coeffs[0..m), m <= K, at all K leaves (the k real points first); d_out holds K entries.
+// bx, by: caller's temporaries of 2K entries each, tk: K entries.
+int polytree_evaluate_all(sc_polytree* t, const Fe* d_coeffs, uint64_t m, Fe* d_out, Fe* bx, Fe* by, Fe* tk, hipStream_t st) {
+    const uint64_t K = t->K;
+    const int L = t->L;
+    if (L == 0) {
+        if (m) HIPCHK(hipMemcpyAsync(d_out, d_coeffs, sizeof(Fe), hipMemcpyDeviceToDevice, st));
+        else HIPCHK(hipMemsetAsync(d_out, 0, sizeof(Fe), st));
+        return SC_OK;
+    }
+    SCCHK(polytree_inverse_series(t, st));
+    // root: c = first K coefficients of f/Z in 1/x = rev_K(f) * rev(Z)^-1 mod y^K
+    hipLaunchKernelGGL(pt_rev_poly_kernel, dim3(pt_blocks(2 * K)), dim3(256), 0, st, d_coeffs, m, by, K, 2 * K);
+    SCCHK(ntt_cols(by, bx, L + 1, 0, false, st));
+    hipLaunchKernelGGL(pt_mul_scaled_kernel, dim3(pt_blocks(2 * K)), dim3(256), 0, st, (const Fe*)bx, (const Fe*)t->invg_f, bx, 2 * K, ninv_scaled(L + 1, 2));
+    SCCHK(ntt_cols(bx, by, L + 1, 0, true, st));
+    // down: cur = by[0..K) holds the series of the level-l nodes, [2^l][K >> l]
+    for (int l = L; l >= 1; --l) {
+        const uint64_t n = 1ull << l;
+        const int logB = L - l;
+        SCCHK(ntt_cols(by, tk, l, logB, false, st));
+        hipLaunchKernelGGL(pt_corr_kernel, dim3(pt_blocks(2 * K)), dim3(256), 0, st, (const Fe*)tk, (const Fe*)(t->zf + (uint64_t)(l - 1) * 2 * K), bx, n, logB + 1,
+                           ninv_scaled(l, 2));
+        SCCHK(ntt_cols(bx, by, l, logB + 1, true, st));     // rows < n/2 = the first K entries = next level's series
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d_out, by, K * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+    return SC_OK;
+}
+
+// d_points: the k points again (only read when m > K, for the chunk powers x^K)
+int polytree_evaluate(sc_polytree* t, const Fe* d_coeffs, uint64_t m, const Fe* d_points, Fe* d_out, hipStream_t st) {
+    const uint64_t K = t->K, k = t->k;
+    PoolTmp bx, by, tk, all;
+    SCCHK(bx.get(2 * K * sizeof(Fe)));
+    SCCHK(by.get(2 * K * sizeof(Fe)));
+    SCCHK(tk.get(K * sizeof(Fe)));
+    SCCHK(all.get(K * sizeof(Fe)));
+    if (m <= K) {
+        SCCHK(polytree_evaluate_all(t, d_coeffs, m, all.fe(), bx.fe(), by.fe(), tk.fe(), st));
+        HIPCHK(hipMemcpyAsync(d_out, all.p, k * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+    } else {
+        if (!d_points) return fail(SC_ERR_BAD_ARG, "polynomial longer than the padded domain needs the points for chunked evaluation");
+        PoolTmp y;
+        SCCHK(y.get(k * sizeof(Fe)));
+        hipLaunchKernelGGL(pt_pow2_kernel, dim3(pt_blocks(k)), dim3(256), 0, st, d_points, k, t->L, y.fe());
+        const uint64_t chunks = (m + K - 1) / K;
+        for (uint64_t j = chunks; j-- > 0;) {
+            const uint64_t len = (j == chunks - 1) ? m - j * K : K;
+            SCCHK(polytree_evaluate_all(t, d_coeffs + j * K, len, all.fe(), bx.fe(), by.fe(), tk.fe(), st));
+            if (j == chunks - 1) HIPCHK(hipMemcpyAsync(d_out, all.p, k * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+            else hipLaunchKernelGGL(pt_horner_kernel, dim3(pt_blocks(k)), dim3(256), 0, st, d_out, (const Fe*)y.fe(), (const Fe*)all.fe(), k);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return SC_OK;
+}
+
+int polytree_interpolate(sc_polytree* t, const Fe* d_values, Fe* d_out, hipStream_t st) {
+    const uint64_t K = t->K, k = t->k, pad = K - k;
+    const int L = t->L;
+    if (L == 0) {
+        HIPCHK(hipMemcpyAsync(d_out, d_values, sizeof(Fe), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return SC_OK;
+    }
+    PoolTmp bx, by, tk, p;
+    SCCHK(bx.get(2 * K * sizeof(Fe)));
+    SCCHK(by.get(2 * K * sizeof(Fe)));
+    SCCHK(tk.get(K * sizeof(Fe)));
+    SCCHK(p.get(K * sizeof(Fe)));
+    const Fe* top = t->zc + (uint64_t)L * K;
+    // weights w_i = v_i / Z_real'(d_i); padding leaves get weight 0
+    hipLaunchKernelGGL(pt_deriv_kernel, dim3(pt_blocks(K)), dim3(256), 0, st, top, K, pad, k, p.fe());
+    SCCHK(polytree_evaluate_all(t, p.fe(), k, tk.fe(), bx.fe(), by.fe(), p.fe(), st));     // p doubles as the K-entry temporary: its content is consumed first
+    HIPCHK(hipMemsetAsync(p.p, 0, K * sizeof(Fe), st));
+    SCCHK(pointwise_div_device(d_values, tk.fe(), p.fe(), k, st));
+    // up: P = P_L * Z_R + P_R * Z_L
+    Fe* cur = p.fe();
+    Fe* nxt = tk.fe();
+    for (int l = 0; l < L; ++l) {
+        const uint64_t B = K >> l;
+        hipLaunchKernelGGL(pt_expand_kernel, dim3(pt_blocks(2 * K)), dim3(256), 0, st, (const Fe*)cur, bx.fe(), K, B, (uint64_t)0);
+        SCCHK(ntt_cols(bx.fe(), by.fe(), l + 1, L - l, false, st));
+        hipLaunchKernelGGL(pt_comb_kernel, dim3(pt_blocks(K)), dim3(256), 0, st, (const Fe*)by.fe(), (const Fe*)(t->zf + (uint64_t)l * 2 * K), bx.fe(), K, ninv_scaled(l + 1, 2));
+        SCCHK(ntt_cols(bx.fe(), nxt, l + 1, L - l - 1, true, st));
+        Fe* s = cur; cur = nxt; nxt = s;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d_out, cur + pad, k * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
     return SC_OK;
 }
 
@@ -1105,6 +1362,112 @@ int sc_merkle_free(sc_merkle_t* tree) {
     pool_free(tree->d_levels, (2 * tree->N - 1) * 64);
     delete tree;
     return SC_OK;
+}
+
+// ---- subproduct tree: fast_zerofier / fast_evaluate / fast_interpolate
+int sc_polytree_build_dev(const void* d_points, uint64_t k, sc_polytree_t** tree, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_points) return fail(SC_ERR_BAD_ARG, "null argument");
+    return polytree_build((const Fe*)d_points, k, tree, pick_stream(stream));
+}
+int sc_polytree_build(const void* points, uint64_t k, sc_polytree_t** tree) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !points || !k) return fail(SC_ERR_BAD_ARG, "empty domain");
+    PoolTmp dp;
+    SCCHK(dp.get(k * sizeof(Fe)));
+    SCCHK(upload(dp.p, points, k * sizeof(Fe), g.stream));
+    return polytree_build(dp.fe(), k, tree, g.stream);       // synchronises before returning: dp may go back to the pool
+}
+uint64_t sc_polytree_points(const sc_polytree_t* tree) { return tree ? tree->k : 0; }
+int sc_polytree_zerofier_dev(const sc_polytree_t* tree, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    hipStream_t st = pick_stream(stream);
+    hipLaunchKernelGGL(pt_zerofier_out_kernel, dim3(pt_blocks(tree->k + 1)), dim3(256), 0, st, (const Fe*)(tree->zc + (uint64_t)tree->L * tree->K), tree->K,
+                       tree->K - tree->k, tree->k, (Fe*)d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return SC_OK;
+}
+int sc_polytree_evaluate_dev(sc_polytree_t* tree, const void* d_coeffs, uint64_t m, const void* d_points, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_out || (m && !d_coeffs)) return fail(SC_ERR_BAD_ARG, "null argument");
+    return polytree_evaluate(tree, (const Fe*)d_coeffs, m, (const Fe*)d_points, (Fe*)d_out, pick_stream(stream));
+}
+int sc_polytree_interpolate_dev(sc_polytree_t* tree, const void* d_values, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_out || !d_values) return fail(SC_ERR_BAD_ARG, "null argument");
+    return polytree_interpolate(tree, (const Fe*)d_values, (Fe*)d_out, pick_stream(stream));
+}
+int sc_polytree_free(sc_polytree_t* tree) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!tree) return SC_OK;
+    hipStreamSynchronize(g.stream);
+    pool_free(tree->zc, tree->zc_bytes);
+    pool_free(tree->zf, tree->zf_bytes);
+    if (tree->invg_f) pool_free(tree->invg_f, 2 * tree->K * sizeof(Fe));
+    delete tree;
+    return SC_OK;
+}
+
+// host-buffer forms of ntt.py:66-80, :82-100, :102-130
+int sc_zerofier(const void* points, uint64_t k, void* out) {
+    if (k == 0) return SC_OK;
+    sc_polytree_t* t = nullptr;
+    SCCHK(sc_polytree_build(points, k, &t));
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PoolTmp d;
+        rc = d.get((k + 1) * sizeof(Fe));
+        if (rc == SC_OK) {
+            hipLaunchKernelGGL(pt_zerofier_out_kernel, dim3(pt_blocks(k + 1)), dim3(256), 0, g.stream, (const Fe*)(t->zc + (uint64_t)t->L * t->K), t->K, t->K - k, k, d.fe());
+            rc = download(out, d.p, (k + 1) * sizeof(Fe), g.stream);
+        }
+    }
+    sc_polytree_free(t);
+    return rc;
+}
+int sc_evaluate(const void* coeffs, uint64_t m, const void* points, uint64_t k, void* out) {
+    if (k == 0) return SC_OK;
+    sc_polytree_t* t = nullptr;
+    SCCHK(sc_polytree_build(points, k, &t));
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PoolTmp dc, dp, dv;
+        rc = dc.get((m ? m : 1) * sizeof(Fe));
+        if (rc == SC_OK) rc = dp.get(k * sizeof(Fe));
+        if (rc == SC_OK) rc = dv.get(k * sizeof(Fe));
+        if (rc == SC_OK) rc = upload(dc.p, coeffs, m * sizeof(Fe), g.stream);
+        if (rc == SC_OK) rc = upload(dp.p, points, k * sizeof(Fe), g.stream);
+        if (rc == SC_OK) rc = polytree_evaluate(t, dc.fe(), m, dp.fe(), dv.fe(), g.stream);
+        if (rc == SC_OK) rc = download(out, dv.p, k * sizeof(Fe), g.stream);
+    }
+    sc_polytree_free(t);
+    return rc;
+}
+int sc_interpolate(const void* points, const void* values, uint64_t k, void* out) {
+    if (k == 0) return SC_OK;
+    sc_polytree_t* t = nullptr;
+    SCCHK(sc_polytree_build(points, k, &t));
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PoolTmp dv, dout;
+        rc = dv.get(k * sizeof(Fe));
+        if (rc == SC_OK) rc = dout.get(k * sizeof(Fe));
+        if (rc == SC_OK) rc = upload(dv.p, values, k * sizeof(Fe), g.stream);
+        if (rc == SC_OK) rc = polytree_interpolate(t, dv.fe(), dout.fe(), g.stream);
+        if (rc == SC_OK) rc = download(out, dout.p, k * sizeof(Fe), g.stream);
+    }
+    sc_polytree_free(t);
+    return rc;
 }
 
 }  // extern "C"

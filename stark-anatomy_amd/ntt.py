@@ -98,6 +98,23 @@ def fast_multiply(lhs, rhs, primitive_root, root_order):
     return Polynomial(_unpack(out.raw, degree + 1, field))
 
 
+# Domains of at least this many points go to the device's level-batched subproduct tree (csrc/polytree.cuh); smaller ones
+# follow the reference's recursion below.  Zerofier, values and interpolant are unique, so both give the same lists.
+DEVICE_TREE_MIN_POINTS = 16
+
+_tree_memo = {}           # points (as packed bytes) -> PolyTree; fast_interpolate / fast_evaluate revisit the same domains
+
+
+def _device_tree(domain):
+    key = _pack(domain)
+    tree = _tree_memo.get(key)
+    if tree is None:
+        if len(_tree_memo) >= 8:
+            _tree_memo.clear()
+        tree = _tree_memo[key] = _sc.PolyTree(key)
+    return tree
+
+
 # The reference recomputes the zerofier of every sub-domain at every node of fast_evaluate / fast_interpolate
 # (ntt.py:92-93, :115-116); the polynomials are the same each time, so they are remembered per call tree.
 _zerofier_memo = {}
@@ -109,6 +126,8 @@ def fast_zerofier(domain, primitive_root, root_order):
         return Polynomial([])
     if len(domain) == 1:
         return Polynomial([-domain[0], primitive_root.field.one()])
+    if len(domain) >= DEVICE_TREE_MIN_POINTS:
+        return Polynomial(_unpack(_device_tree(domain).zerofier().to_bytes(), len(domain) + 1, primitive_root.field))
     key = (primitive_root.value, root_order, tuple(d.value for d in domain))
     hit = _zerofier_memo.get(key)
     if hit is not None:
@@ -128,6 +147,9 @@ def fast_evaluate(polynomial, domain, primitive_root, root_order):
         return []
     if len(domain) == 1:
         return [polynomial.evaluate(domain[0])]
+    if len(domain) >= DEVICE_TREE_MIN_POINTS:
+        coeffs = DeviceVector.from_bytes(_pack(polynomial.coefficients))
+        return _unpack(_device_tree(domain).evaluate(coeffs).to_bytes(), len(domain), primitive_root.field)
     half = len(domain) // 2
     lower, upper = domain[:half], domain[half:]
     lower_rem = polynomial % fast_zerofier(lower, primitive_root, root_order)
@@ -142,6 +164,10 @@ def fast_interpolate(domain, values, primitive_root, root_order):
         return Polynomial([])
     if len(domain) == 1:
         return Polynomial([values[0]])
+    if len(domain) >= DEVICE_TREE_MIN_POINTS:
+        # a repeated point raises AssertionError("divide by zero") like the field division at ntt.py:124-125
+        out = _device_tree(domain).interpolate(DeviceVector.from_bytes(_pack(values)))
+        return Polynomial(_unpack(out.to_bytes(), len(domain), primitive_root.field))
     half = len(domain) // 2
     lower, upper = domain[:half], domain[half:]
     lower_zerofier = fast_zerofier(lower, primitive_root, root_order)

@@ -60,6 +60,16 @@ SIGNATURES = {
     "sc_fri_fold_slab_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
     "sc_merkle_leaves": (_u64, [_vp]),
     "sc_merkle_free": (_int, [_vp]),
+    "sc_zerofier": (_int, [_vp, _u64, _vp]),
+    "sc_evaluate": (_int, [_vp, _u64, _vp, _u64, _vp]),
+    "sc_interpolate": (_int, [_vp, _vp, _u64, _vp]),
+    "sc_polytree_build": (_int, [_vp, _u64, ctypes.POINTER(_vp)]),
+    "sc_polytree_build_dev": (_int, [_vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "sc_polytree_points": (_u64, [_vp]),
+    "sc_polytree_zerofier_dev": (_int, [_vp, _vp, _vp]),
+    "sc_polytree_evaluate_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    "sc_polytree_interpolate_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "sc_polytree_free": (_int, [_vp]),
 }
 
 _lib = None
@@ -172,6 +182,49 @@ class DeviceVector:
     def free(self):
         if self._h is not None and _lib is not None:
             _lib.sc_vec_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PolyTree:
+    """Owner of an sc_polytree_t: the subproduct tree over a list of points, resident in HBM (code/ntt.py:66-130).
+
+    One tree serves the zerofier, any number of multipoint evaluations and interpolations over the same points."""
+
+    def __init__(self, points):
+        """points: DeviceVector or packed bytes (16 bytes per point), at least one point"""
+        self.points = points if isinstance(points, DeviceVector) else DeviceVector.from_bytes(points)
+        self.k = self.points.n
+        h = _vp()
+        _check(lib().sc_polytree_build_dev(self.points.ptr, self.k, ctypes.byref(h), None))
+        self._h = h
+
+    def zerofier(self):
+        out = DeviceVector(self.k + 1)
+        _check(lib().sc_polytree_zerofier_dev(self._h, out.ptr, None))
+        return out
+
+    def evaluate(self, coeffs):
+        """coeffs: DeviceVector of polynomial coefficients (any length) -> DeviceVector of the k values"""
+        out = DeviceVector(self.k)
+        _check(lib().sc_polytree_evaluate_dev(self._h, coeffs.ptr, coeffs.n, self.points.ptr, out.ptr, None))
+        return out
+
+    def interpolate(self, values):
+        """values: DeviceVector of k values -> DeviceVector of the k coefficients of the interpolant (degree < k)"""
+        assert values.n == self.k
+        out = DeviceVector(self.k)
+        _check(lib().sc_polytree_interpolate_dev(self._h, values.ptr, out.ptr, None))
+        return out
+
+    def free(self):
+        if self._h is not None and _lib is not None:
+            _lib.sc_polytree_free(self._h)
         self._h = None
 
     def __del__(self):

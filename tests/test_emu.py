@@ -131,7 +131,10 @@ def _batched_expect(data, kind, loglen, logbatch, root):
 
 @pytest.mark.parametrize("cfg", [(0, 3, 2, 6, 2, 0, 3, 8), (0, 6, 4, 8, 2, 0, 4, 3), (0, 7, 3, 9, 2, 0, 3, 4), (0, 12, 2, 11, 2, 4, 6, 8), (0, 5, 0, 6, 2, 0, 3, 8),
                                  (1, 3, 2, 6, 2, 0, 3, 8), (1, 6, 4, 8, 2, 0, 4, 3), (1, 7, 3, 9, 3, 0, 3, 4), (1, 12, 2, 11, 2, 4, 6, 8), (1, 9, 1, 11, 2, 0, 6, 8),
-                                 (0, 11, 4, 11, 2, 10, 6, 8), (1, 11, 4, 11, 2, 10, 6, 8)])
+                                 (0, 11, 4, 11, 2, 10, 6, 8), (1, 11, 4, 11, 2, 10, 6, 8),
+                                 # short columns, many of them: the level-batched transforms of the subproduct tree (polytree.cuh)
+                                 (0, 1, 9, 11, 2, 8, 6, 8), (0, 2, 8, 11, 2, 8, 6, 8), (0, 1, 1, 11, 2, 8, 6, 8), (0, 2, 1, 11, 2, 8, 6, 8), (0, 3, 1, 11, 2, 8, 6, 8),
+                                 (0, 4, 7, 11, 2, 8, 6, 8), (0, 9, 3, 11, 2, 8, 6, 8), (0, 10, 1, 11, 2, 8, 6, 8)])
 def test_emu_batched(emu, cfg):
     kind, loglen, logbatch, tile, loge, min_tiles, max_col, digit = cfg
     emu.emu_ntt_batched.restype = ctypes.c_int
