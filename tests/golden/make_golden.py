@@ -202,6 +202,23 @@ def gen_poly():
     for i, (m, f) in enumerate([(0, 2), (1, 2), (9, field.generator().value), (9, 0)]):
         c = fes(1300 + i, m)
         out["scale"].append({"seed": 1300 + i, "m": m, "factor": str(f), "out": vals(Polynomial(c).scale(fe(f)).coefficients)})
+    # larger trees (digest only): the device computes these level by level instead of by the reference's recursion
+    out["tree_big"] = []
+    n4 = 1024
+    root4 = field.primitive_nth_root(n4)
+    t0 = time.time()
+    dom = fes(1400, 300)
+    z = ref_ntt.fast_zerofier(dom, root4, n4)
+    out["tree_big"].append({"what": "zerofier", "dom_seed": 1400, "k": 300, "out_len": len(z.coefficients), "sha256": sha_packed(z.coefficients)})
+    dom = fes(1401, 257)
+    pol = Polynomial(fes(1402, 300))
+    ev = ref_ntt.fast_evaluate(pol, dom, root4, n4)
+    out["tree_big"].append({"what": "evaluate", "dom_seed": 1401, "k": 257, "poly_seed": 1402, "poly_len": 300, "out_len": len(ev), "sha256": sha_packed(ev)})
+    dom = fes(1403, 200)
+    vv = fes(1404, 200)
+    ip = ref_ntt.fast_interpolate(dom, vv, root4, n4)
+    out["tree_big"].append({"what": "interpolate", "dom_seed": 1403, "k": 200, "val_seed": 1404, "out_len": len(ip.coefficients), "sha256": sha_packed(ip.coefficients)})
+    print("tree_big %.1fs" % (time.time() - t0), flush=True)
     # schoolbook divide (univariate.py:80-97) incl. operands carrying trailing zeros: the LIST LENGTHS are part of the contract
     out["divmod"] = []
     for a, b in [([1], [1, 0]), ([1, 2, 3], [1, 1, 0, 0]), ([0, 0, 5, 0], [2, 0]), ([1, 2, 3, 4, 0, 0], [3, 1, 0]), ([5, 4, 3, 2, 1], [7, 1]),

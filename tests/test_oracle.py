@@ -139,6 +139,16 @@ def test_poly_golden_py():
             dom = synth.synth_ints(rec["dom_seed"], rec["k"])
         out = po.fast_interpolate(dom, synth.synth_ints(rec["val_seed"], rec["k"]), int(rec["root"]), rec["order"])
         assert [str(v) for v in out] == rec["out"]
+    for rec in g["tree_big"]:
+        dom = synth.synth_ints(rec["dom_seed"], rec["k"])
+        root, order = po.primitive_nth_root(1024), 1024
+        if rec["what"] == "zerofier":
+            out = po.fast_zerofier(dom, root, order)
+        elif rec["what"] == "evaluate":
+            out = po.fast_evaluate(synth.synth_ints(rec["poly_seed"], rec["poly_len"]), dom, root, order)
+        else:
+            out = po.fast_interpolate(dom, synth.synth_ints(rec["val_seed"], rec["k"]), root, order)
+        assert len(out) == rec["out_len"] and sha(synth.pack_ints(out)) == rec["sha256"], rec["what"]
     for rec in g["scale"]:
         c = synth.synth_ints(rec["seed"], rec["m"])
         assert [str(v) for v in po.scale(c, int(rec["factor"]))] == rec["out"]
