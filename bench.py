@@ -273,6 +273,42 @@ def extras(sc, lib):
         res["stark_census_2p24_1gpu"] = stark_census(sc, lib, field, 24)
     except Exception as e:
         res["stark_census_2p24_1gpu"] = {"error": repr(e)}
+    # Merkle.commit on 2^24 leaves (2^25 BLAKE2b compressions) and the subproduct tree of ntt.py:66-130 over 2^20 arbitrary points
+    try:
+        v = sc.DeviceVector.from_bytes(synth.synth_packed(9, 1 << 24).tobytes())
+        best = None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            t = sc.MerkleTree.from_device(v)
+            dt = time.perf_counter() - t0
+            t.free()
+            best = dt if best is None or dt < best else best
+        res["merkle_commit_2p24"] = {"ms": best * 1e3, "gcompress_s": (2 ** 25 - 1) / best / 1e9}
+        del v
+        k = 1 << 20
+        pts = sc.DeviceVector.from_bytes(synth.synth_packed(11, k).tobytes())
+        f = sc.DeviceVector.from_bytes(synth.synth_packed(12, k).tobytes())
+
+        def timed(fn, reps):
+            b, r = None, None
+            for _ in range(reps):
+                sc.synchronize()
+                t0 = time.perf_counter()
+                r = fn()
+                sc.synchronize()
+                d = time.perf_counter() - t0
+                b = d if b is None or d < b else b
+            return b, r
+
+        tb, tree = timed(lambda: sc.PolyTree(pts), 3)
+        timed(lambda: tree.evaluate(f), 1)                       # builds the tree's power-series inverse (once per tree)
+        te, vals = timed(lambda: tree.evaluate(f), 3)
+        ti, back = timed(lambda: tree.interpolate(vals), 3)
+        res["polytree_2p20_points"] = {"build_ms": tb * 1e3, "evaluate_ms": te * 1e3, "interpolate_ms": ti * 1e3,
+                                       "round_trip_ok": back.to_bytes() == f.to_bytes()}
+        tree.free()
+    except Exception as e:
+        res["merkle_polytree"] = {"error": repr(e)}
     return res
 
 

@@ -184,6 +184,42 @@ def fast_interpolate(domain, values, primitive_root, root_order):
     return lower_interpolant * upper_zerofier + upper_interpolant * lower_zerofier
 
 
+class DeviceDomain:
+    """A list of evaluation points resident in HBM together with its subproduct tree (built once): the device-resident form
+    of the `domain` argument of fast_zerofier / fast_evaluate / fast_interpolate for domains too large to marshal per call."""
+
+    def __init__(self, points, field=None):
+        """points: DeviceCodeword, DeviceVector (give `field`) or list[FieldElement]"""
+        if isinstance(points, DeviceCodeword):
+            vec, field = points.vec, points.field
+        elif isinstance(points, DeviceVector):
+            vec = points
+        else:
+            vec, field = DeviceVector.from_bytes(_pack(points)), points[0].field
+        assert(vec.n > 0), "empty domain"
+        self.field = field
+        self.tree = _sc.PolyTree(vec)
+
+    def __len__(self):
+        return self.tree.k
+
+
+def fast_zerofier_device(domain):
+    """fast_zerofier (ntt.py:66-80) of a DeviceDomain -> DeviceCodeword of len(domain) + 1 coefficients"""
+    return DeviceCodeword(domain.tree.zerofier(), domain.field)
+
+
+def fast_evaluate_device(coefficients, domain):
+    """fast_evaluate (ntt.py:82-100): coefficients (DeviceCodeword) at a DeviceDomain -> DeviceCodeword of values"""
+    return DeviceCodeword(domain.tree.evaluate(coefficients.vec), domain.field)
+
+
+def fast_interpolate_device(domain, values):
+    """fast_interpolate (ntt.py:102-130): values (DeviceCodeword) on a DeviceDomain -> DeviceCodeword of len(domain) coefficients"""
+    assert(len(domain) == len(values)), "cannot interpolate over domain of different length than values list"
+    return DeviceCodeword(domain.tree.interpolate(values.vec), domain.field)
+
+
 def fast_coset_evaluate_device(polynomial, offset, generator, order):
     """fast_coset_evaluate with the result left in HBM as a DeviceCodeword."""
     coeffs = polynomial.coefficients

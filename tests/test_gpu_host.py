@@ -117,14 +117,59 @@ def test_poly_golden_through_host_api():
         assert len(out) == rec["order"] and sha_packed(out) == rec["sha256"]
 
 
-def test_interpolate():                           # code/test_ntt.py:72-96 (fewer, smaller trials)
+def test_interpolate():                           # code/test_ntt.py:72-96: 10 trials of random size below 512
     n = 1 << 9
     primitive_root = field.primitive_nth_root(n)
-    for N in (1, 2, 37, 130):
+    for N in [1, 2, 15, 16, 37, 511] + [1 + rng.randrange(n - 1) for _ in range(10)]:
         values = [rand_fe() for _ in range(N)]
         domain = [rand_fe() for _ in range(N)]
         poly = fast_interpolate(domain, values, primitive_root, n)
+        assert len(poly.coefficients) == N
         assert fast_evaluate(poly, domain, primitive_root, n)[0:N] == values
+
+
+def test_tree_paths_agree_and_big_goldens():
+    """the device subproduct tree (>= DEVICE_TREE_MIN_POINTS points) and the reference-shaped host recursion return the same
+    lists; larger reference goldens through the host API; the device-resident DeviceDomain API"""
+    import ntt as ntt_mod
+    from starkcore import DeviceCodeword
+    n = 128
+    root = field.primitive_nth_root(n)
+    for k in (16, 23, 40):
+        dom = [rand_fe() for _ in range(k)]
+        vals = [rand_fe() for _ in range(k)]
+        pol = Polynomial([rand_fe() for _ in range(k + 5)])
+        dev = (fast_zerofier(dom, root, n), fast_evaluate(pol, dom, root, n), fast_interpolate(dom, vals, root, n))
+        keep = ntt_mod.DEVICE_TREE_MIN_POINTS
+        ntt_mod.DEVICE_TREE_MIN_POINTS = 1 << 30
+        try:
+            host = (fast_zerofier(dom, root, n), fast_evaluate(pol, dom, root, n), fast_interpolate(dom, vals, root, n))
+        finally:
+            ntt_mod.DEVICE_TREE_MIN_POINTS = keep
+        assert dev[0].coefficients == host[0].coefficients and dev[1] == host[1] and dev[2].coefficients == host[2].coefficients
+    g = load_golden("poly.json")
+    root4 = field.primitive_nth_root(1024)
+
+    def fes(seed, cnt):
+        return [FieldElement(v, field) for v in synth.synth_ints(seed, cnt)]
+
+    for rec in g["tree_big"]:
+        dom = fes(rec["dom_seed"], rec["k"])
+        if rec["what"] == "zerofier":
+            out = fast_zerofier(dom, root4, 1024).coefficients
+        elif rec["what"] == "evaluate":
+            out = fast_evaluate(Polynomial(fes(rec["poly_seed"], rec["poly_len"])), dom, root4, 1024)
+        else:
+            out = fast_interpolate(dom, fes(rec["val_seed"], rec["k"]), root4, 1024).coefficients
+        assert len(out) == rec["out_len"] and sha_packed(out) == rec["sha256"], rec["what"]
+    # device-resident API: nothing is marshalled per element
+    k = 5000
+    dd = DeviceDomain(fes(31, k))
+    vals = DeviceCodeword.from_list(fes(32, k), field)
+    coeffs = fast_interpolate_device(dd, vals)
+    assert len(coeffs) == k and fast_evaluate_device(coeffs, dd).vec.to_bytes() == vals.vec.to_bytes()
+    z = fast_zerofier_device(dd)
+    assert len(z) == k + 1 and z[k] == field.one() and not any(fast_evaluate_device(z, dd).vec.to_bytes())
 
 
 def test_coset_evaluate():                        # code/test_ntt.py:98-116
