@@ -7,6 +7,9 @@
 // tree is kept in HBM (level 0 = leaf digests, then N/2, ..., root; (2N-1) * 64 bytes) so that
 // Merkle.open is a gather of log2 N digests instead of the reference's rebuild-per-open.
 #pragma once
+#ifndef SC_MERKLE_4LANE
+#define SC_MERKLE_4LANE 1      // narrow tree levels: four lanes per BLAKE2b compression (0: one lane per hash everywhere)
+#endif
 #include "field.cuh"
 
 namespace sc {
@@ -73,6 +76,76 @@ __device__ __forceinline__ void blake2b_single_block(const uint64_t m[16], uint3
     B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
 #pragma unroll
     for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+
+// ---- four lanes per hash ---------------------------------------------------------------------------------------------
+// Levels narrower than the machine are pure latency: a lone wave issues one VALU instruction per ~5.5 cycles, ~5 us for the
+// ~1950 instructions of a compression, whatever the level's width.  There the state is spread over a quad: lane j of the
+// quad holds column j (a, b, c, d) = (v[j], v[4+j], v[8+j], v[12+j]) and runs ONE G per half-round instead of four; the
+// diagonal step rotates b, c, d by 1, 2, 3 lanes inside the quad (DPP quad_perm, no LDS).  The message words are read from LDS
+// with per-lane addresses: COL/DIA pack, per round, byte j = sigma[2j] | sigma[2j+1] << 4 resp. sigma[8+2j] | sigma[9+2j] << 4.
+// ~800 instructions per lane and compression: ~2.7x shorter dependent chain.
+template <int CTRL> __device__ __forceinline__ uint64_t quad_perm64(uint64_t x) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xF, 0xF, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+#define B2_G4(x, y)                      \
+    do {                                 \
+        a = a + b + (x);                 \
+        d = rotr64(d ^ a, 32);           \
+        c = c + d;                       \
+        b = rotr64(b ^ c, 24);           \
+        a = a + b + (y);                 \
+        d = rotr64(d ^ a, 16);           \
+        c = c + d;                       \
+        b = rotr64(b ^ c, 63);           \
+    } while (0)
+
+#define B2_ROUND4(COL, DIA)                                                          \
+    do {                                                                             \
+        const uint32_t bc = ((uint32_t)(COL) >> sh) & 0xFFu;                         \
+        B2_G4(msg[bc & 15u], msg[bc >> 4]);                                          \
+        b = quad_perm64<0x39>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x93>(d); \
+        const uint32_t bd = ((uint32_t)(DIA) >> sh) & 0xFFu;                         \
+        B2_G4(msg[bd & 15u], msg[bd >> 4]);                                          \
+        b = quad_perm64<0x93>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x39>(d); \
+    } while (0)
+
+// single-block BLAKE2b-512 of the 128-byte message msg[0..16) (LDS), computed by the 4 lanes j = 0..3 of a quad (all four must
+// be active).  Lane j returns digest words j (h_lo) and 4 + j (h_hi).
+__device__ __forceinline__ void blake2b_node_4lane(const uint64_t* msg, uint32_t j, uint64_t& h_lo, uint64_t& h_hi) {
+    const uint32_t sh = 8u * j;
+    const uint64_t iv_a = B2_IV[j], iv_b = B2_IV[4 + j];
+    const uint64_t h0 = (j == 0) ? (iv_a ^ 0x01010040ull) : iv_a;
+    uint64_t a = h0, b = iv_b, c = iv_a, d = iv_b;
+    if (j == 0) d ^= 128ull;          // t0 = message length
+    if (j == 2) d = ~d;               // final block
+    B2_ROUND4(0x76543210u, 0xfedcba98u); B2_ROUND4(0x6df984aeu, 0x357b20c1u); B2_ROUND4(0xdf250c8bu, 0x491763eau);
+    B2_ROUND4(0xebcd1397u, 0x8f04a562u); B2_ROUND4(0xfa427509u, 0xd386cb1eu); B2_ROUND4(0x38b0a6c2u, 0x91ef57d4u);
+    B2_ROUND4(0xa4def15cu, 0xb8293670u); B2_ROUND4(0x931ce7bdu, 0xa2684f05u); B2_ROUND4(0x803b9ef6u, 0x5a417d2cu);
+    B2_ROUND4(0x5167482au, 0x0dc3e9bfu); B2_ROUND4(0x76543210u, 0xfedcba98u); B2_ROUND4(0x6df984aeu, 0x357b20c1u);
+    h_lo = h0 ^ a ^ c;
+    h_hi = iv_b ^ b ^ d;
+}
+
+// LDS layout of a level for the 4-lane path: digest n at 64-bit word (n >> 1) * 17 + (n & 1) * 8, i.e. a parent's two children
+// are 16 contiguous words (its message) and consecutive messages are 136 bytes apart (spreads the quads over the banks)
+__device__ __forceinline__ uint32_t lin_off(uint32_t n) { return (n >> 1) * 17u + (n & 1u) * 8u; }
+
+// one level by the 4-lane path: `parents` nodes from the 2*parents digests in `src` (lin layout) into `dst` (lin layout) and to
+// the tree (`out`: the level's place in global memory).  Threads >= 4*parents idle as whole quads.
+__device__ __forceinline__ void merkle_level_4lane(const uint64_t* src, uint64_t* dst, uint64_t* __restrict__ out, uint32_t parents, uint32_t t) {
+    const uint32_t n = t >> 2, j = t & 3u;
+    if (n < parents) {
+        uint64_t lo, hi;
+        blake2b_node_4lane(src + 17u * n, j, lo, hi);
+        dst[lin_off(n) + j] = lo;
+        dst[lin_off(n) + 4u + j] = hi;
+        out[8u * n + j] = lo;
+        out[8u * n + 4u + j] = hi;
+    }
 }
 
 __device__ __forceinline__ uint32_t ndigits9(uint32_t x) {   // decimal digits of x < 10^9, x > 0
@@ -219,9 +292,14 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __res
 // are read from the tree.  One launch replaces up to nlev + 1 dependent launches (each a few microseconds of pure latency).
 //   levels : base of the tree; level l starts at digest offset level_off(l) = (l == 0 ? 0 : 2N - (N >> (l-1)))
 //   N      : number of leaves of the tree (power of two), width0 = N >> lvl0 nodes at the start level (multiple of 256)
+//   four_lane : latency-bound launch (few workgroups): levels of <= 64 nodes run four lanes per hash; throughput-bound
+//               launches keep one lane per hash (the 4-lane form costs ~1.6x the instructions per compression)
 template <bool LEAVES>
-__global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev) {
+__global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev, int four_lane) {
     __shared__ uint4 cur[256 * 4];                    // this level's digests of the subtree (16 KiB)
+#if SC_MERKLE_4LANE
+    __shared__ uint64_t linA[64 * 17], linB[32 * 17]; // 4-lane path: 128 resp. 64 digests in the lin layout
+#endif
     const uint32_t t = threadIdx.x;
     const uint64_t wg = blockIdx.x;
     auto level_off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
@@ -236,7 +314,8 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         for (int k = 0; k < 4; ++k) { ulonglong2 v = s[k]; h[2 * k] = v.x; h[2 * k + 1] = v.y; }
     }
     uint32_t width = 256;
-    for (int l = 0;; ++l) {
+    int l = 0;
+    for (;; ++l) {
         // publish this level: LDS for the next level, global for the tree (level lvl0 of a non-leaf launch is already there)
         if (t < width) {
 #pragma unroll
@@ -245,13 +324,22 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
                 v.x = (uint32_t)h[2 * k]; v.y = (uint32_t)(h[2 * k] >> 32); v.z = (uint32_t)h[2 * k + 1]; v.w = (uint32_t)(h[2 * k + 1] >> 32);
                 cur[dig_slot(t, k)] = v;
             }
+#if SC_MERKLE_4LANE
+            if (four_lane && width == 128) {
+#pragma unroll
+                for (uint32_t w = 0; w < 8; ++w) linA[lin_off(t) + w] = h[w];
+            }
+#endif
         }
         __syncthreads();
         if (LEAVES || l > 0) {
             uint4* dst = reinterpret_cast<uint4*>(levels + 8 * (level_off(lvl0 + l) + wg * width));
             for (uint32_t q = t; q < width * 4u; q += 256u) dst[q] = cur[dig_slot(q >> 2, q & 3u)];     // coalesced
         }
-        if (l == nlev) break;
+        if (l == nlev) return;
+#if SC_MERKLE_4LANE
+        if (four_lane && width == 128) break;          // latency-bound launch: the remaining levels (<= 64 nodes) go four lanes per hash
+#endif
         width >>= 1;
         if (t < width) {
             uint64_t m[16];
@@ -265,19 +353,50 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         }
         __syncthreads();                               // everyone has read `cur` before it is overwritten
     }
+#if SC_MERKLE_4LANE
+    uint64_t* src = linA;
+    uint64_t* dst = linB;
+    for (++l; l <= nlev; ++l) {
+        width >>= 1;
+        merkle_level_4lane(src, dst, levels + 8 * (level_off(lvl0 + l) + wg * width), width, t);
+        __syncthreads();
+        uint64_t* s = src; src = dst; dst = s;
+    }
+#endif
 }
 
 // finishes the tree from a level of `width` <= 2048 digests down to the root inside ONE workgroup
-// (levels are written once and read only after the barrier, so L1 cannot hold a stale copy).
+// (levels are written once and read only after the barrier, so L1 cannot hold a stale copy).  Levels of <= 256 parents run
+// four lanes per hash out of LDS.
 __global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint64_t width) {
     uint64_t* cur = level;
-    for (uint64_t w = width; w > 1; w >>= 1) {
+    uint64_t w = width;
+#if SC_MERKLE_4LANE
+    __shared__ uint64_t linA[256 * 17], linB[128 * 17];   // 512 resp. 256 digests in the lin layout
+    for (; w > 512; w >>= 1) {
+#else
+    for (; w > 1; w >>= 1) {
+#endif
         uint64_t* nxt = cur + 8 * w;
         if (threadIdx.x < (w >> 1)) merkle_node(cur, nxt, threadIdx.x);
         __threadfence_block();
         __syncthreads();
         cur = nxt;
     }
+#if SC_MERKLE_4LANE
+    if (w <= 1) return;
+    for (uint32_t q = threadIdx.x; q < (uint32_t)w * 8u; q += 1024u) linA[lin_off(q >> 3) + (q & 7u)] = cur[q];
+    __syncthreads();
+    uint64_t* src = linA;
+    uint64_t* dst = linB;
+    for (; w > 1; w >>= 1) {
+        uint64_t* nxt = cur + 8 * w;
+        merkle_level_4lane(src, dst, nxt, (uint32_t)(w >> 1), threadIdx.x);
+        __syncthreads();
+        cur = nxt;
+        uint64_t* s = src; src = dst; dst = s;
+    }
+#endif
 }
 
 // authentication paths (merkle.py:16-27): for query q, digest l of the path = level_l[(index >> l) ^ 1]
