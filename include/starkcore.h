@@ -134,6 +134,10 @@ int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /*
 int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out /* k*64*log2 N */);
 /* opened elements AND their paths in one call: elems_out[i] = d_elems[indices[i]] (d_elems = the device vector the tree was built from) */
 int sc_merkle_query_dev(const sc_merkle_t* tree, const void* d_elems, const uint64_t* indices, uint64_t k, void* elems_out, uint8_t* paths_out);
+/* several (tree, vector) pairs in one round trip (the query phase of Fri.prove, fri.py:124-128): counts[t] of the concatenated
+ * `indices` belong to pair t; outputs concatenated in the same order (16 bytes per element, 64 * log2 N_t bytes per path) */
+int sc_merkle_query_multi_dev(uint64_t n, const sc_merkle_t* const* trees, const void* const* d_elems, const uint64_t* indices, const uint64_t* counts,
+                              void* elems_out, uint8_t* paths_out);
 /* pieces for a tree sharded over ranks: copy of one level of a built tree (level 0 = leaf digests; (N >> level) * 64 bytes),
  * a tree whose level 0 is given digests, and the fold of fri.py:85 on a rank's column slab [rows][cols] of the codeword
  * viewed as a rows x R matrix (index i = row*R + col_base + col; the partner i + N/2 is row + rows/2 of the same slab) */

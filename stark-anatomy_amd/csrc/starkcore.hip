@@ -1303,6 +1303,50 @@ int sc_merkle_query_dev(const sc_merkle_t* tree, const void* d_elems, const uint
     return SC_OK;
 }
 
+// the same for several (tree, vector) pairs in ONE round trip: Fri.prove's query phase opens every round's codeword
+// (fri.py:124-128); counts[t] indices belong to pair t, concatenated in `indices`; outputs are concatenated in the same order
+// (elements: 16 bytes each; paths: 64 * logN_t bytes per index of pair t).
+int sc_merkle_query_multi_dev(uint64_t n, const sc_merkle_t* const* trees, const void* const* d_elems, const uint64_t* indices, const uint64_t* counts,
+                              void* elems_out, uint8_t* paths_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    uint64_t total = 0;
+    size_t path_bytes = 0;
+    for (uint64_t t = 0; t < n; ++t) {
+        if (!trees[t] || !d_elems[t]) return fail(SC_ERR_BAD_ARG, "null tree or vector");
+        for (uint64_t i = 0; i < counts[t]; ++i) if (indices[total + i] >= trees[t]->N) return fail(SC_ERR_BAD_ARG, "cannot open invalid index");
+        total += counts[t];
+        path_bytes += counts[t] * 64 * (size_t)trees[t]->logN;
+    }
+    if (total == 0) return SC_OK;
+    const size_t idx_bytes = (total * 8 + 255) & ~255ull;
+    const size_t el_bytes = (total * sizeof(Fe) + 255) & ~255ull;
+    void* buf;
+    SCCHK(scratch(5, idx_bytes + el_bytes + path_bytes + 256, &buf));
+    uint64_t* d_idx = (uint64_t*)buf;
+    Fe* d_el = (Fe*)((char*)buf + idx_bytes);
+    uint64_t* d_paths = (uint64_t*)((char*)buf + idx_bytes + el_bytes);
+    SCCHK(upload(d_idx, indices, total * 8, g.stream));
+    uint64_t off = 0, poff = 0;
+    for (uint64_t t = 0; t < n; ++t) {
+        const uint64_t k = counts[t];
+        if (!k) continue;
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, g.stream, (const Fe*)d_elems[t], d_idx + off, k, d_el + off);
+        if (trees[t]->logN > 0) {
+            const uint64_t threads = k * (uint64_t)trees[t]->logN * 4;
+            hipLaunchKernelGGL(merkle_open_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g.stream, trees[t]->d_levels, trees[t]->N, trees[t]->logN,
+                               d_idx + off, k, d_paths + poff);
+        }
+        off += k;
+        poff += k * 8 * (uint64_t)trees[t]->logN;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(elems_out, d_el, total * sizeof(Fe), hipMemcpyDeviceToHost, g.stream));
+    if (path_bytes) HIPCHK(hipMemcpyAsync(paths_out, d_paths, path_bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return SC_OK;
+}
+
 // ---- pieces of a Merkle tree that is sharded over ranks (stark-anatomy_amd/sharded.py: ShardedFri)
 int sc_merkle_level_copy_dev(const sc_merkle_t* tree, int level, void* d_out, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -15,7 +15,7 @@ from ip import *
 from ntt import *
 from univariate import *
 import starkcore as _sc
-from starkcore import DeviceCodeword, DeviceVector
+from starkcore import DeviceCodeword, DeviceVector, query_codewords
 
 
 class Fri:
@@ -113,7 +113,7 @@ class Fri:
         return top_level_indices
 
     def _query_all(self, codewords, top_level_indices, proof_stream):
-        """The query phase of fri.py:124-128 with ONE device round trip per codeword: everything a codeword has to open
+        """The query phase of fri.py:124-128 with ONE device round trip for all rounds: everything a codeword has to open
         (its a/b entries for its own round, the c entries of the previous round) is fetched together, then pushed in the
         reference's order (per round: s triples, then 3*s paths as a, b, c)."""
         s = self.num_colinearity_tests
@@ -122,14 +122,18 @@ class Fri:
         for i in range(rounds):
             indices = [index % (len(codewords[i]) // 2) for index in indices]
             per_round.append(indices)
-        fetched = []
+        requests = []
         for j, cw in enumerate(codewords):
             request = []
             if j < rounds:
                 request += per_round[j][:s] + [index + len(cw) // 2 for index in per_round[j][:s]]
             if j > 0:
                 request += per_round[j - 1][:s]
-            fetched.append(cw.query(request))
+            requests.append(request)
+        if all(isinstance(cw, DeviceCodeword) for cw in codewords):
+            fetched = query_codewords(codewords, requests)          # every round's openings in one device round trip
+        else:
+            fetched = [cw.query(request) for cw, request in zip(codewords, requests)]
         for i in range(rounds):
             entries, paths = fetched[i]
             next_entries, next_paths = fetched[i + 1]

@@ -55,6 +55,7 @@ SIGNATURES = {
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
     "sc_merkle_open_batch": (_int, [_vp, _vp, _u64, _vp]),
     "sc_merkle_query_dev": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "sc_merkle_query_multi_dev": (_int, [_u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_merkle_level_copy_dev": (_int, [_vp, _int, _vp, _vp]),
     "sc_merkle_from_digests_dev": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_fri_fold_slab_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
@@ -189,6 +190,32 @@ class DeviceVector:
             self.free()
         except Exception:
             pass
+
+
+def query_codewords(codewords, requests):
+    """DeviceCodeword.query for several codewords in ONE device round trip: requests[t] = indices into codewords[t];
+    returns [(entries, paths)] in the same order (entries identity-preserving, paths fresh objects)."""
+    n = len(codewords)
+    trees = [cw.tree() for cw in codewords]
+    flat = [int(i) for req in requests for i in req]
+    total = len(flat)
+    if total == 0:
+        return [([], []) for _ in codewords]
+    depths = [t.depth for t in trees]
+    path_bytes = sum(64 * d * len(req) for d, req in zip(depths, requests))
+    elems = ctypes.create_string_buffer(16 * total)
+    paths = ctypes.create_string_buffer(path_bytes if path_bytes else 64)
+    _check(lib().sc_merkle_query_multi_dev(n, (_vp * n)(*[t._h for t in trees]), (_vp * n)(*[cw.vec.ptr for cw in codewords]),
+                                           (ctypes.c_uint64 * total)(*flat), (ctypes.c_uint64 * n)(*[len(req) for req in requests]), elems, paths))
+    values = unpack(elems.raw, total)
+    digests = _digest_struct(path_bytes // 64).unpack_from(paths) if path_bytes else ()
+    out, vo, po = [], 0, 0
+    for cw, req, d in zip(codewords, requests, depths):
+        k = len(req)
+        out.append((cw._entries(req, values[vo:vo + k]), [list(digests[po + q * d:po + (q + 1) * d]) for q in range(k)]))
+        vo += k
+        po += k * d
+    return out
 
 
 class PolyTree:
@@ -410,15 +437,16 @@ class DeviceCodeword(Sequence):
         elems = ctypes.create_string_buffer(16 * k)
         paths = ctypes.create_string_buffer(64 * d * k if d else 64)
         _check(lib().sc_merkle_query_dev(tree._h, self.vec.ptr, idx, k, elems, paths))
-        values = unpack(elems.raw, k)
-        out = []
-        if self._full is not None:
-            out = [self._full[i] for i in indices]
-        else:
-            known = self._elems
-            for i, v in zip(indices, values):
-                if i not in known:
-                    known[i] = self._fe(v)
-                out.append(known[i])
         digests = _digest_struct(d * k).unpack_from(paths) if d else ()
-        return out, [list(digests[q * d:(q + 1) * d]) for q in range(k)]
+        return self._entries(indices, unpack(elems.raw, k)), [list(digests[q * d:(q + 1) * d]) for q in range(k)]
+
+    def _entries(self, indices, values):
+        """FieldElement objects for freshly fetched residues, created once per index (see __init__)"""
+        if self._full is not None:
+            return [self._full[i] for i in indices]
+        out, known = [], self._elems
+        for i, v in zip(indices, values):
+            if i not in known:
+                known[i] = self._fe(v)
+            out.append(known[i])
+        return out

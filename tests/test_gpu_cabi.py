@@ -304,6 +304,19 @@ def test_merkle(sc):
         sc._check(lib.sc_merkle_commit(packed(1, 6), 6, root))
 
 
+@pytest.mark.parametrize("logn", list(range(0, 15)))
+def test_merkle_every_small_size(sc, logn):
+    """every tree shape of the latency-bound kernels (one workgroup tail, 4-lane narrow levels, fused subtrees) against the oracle"""
+    N = 1 << logn
+    data = packed(1200 + logn, N)
+    tree = sc.MerkleTree.from_bytes(data)
+    levels = C.merkle_tree(data, N)
+    assert tree.root == levels[-64:]
+    if N > 1:                                       # the reference cannot open a one-leaf tree either (merkle.py:17 on the empty half)
+        for i in sorted({0, N - 1, N // 3}):
+            assert tree.open(i) == C.merkle_open(data, N, i)
+
+
 def test_device_vector_api(sc):
     n = 1 << 14
     data = packed(1200, n)
