@@ -81,11 +81,20 @@ class MPolynomial:
         return acc
 
     def evaluate_symbolic(self, point):
+        # Same sums of products as multivariate.py:83-90.  The reference recomputes point[i] ^ e for every term; the powers
+        # are the same polynomials each time, so they are computed once per call, and a factor that is the constant 1
+        # (e = 0) is not multiplied out: `term * Polynomial([1])` has the same coefficient list as `term`.
+        powers = {}
         acc = Polynomial([])
         for k, v in self.dictionary.items():
             term = Polynomial([v])
             for i, e in enumerate(k):
-                term = term * (point[i] ^ e)
+                power = powers.get((i, e))
+                if power is None:
+                    power = powers[(i, e)] = point[i] ^ e
+                if len(power.coefficients) == 1 and power.coefficients[0].value == 1 and term.coefficients != []:
+                    continue
+                term = term * power
             acc = acc + term
         return acc
 
