@@ -139,6 +139,16 @@ class ShardedNtt:
     def _all_to_all(self, recv, a):
         """recv[g'] <- rows [rank*rw, (rank+1)*rw) of rank g's slab.  One collective; the list form is only a fallback for
         backends without all_to_all_single."""
+        if a.is_cuda and dist.get_backend(self.group) == "gloo":
+            # functional-test configuration only (several ranks sharing one GPU, tests/sharded_gpu_worker.py): gloo has no
+            # device all-to-all, so the exchange is staged through the host.  Production is backend "nccl" (= RCCL).
+            host_recv = torch.empty(recv.shape, dtype=recv.dtype)
+            self._exchange(host_recv, a.cpu())
+            recv.copy_(host_recv)
+            return
+        self._exchange(recv, a)
+
+    def _exchange(self, recv, a):
         if self._a2a_single:
             try:
                 dist.all_to_all_single(recv.view(-1), a.view(-1), group=self.group)

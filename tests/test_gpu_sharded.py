@@ -135,6 +135,26 @@ def test_bench_sharded_path_under_torchrun_one_rank():
     assert "fourstep" in out["config"]["workload"]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_share_one_gpu(world):
+    """Several PROCESSES, each driving the HIP engine on its slab (all on GPU 0), exchanging through gloo with a host-staged
+    all-to-all: everything of the N > 1 path except RCCL itself, against the oracle's transform of the full vector."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "tests", "sharded_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == world
+
+
 def test_sharded_fri_hip_engine_matches_reference_proofs(sc):
     """ShardedFri with the HIP engine (slab fold kernel, tree levels, tree from digests, openings) on one rank: the proof
     must be byte-identical to the reference's golden Fri.prove for every slab shape (the multi-rank orchestration is
