@@ -120,6 +120,13 @@ int sc_polytree_evaluate_dev(sc_polytree_t* tree, const void* d_coeffs, uint64_t
 int sc_polytree_interpolate_dev(sc_polytree_t* tree, const void* d_values, void* d_out, void* stream);
 int sc_polytree_free(sc_polytree_t* tree);
 
+/* ---- MPolynomial.evaluate_symbolic in the value domain : code/multivariate.py:83-90 (call site fast_stark.py:109-110) ---- */
+/* d_vals: [nvars][n] values of the point polynomials on an n-point domain (CONSUMED: converted in place to the library's
+ * internal form); exps: host [nterms][nvars] exponents, coefs: host nterms packed residues.
+ * d_out[i] = sum_t coefs[t] * prod_j vals[j][i]^exps[t][j].  With n > the degree of the result, an inverse NTT of d_out
+ * gives exactly the polynomial the reference builds from schoolbook products (§8(f)-2). */
+int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, void* stream);
+
 /* ---- FRI split-and-fold : code/fri.py:85 ---------------------------------------------------- */
 /* out[i] = 2^-1 * ((1 + alpha/(offset*omega^i)) * in[i] + (1 - alpha/(offset*omega^i)) * in[N/2+i]), i < N/2 */
 int sc_fri_fold(const void* in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* out);

@@ -128,6 +128,33 @@ __global__ void __launch_bounds__(256) twiddle_matrix_kernel(Fe* __restrict__ da
     data[i] = mont_mul(data[i], t);
 }
 
+// MPolynomial.evaluate_symbolic (code/multivariate.py:83-90) in the VALUE domain: the AIR polynomial evaluated pointwise on
+// the values of the point polynomials; vals_m: [nvars][n] in Montgomery form, coef_m: [nterms] in Montgomery form,
+// exps: [nterms][nvars].  out[i] = sum_t coef[t] * prod_j vals[j][i]^exps[t][j]  (canonical).  The term loop is uniform
+// across the wave (scalar control flow); the value loads are coalesced and stay in L1 across the terms.
+__global__ void __launch_bounds__(256) mpoly_eval_kernel(const Fe* __restrict__ vals_m, uint32_t nvars, uint64_t n, const uint8_t* __restrict__ exps,
+                                                        const Fe* __restrict__ coef_m, uint32_t nterms, Fe* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe acc{0, 0};
+    for (uint32_t t = 0; t < nterms; ++t) {
+        Fe p = coef_m[t];
+        const uint8_t* e = exps + (size_t)t * nvars;
+        for (uint32_t j = 0; j < nvars; ++j) {
+            const uint32_t ej = e[j];
+            if (ej == 0) continue;
+            const Fe v = vals_m[(uint64_t)j * n + i];
+            for (uint32_t k = 0; k < ej; ++k) p = mont_mul(p, v);
+        }
+        acc = fe_add(acc, p);
+    }
+    out[i] = from_mont(acc);
+}
+__global__ void __launch_bounds__(256) to_mont_kernel(Fe* __restrict__ a, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = to_mont(a[i]);
+}
+
 // diagnostics: elementwise field operations exactly as the kernels use them
 __global__ void __launch_bounds__(256) field_selftest_kernel(int op, const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1512,6 +1539,31 @@ int sc_interpolate(const void* points, const void* values, uint64_t k, void* out
     }
     sc_polytree_free(t);
     return rc;
+}
+
+// ---- MPolynomial.evaluate_symbolic in the value domain
+int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (!d_vals || !d_out || nvars == 0 || nvars > 255 || n == 0) return fail(SC_ERR_BAD_ARG, "bad argument");
+    const Fe* c = (const Fe*)coefs;
+    std::vector<Fe> cm(nterms ? nterms : 1);
+    for (uint64_t t = 0; t < nterms; ++t) {
+        if (fe_ge_p(c[t])) return fail(SC_ERR_BAD_ARG, "coefficient is not a canonical residue");
+        cm[t] = to_mont(c[t]);
+    }
+    const size_t cbytes = (cm.size() * sizeof(Fe) + 255) & ~255ull;
+    void* buf;
+    SCCHK(scratch(4, cbytes + nterms * nvars + 256, &buf));
+    SCCHK(upload(buf, cm.data(), cm.size() * sizeof(Fe), st));
+    if (nterms) SCCHK(upload((char*)buf + cbytes, exps, nterms * nvars, st));
+    hipLaunchKernelGGL(to_mont_kernel, dim3((unsigned)((nvars * n + 255) / 256)), dim3(256), 0, st, (Fe*)d_vals, nvars * n);
+    hipLaunchKernelGGL(mpoly_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fe*)d_vals, (uint32_t)nvars, n,
+                       (const uint8_t*)((char*)buf + cbytes), (const Fe*)buf, (uint32_t)nterms, (Fe*)d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));       // cm / exps are host temporaries of this call
+    return SC_OK;
 }
 
 }  // extern "C"

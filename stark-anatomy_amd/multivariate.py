@@ -2,7 +2,8 @@
 
 Host mirror of the interface of reference code/multivariate.py:3-123: `MPolynomial(dictionary)` maps exponent
 tuples to FieldElement coefficients; `zero / constant / variables / lift`, `+ - * ^ neg`, `is_zero`,
-`evaluate(point)` and `evaluate_symbolic(point)` (point = list of Polynomial).  Not on the GPU hot path.
+`evaluate(point)` and `evaluate_symbolic(point)` (point = list of Polynomial).  `evaluate_symbolic` of large points runs
+in the value domain on the GPU; everything else is host bookkeeping.
 """
 from univariate import *
 
@@ -72,15 +73,30 @@ class MPolynomial:
         return all(v.is_zero() for v in self.dictionary.values())
 
     def evaluate(self, point):
-        acc = point[0].field.zero()
+        # multivariate.py:75-81 on residues: each power point[i]^e is computed once per call instead of once per term,
+        # and factors with exponent 0 (the field's one) are not multiplied out -- same value
+        p = point[0].field.p
+        vals = [q.value for q in point]
+        powers = {}
+        acc = 0
         for k, v in self.dictionary.items():
-            term = v
+            term = v.value
             for i, e in enumerate(k):
-                term = term * (point[i] ^ e)
-            acc = acc + term
-        return acc
+                if e:
+                    pw = powers.get((i, e))
+                    if pw is None:
+                        pw = powers[(i, e)] = pow(vals[i], e, p)
+                    term = term * pw % p
+            acc = (acc + term) % p
+        return FieldElement(acc, point[0].field)
+
+    # degree bound of the result from which evaluate_symbolic goes through the value domain on the GPU
+    VALUE_DOMAIN_MIN_DEGREE = 48
 
     def evaluate_symbolic(self, point):
+        device = self._evaluate_symbolic_value_domain(point)
+        if device is not None:
+            return device
         # Same sums of products as multivariate.py:83-90.  The reference recomputes point[i] ^ e for every term; the powers
         # are the same polynomials each time, so they are computed once per call, and a factor that is the constant 1
         # (e = 0) is not multiplied out: `term * Polynomial([1])` has the same coefficient list as `term`.
@@ -97,6 +113,62 @@ class MPolynomial:
                 term = term * power
             acc = acc + term
         return acc
+
+    def _evaluate_symbolic_value_domain(self, point):
+        """The same polynomial computed pointwise: the point polynomials are evaluated on a power-of-two domain larger than
+        the degree of the result (one zero-padded NTT each), the AIR is evaluated value by value (`mpoly_eval_kernel`), and
+        one inverse NTT returns the coefficients.  The result is the unique polynomial the reference builds from schoolbook
+        products; only its list length (trailing zeros) may differ, which no caller observes (fast_stark.py:110 divides it
+        by the transition zerofier, which trims by degree).  Returns None when the point is too small to be worth it."""
+        if not self.dictionary or not point:
+            return None
+        field = None
+        for q in point:
+            if q.coefficients:
+                field = q.coefficients[0].field
+                break
+        if field is None or field.p != Field.P_MAIN:
+            return None
+        nvars = len(point)
+        degs = [q.degree() for q in point]
+        bound, terms = -1, []
+        for k, v in self.dictionary.items():
+            if len(k) > nvars or max(k, default=0) > 255:
+                return None
+            d, dead = 0, False
+            for i, e in enumerate(k):
+                if degs[i] < 0:
+                    dead = True               # Polynomial.__xor__ returns the zero polynomial for a zero base whatever the
+                    break                     # exponent, 0 included (univariate.py:139-140): the term vanishes
+                d += e * degs[i]
+            if dead or v.value == 0:
+                continue
+            terms.append((tuple(k) + (0,) * (nvars - len(k)), v.value))
+            bound = max(bound, d)
+        if bound < MPolynomial.VALUE_DOMAIN_MIN_DEGREE or nvars > 255:
+            return None
+        import ctypes
+        import starkcore as _sc
+        n = 1 << max(1, bound.bit_length())            # > bound
+        root = field.primitive_nth_root(n)
+        one = _sc.fe_bytes(1)
+        vals = _sc.DeviceVector(nvars * n)
+        lib = _sc.lib()
+        keep = []
+        for j, q in enumerate(point):
+            m = degs[j] + 1
+            src = _sc.DeviceVector.from_bytes(b"".join(c.value.to_bytes(16, "little") for c in q.coefficients[:m])) if m else _sc.DeviceVector(1)
+            keep.append(src)
+            _sc._check(lib.sc_coset_evaluate_dev(src.ptr, m, one, _sc.fe_bytes(root.value), n, vals.ptr + 16 * j * n, None))
+        exps = bytes(e for k, _ in terms for e in k)
+        coefs = b"".join(v.to_bytes(16, "little") for _, v in terms)
+        out = _sc.DeviceVector(n)
+        _sc._check(lib.sc_mpoly_eval_dev(vals.ptr, nvars, n, exps, coefs, len(terms), out.ptr, None))
+        coeffs = _sc.DeviceVector(n)
+        _sc._check(lib.sc_ntt_dev(out.ptr, coeffs.ptr, n, _sc.fe_bytes(root.value), 1, None))
+        raw = coeffs.to_bytes(0, bound + 1)
+        frm = int.from_bytes
+        return Polynomial([FieldElement(frm(raw[16 * i:16 * i + 16], "little"), field) for i in range(bound + 1)])
 
     def lift(polynomial, variable_index):
         if polynomial.is_zero():

@@ -256,3 +256,34 @@ def test_merkle_through_host_api():
         assert not Merkle.verify(Merkle.commit(els), rec["index"], path, els[rec["index"]] + field.one())
     with pytest.raises(AssertionError):
         Merkle.commit([field.one()] * 3)
+
+
+def test_evaluate_symbolic_value_domain_matches_schoolbook():
+    """MPolynomial.evaluate_symbolic through the value domain on the GPU (NTTs + mpoly_eval_kernel + inverse NTT) gives the
+    polynomial the reference's sums of schoolbook products give (multivariate.py:83-90)."""
+    from multivariate import MPolynomial
+
+    def trim(p):
+        return [c.value for c in p.coefficients[:p.degree() + 1]]
+
+    for nvars, nterms, maxe, plen in [(5, 40, 3, 40), (3, 7, 5, 33), (2, 3, 9, 20), (6, 60, 2, 70)]:
+        d = {}
+        for _ in range(nterms):
+            k = tuple(rng.randrange(maxe + 1) for _ in range(nvars))
+            d[k] = rand_fe()
+        d[(0,) * nvars] = rand_fe()                       # constant term
+        d[tuple([1] + [0] * (nvars - 1))] = field.zero()  # a zero coefficient
+        mp = MPolynomial(d)
+        point = [Polynomial([rand_fe() for _ in range(1 + rng.randrange(plen))]) for _ in range(nvars)]
+        point[-1] = Polynomial([field.zero(), field.one()])             # X itself, as fast_stark.py:108 passes it
+        if nvars == 6:
+            point[2] = Polynomial([])                                   # a zero polynomial kills the terms that use it
+        keep = MPolynomial.VALUE_DOMAIN_MIN_DEGREE
+        try:
+            MPolynomial.VALUE_DOMAIN_MIN_DEGREE = 0
+            dev = mp.evaluate_symbolic(point)
+            MPolynomial.VALUE_DOMAIN_MIN_DEGREE = 1 << 40
+            host = mp.evaluate_symbolic(point)
+        finally:
+            MPolynomial.VALUE_DOMAIN_MIN_DEGREE = keep
+        assert trim(dev) == trim(host), (nvars, nterms)

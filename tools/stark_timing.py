@@ -27,8 +27,15 @@ if prof: prof.enable()
 proof = stark.prove(trace, air, boundary, tz, tzc)
 if prof: prof.disable()
 t_prove = time.perf_counter() - t0
-t0 = time.perf_counter(); ok = stark.verify(proof, air, boundary, tzr); t_ver = time.perf_counter() - t0
+vprof = cProfile.Profile() if "--profile-verify" in sys.argv else None
+t0 = time.perf_counter()
+if vprof: vprof.enable()
+ok = stark.verify(proof, air, boundary, tzr)
+if vprof: vprof.disable()
+t_ver = time.perf_counter() - t0
 print(json.dumps(dict(fri_domain=stark.fri_domain_length, omicron_domain=stark.omicron_domain_length, preprocess_s=round(t_pre, 3), prove_s=round(t_prove, 3),
                       verify_s=round(t_ver, 3), verifies=ok, proof_bytes=len(proof))))
+if vprof:
+    pstats.Stats(vprof).sort_stats("cumulative").print_stats(22)
 if prof:
     pstats.Stats(prof).sort_stats("cumulative").print_stats(18)
