@@ -410,3 +410,53 @@ def test_sharded_merkle_and_fold_primitives(sc):
     sc.synchronize()
     want = np.frombuffer(C.fold(data, N, alpha, po.GENERATOR, omega), dtype=np.uint64).reshape(rows // 2, R, 2)[:, col_base:col_base + cols, :]
     assert dst.to_bytes() == np.ascontiguousarray(want).tobytes()
+
+
+def test_query_multi_and_mpoly_eval(sc):
+    """sc_merkle_query_multi_dev (all rounds of a FRI query phase in one round trip) and sc_mpoly_eval_dev (pointwise AIR
+    evaluation, multivariate.py:75-81 at every point of a domain) against the oracle / plain modular arithmetic."""
+    lib = sc.lib()
+    sizes = [1 << 10, 1 << 7, 1 << 3, 2]
+    datas = [packed(1300 + i, N) for i, N in enumerate(sizes)]
+    vecs = [sc.DeviceVector.from_bytes(d) for d in datas]
+    trees = [sc.MerkleTree.from_device(v) for v in vecs]
+    reqs = [[0, 5, 1023, 77], [127], [], [1, 0]]
+    n = len(sizes)
+    flat = [i for r in reqs for i in r]
+    el = ctypes.create_string_buffer(16 * len(flat))
+    pbytes = sum(64 * (N.bit_length() - 1) * len(r) for N, r in zip(sizes, reqs))
+    pa = ctypes.create_string_buffer(pbytes)
+    sc._check(lib.sc_merkle_query_multi_dev(n, (ctypes.c_void_p * n)(*[t._h for t in trees]), (ctypes.c_void_p * n)(*[v.ptr for v in vecs]),
+                                            (ctypes.c_uint64 * len(flat))(*flat), (ctypes.c_uint64 * n)(*[len(r) for r in reqs]), el, pa))
+    eo = po_ = 0
+    for data, N, r in zip(datas, sizes, reqs):
+        d = N.bit_length() - 1
+        for i in r:
+            assert el.raw[eo:eo + 16] == data[16 * i:16 * i + 16]
+            assert pa.raw[po_:po_ + 64 * d] == b"".join(C.merkle_open(data, N, i))
+            eo += 16
+            po_ += 64 * d
+    assert eo == 16 * len(flat) and po_ == pbytes
+    with pytest.raises(sc.StarkCoreError):
+        sc._check(lib.sc_merkle_query_multi_dev(1, (ctypes.c_void_p * 1)(trees[3]._h), (ctypes.c_void_p * 1)(vecs[3].ptr), (ctypes.c_uint64 * 1)(2),
+                                                (ctypes.c_uint64 * 1)(1), el, pa))
+    # pointwise multivariate evaluation
+    import random
+    rng = random.Random(11)
+    nvars, npts, nterms = 4, 300, 25
+    vals = [synth.synth_ints(1400 + j, npts) for j in range(nvars)]
+    terms = [(tuple(rng.randrange(4) for _ in range(nvars)), rng.randrange(P)) for _ in range(nterms)] + [((0,) * nvars, 5), ((9, 0, 0, 1), P - 1)]
+    dv = sc.DeviceVector.from_bytes(b"".join(synth.pack_ints(v) for v in vals))
+    out = sc.DeviceVector(npts)
+    exps = bytes(e for k, _ in terms for e in k)
+    sc._check(lib.sc_mpoly_eval_dev(dv.ptr, nvars, npts, exps, synth.pack_ints([c for _, c in terms]), len(terms), out.ptr, None))
+    want = []
+    for i in range(npts):
+        acc = 0
+        for k, c in terms:
+            t = c
+            for j, e in enumerate(k):
+                t = t * pow(vals[j][i], e, P) % P
+            acc = (acc + t) % P
+        want.append(acc)
+    assert synth.unpack_ints(out.to_bytes()) == want
