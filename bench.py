@@ -270,9 +270,31 @@ def extras(sc, lib):
     # fri_domain_length 2^24, omicron_domain_length 2^22, 2 registers: 4 LDEs to 2^24, 2 coset divisions at 2^22,
     # 3 Merkle commits of 2^24 leaves, Fri.prove on the combined codeword (17 rounds), 4 x 160 openings.
     try:
-        res["stark_census_2p24_1gpu"] = stark_census(sc, lib, field, 24)
+        runs = [stark_census(sc, lib, field, 24) for _ in range(2)]      # the first run also pays for mapping ~10 GB of fresh HBM
+        res["stark_census_2p24_1gpu"] = min(runs, key=lambda r: r["ms"])
     except Exception as e:
         res["stark_census_2p24_1gpu"] = {"error": repr(e)}
+    # the metric's other sizes (BASELINE.json: NTT elements/s at 2^22 and 2^24, forward + inverse), library stream, best of 3
+    for lg in (22, 24):
+        try:
+            nn = 1 << lg
+            rt = sc.fe_bytes(field.primitive_nth_root(nn).value)
+            a = sc.DeviceVector.from_bytes(synth.synth_packed(1, nn).tobytes())
+            b, c = sc.DeviceVector(nn), sc.DeviceVector(nn)
+            reps, best = (40 if lg == 22 else 10), None
+            for _ in range(3):
+                sc.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    sc._check(lib.sc_ntt_dev(a.ptr, b.ptr, nn, rt, 0, None))
+                    sc._check(lib.sc_ntt_dev(b.ptr, c.ptr, nn, rt, 1, None))
+                sc.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                best = dt if best is None or dt < best else best
+            res["ntt_fwd_inv_2p%d" % lg] = {"ms_per_pair": best * 1e3, "elements_per_s": 2 * nn / best, "roundtrip_bit_exact": c.to_bytes(0, 4096) == a.to_bytes(0, 4096)}
+            del a, b, c
+        except Exception as e:
+            res["ntt_fwd_inv_2p%d" % lg] = {"error": repr(e)}
     # Merkle.commit on 2^24 leaves (2^25 BLAKE2b compressions) and the subproduct tree of ntt.py:66-130 over 2^20 arbitrary points
     try:
         v = sc.DeviceVector.from_bytes(synth.synth_packed(9, 1 << 24).tobytes())
