@@ -326,6 +326,11 @@ class ShardedFri:
         t = t.contiguous()
         if self.world == 1:
             return t.unsqueeze(0)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":        # functional tests with several ranks on one GPU: host-staged
+            host = t.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(parts, host, group=self.group)
+            return torch.stack(parts, dim=0).to(t.device)
         parts = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(parts, t, group=self.group)
         return torch.stack(parts, dim=0)

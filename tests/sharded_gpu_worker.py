@@ -53,11 +53,47 @@ def main():
         if not ok:
             print("rank", rank, "MISMATCH at log2n", log2n, flush=True)
             break
+    ok &= fri_check(rank, world, dev)
     dist.barrier()
     dist.destroy_process_group()
     if not ok:
         sys.exit(3)
     print("rank", rank, "ok")
+
+
+def fri_check(rank, world, dev):
+    """ShardedFri with the HIP engine on every rank (slab-local folds, sharded Merkle commits, collective openings): the proof
+    must be the reference's, byte for byte (golden SHA-256 of the serialized proof stream)."""
+    import hashlib
+    import json
+    from sharded import ShardedFri
+    from algebra import Field
+    from fri import Fri
+    from ip import ProofStream
+    golden = json.load(open(os.path.join(REPO, "tests", "golden", "fri.json")))
+    field = Field.main()
+    ok = True
+    for rec in golden["prove_synth"]:
+        logN = rec["logN"]
+        N = 1 << logN
+        om = field.primitive_nth_root(N)
+        coeffs = synth.synth_packed(rec["coeff_seed"], N // 4).tobytes()
+        cw = np.frombuffer(po.C.coset_evaluate(coeffs, N // 4, po.GENERATOR, om.value, N), dtype=np.int64).reshape(N, 2)
+        for logR in {6: (2, 3), 10: (3, 5, 8), 12: (4, 6)}.get(logN, ()):
+            R = 1 << logR
+            if R < world:
+                continue
+            C, Rw = N // R, R // world
+            slab = torch.from_numpy(cw.reshape(C, R, 2)[:, rank * Rw:(rank + 1) * Rw, :].copy()).to(dev)
+            fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+            ps = ProofStream()
+            top = ShardedFri(fr, R, rank, world, dev).prove(slab, ps)
+            ser = ps.serialize()
+            good = (top == rec["top_level_indices"] and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
+            if not good:
+                print("rank", rank, "FRI MISMATCH logN", logN, "R", R, flush=True)
+            ok &= good
+    return ok
 
 
 if __name__ == "__main__":
