@@ -317,6 +317,22 @@ def test_merkle_every_small_size(sc, logn):
             assert tree.open(i) == C.merkle_open(data, N, i)
 
 
+def test_merkle_launch_shapes_do_not_change_the_tree(sc):
+    """the number of levels fused per launch on wide levels is a tuning knob: every setting must give the oracle's tree"""
+    N = 1 << 19
+    data = packed(1250, N)
+    levels = C.merkle_tree(data, N)
+    try:
+        for nlev in (0, 1, 2, 3, 5, 8):
+            sc.set_tuning("merkle_big_nlev", nlev)
+            tree = sc.MerkleTree.from_bytes(data)
+            assert tree.root == levels[-64:], nlev
+            assert tree.open(N - 3) == C.merkle_open(data, N, N - 3), nlev
+            tree.free()
+    finally:
+        sc.set_tuning("merkle_big_nlev", 2)
+
+
 def test_device_vector_api(sc):
     n = 1 << 14
     data = packed(1200, n)
