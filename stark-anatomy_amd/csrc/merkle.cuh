@@ -292,14 +292,14 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __res
 // are read from the tree.  One launch replaces up to nlev + 1 dependent launches (each a few microseconds of pure latency).
 //   levels : base of the tree; level l starts at digest offset level_off(l) = (l == 0 ? 0 : 2N - (N >> (l-1)))
 //   N      : number of leaves of the tree (power of two), width0 = N >> lvl0 nodes at the start level (multiple of 256)
-//   four_lane : latency-bound launch (few workgroups): levels of <= 64 nodes run four lanes per hash; throughput-bound
-//               launches keep one lane per hash (the 4-lane form costs ~1.6x the instructions per compression)
-template <bool LEAVES>
-__global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev, int four_lane) {
+//   FOUR_LANE : latency-bound launch (few workgroups): levels of <= 64 nodes run four lanes per hash; throughput-bound
+//               launches keep one lane per hash (the 4-lane form costs ~1.6x the instructions per compression) and the leaner
+//               instantiation (fewer registers, 16 KiB of LDS)
+template <bool LEAVES, bool FOUR_LANE>
+__global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev) {
     __shared__ uint4 cur[256 * 4];                    // this level's digests of the subtree (16 KiB)
-#if SC_MERKLE_4LANE
-    __shared__ uint64_t linA[64 * 17], linB[32 * 17]; // 4-lane path: 128 resp. 64 digests in the lin layout
-#endif
+    constexpr bool four_lane = FOUR_LANE && (SC_MERKLE_4LANE != 0);
+    __shared__ uint64_t linA[four_lane ? 64 * 17 : 1], linB[four_lane ? 32 * 17 : 1];   // 4-lane path: 128 resp. 64 digests in the lin layout
     const uint32_t t = threadIdx.x;
     const uint64_t wg = blockIdx.x;
     auto level_off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
@@ -324,12 +324,12 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
                 v.x = (uint32_t)h[2 * k]; v.y = (uint32_t)(h[2 * k] >> 32); v.z = (uint32_t)h[2 * k + 1]; v.w = (uint32_t)(h[2 * k + 1] >> 32);
                 cur[dig_slot(t, k)] = v;
             }
-#if SC_MERKLE_4LANE
-            if (four_lane && width == 128) {
+            if constexpr (four_lane) {
+                if (width == 128) {
 #pragma unroll
-                for (uint32_t w = 0; w < 8; ++w) linA[lin_off(t) + w] = h[w];
+                    for (uint32_t w = 0; w < 8; ++w) linA[lin_off(t) + w] = h[w];
+                }
             }
-#endif
         }
         __syncthreads();
         if (LEAVES || l > 0) {
@@ -337,9 +337,9 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
             for (uint32_t q = t; q < width * 4u; q += 256u) dst[q] = cur[dig_slot(q >> 2, q & 3u)];     // coalesced
         }
         if (l == nlev) return;
-#if SC_MERKLE_4LANE
-        if (four_lane && width == 128) break;          // latency-bound launch: the remaining levels (<= 64 nodes) go four lanes per hash
-#endif
+        if constexpr (four_lane) {
+            if (width == 128) break;                   // latency-bound launch: the remaining levels (<= 64 nodes) go four lanes per hash
+        }
         width >>= 1;
         if (t < width) {
             uint64_t m[16];
@@ -353,16 +353,16 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         }
         __syncthreads();                               // everyone has read `cur` before it is overwritten
     }
-#if SC_MERKLE_4LANE
-    uint64_t* src = linA;
-    uint64_t* dst = linB;
-    for (++l; l <= nlev; ++l) {
-        width >>= 1;
-        merkle_level_4lane(src, dst, levels + 8 * (level_off(lvl0 + l) + wg * width), width, t);
-        __syncthreads();
-        uint64_t* s = src; src = dst; dst = s;
+    if constexpr (four_lane) {
+        uint64_t* src = linA;
+        uint64_t* dst = linB;
+        for (++l; l <= nlev; ++l) {
+            width >>= 1;
+            merkle_level_4lane(src, dst, levels + 8 * (level_off(lvl0 + l) + wg * width), width, t);
+            __syncthreads();
+            uint64_t* s = src; src = dst; dst = s;
+        }
     }
-#endif
 }
 
 // finishes the tree from a level of `width` <= 2048 digests down to the root inside ONE workgroup

@@ -555,7 +555,7 @@ int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
             // whole waves retire as the subtree narrows (256 -> 128 -> 64 nodes: 4, 2, 1 full waves), no lane is wasted and
             // the intermediate levels are never re-read from HBM
             const int nlev = g.merkle_big_nlev;
-            hipLaunchKernelGGL((merkle_subtree_kernel<false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev, 0);
+            hipLaunchKernelGGL((merkle_subtree_kernel<false, false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
             lvl += nlev;
             w >>= nlev;
         } else if (w > FUSE_MAX_W) {
@@ -565,7 +565,7 @@ int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
         } else {
             int nlev = 8;
             if (nlev > logN - lvl) nlev = logN - lvl;
-            hipLaunchKernelGGL((merkle_subtree_kernel<false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev, 1);
+            hipLaunchKernelGGL((merkle_subtree_kernel<false, true>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
             lvl += nlev;
             w >>= nlev;
         }
@@ -585,10 +585,10 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
     HIPCHK(pool_alloc((void**)&levels, tree_bytes));
     if (N >= 256 && N <= FUSE_MAX_W) {
         int nlev = ilog2(N) < 8 ? ilog2(N) : 8;                  // leaves + up to 8 levels of every 256-leaf subtree in one launch
-        hipLaunchKernelGGL((merkle_subtree_kernel<true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev, 1);
+        hipLaunchKernelGGL((merkle_subtree_kernel<true, true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev);
         (void)merkle_climb(levels, N, nlev, st);
     } else if (N > FUSE_MAX_W && g.merkle_big_nlev > 0) {
-        hipLaunchKernelGGL((merkle_subtree_kernel<true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, g.merkle_big_nlev, 0);
+        hipLaunchKernelGGL((merkle_subtree_kernel<true, false>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, g.merkle_big_nlev);
         (void)merkle_climb(levels, N, g.merkle_big_nlev, st);
     } else if (N > FUSE_MAX_W) {
         hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N);
