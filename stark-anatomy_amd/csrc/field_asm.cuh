@@ -26,6 +26,13 @@ namespace sc {
 
 typedef uint64_t smask_t;   // 64-lane mask held in an SGPR pair
 
+#ifndef SC_HAZ_NOP
+// the 2 wait states between a VALU writing an SGPR pair and a VALU reading it.  Timing-only experiment (results are wrong
+// without them): dropping every nop gains 6 % at 2^20, 3 % at 2^22, nothing at 2^24 -- other waves fill the slots, so
+// hand-interleaving two multiplications to get rid of the nops is not worth its register cost.
+#define SC_HAZ_NOP "s_nop 1\n\t"
+#endif
+
 __device__ __forceinline__ uint64_t a_mad(uint32_t a, uint32_t b, uint64_t c) {
     uint64_t d; smask_t cy;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
@@ -44,18 +51,18 @@ __device__ __forceinline__ uint32_t a_add_co(uint32_t x, uint32_t y, smask_t& co
 }
 __device__ __forceinline__ uint32_t a_addc(uint32_t x, uint32_t y, smask_t ci, smask_t& co) {
     uint32_t s;
-    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s), "=s"(co) : "v"(x), "v"(y), "s"(ci));
+    asm(SC_HAZ_NOP "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s), "=s"(co) : "v"(x), "v"(y), "s"(ci));
     return s;
 }
 __device__ __forceinline__ uint32_t a_addc_last(uint32_t x, uint32_t y, smask_t ci) {
     uint32_t s; smask_t co;
-    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s), "=s"(co) : "v"(x), "v"(y), "s"(ci));
+    asm(SC_HAZ_NOP "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s), "=s"(co) : "v"(x), "v"(y), "s"(ci));
     return s;
 }
 // x + 0 + carry  (carry counter)
 __device__ __forceinline__ uint32_t a_inc(uint32_t x, smask_t ci) {
     uint32_t s; smask_t co;
-    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(s), "=s"(co) : "v"(x), "s"(ci));
+    asm(SC_HAZ_NOP "v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(s), "=s"(co) : "v"(x), "s"(ci));
     return s;
 }
 __device__ __forceinline__ uint32_t a_sub_co(uint32_t x, uint32_t y, smask_t& bo) {
@@ -65,19 +72,19 @@ __device__ __forceinline__ uint32_t a_sub_co(uint32_t x, uint32_t y, smask_t& bo
 }
 __device__ __forceinline__ uint32_t a_subb(uint32_t x, uint32_t y, smask_t bi, smask_t& bo) {
     uint32_t s;
-    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s), "=s"(bo) : "v"(x), "v"(y), "s"(bi));
+    asm(SC_HAZ_NOP "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s), "=s"(bo) : "v"(x), "v"(y), "s"(bi));
     return s;
 }
 // 0 - y - borrow
 __device__ __forceinline__ uint32_t a_negb(uint32_t y, smask_t bi, smask_t& bo) {
     uint32_t s;
-    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(s), "=s"(bo) : "v"(y), "s"(bi));
+    asm(SC_HAZ_NOP "v_subb_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(s), "=s"(bo) : "v"(y), "s"(bi));
     return s;
 }
 // sel ? b : a   per lane
 __device__ __forceinline__ uint32_t a_cnd(uint32_t a, uint32_t b, smask_t sel) {
     uint32_t r;
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(sel));
+    asm(SC_HAZ_NOP "v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(sel));
     return r;
 }
 
