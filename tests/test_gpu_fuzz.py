@@ -1,0 +1,119 @@
+"""Seeded differential fuzzing of the C-ABI against the oracle: random shapes (ragged lengths, tiny and mid sizes, random
+primitive roots, edge residues 0 / 1 / p-1 mixed in), every entry point of the hot path.  Bit-exact."""
+import ctypes
+import random
+
+import pytest
+
+from oracle import py_oracle as po
+import synth
+
+pytestmark = pytest.mark.gpu
+C = po.C
+P = po.P
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import starkcore
+    assert starkcore.device_count() > 0, "no GPU visible: the HIP path is mandatory for these tests"
+    starkcore.init()
+    return starkcore
+
+
+def rand_vals(rng, n):
+    edge = (0, 1, 2, P - 1, P - 2, 1 << 64, (1 << 64) - 1, 1 << 127)
+    return [rng.choice(edge) if rng.random() < 0.15 else rng.randrange(P) for _ in range(n)]
+
+
+def rand_root(rng, n):
+    """a random primitive n-th root: the canonical one raised to a random odd power"""
+    return pow(po.primitive_nth_root(n), rng.randrange(n) | 1, P) if n > 1 else 1
+
+
+def test_fuzz_ntt_and_lde(sc):
+    rng = random.Random(101)
+    lib = sc.lib()
+    for _ in range(60):
+        logn = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+        n = 1 << logn
+        root = rand_root(rng, n)
+        data = synth.pack_ints(rand_vals(rng, n))
+        out = ctypes.create_string_buffer(16 * n)
+        inv = rng.randrange(2)
+        sc._check(lib.sc_ntt(data, out, n, sc.fe_bytes(root), inv))
+        assert out.raw == (C.intt(root, data, n) if inv else C.ntt(root, data, n)), (logn, inv)
+        m = rng.randrange(0, n + 1)
+        offset = rng.choice([1, 2, po.GENERATOR, rng.randrange(1, P)])
+        coeffs = synth.pack_ints(rand_vals(rng, m))
+        sc._check(lib.sc_coset_evaluate(coeffs, m, sc.fe_bytes(offset), sc.fe_bytes(root), n, out))
+        assert out.raw == C.coset_evaluate(coeffs, m, offset, root, n), (logn, m)
+
+
+def test_fuzz_multiply_divide(sc):
+    rng = random.Random(102)
+    lib = sc.lib()
+    for _ in range(40):
+        la, lb = rng.randrange(1, 300), rng.randrange(1, 300)
+        a, b = rand_vals(rng, la), rand_vals(rng, lb)
+        if a[-1] == 0:
+            a[-1] = 7                                  # exact division needs the true degree
+        if b[-1] == 0:
+            b[-1] = 9
+        order = 1 << max(1, (la + lb - 1).bit_length())
+        root = rand_root(rng, order)
+        n_out = la + lb - 1
+        out = ctypes.create_string_buffer(16 * n_out)
+        sc._check(lib.sc_poly_mul(synth.pack_ints(a), la, synth.pack_ints(b), lb, sc.fe_bytes(root), order, out, n_out))
+        assert synth.unpack_ints(out.raw) == po.schoolbook_mul(a, b), (la, lb)
+        quo = ctypes.create_string_buffer(16 * lb)
+        offset = rng.choice([po.GENERATOR, 3])
+        try:
+            sc._check(lib.sc_coset_divide(out.raw, n_out, synth.pack_ints(a), la, sc.fe_bytes(offset), sc.fe_bytes(root), order, quo, lb))
+        except AssertionError:
+            continue                                   # the divisor happened to vanish on the coset (algebra.py:92)
+        assert synth.unpack_ints(quo.raw) == b, (la, lb)
+
+
+def test_fuzz_fold_and_merkle(sc):
+    rng = random.Random(103)
+    lib = sc.lib()
+    for _ in range(30):
+        logn = rng.randrange(1, 13)
+        N = 1 << logn
+        data = synth.pack_ints(rand_vals(rng, N))
+        om = rand_root(rng, N)
+        alpha, offset = rng.randrange(P), rng.randrange(1, P)
+        out = ctypes.create_string_buffer(8 * N)
+        sc._check(lib.sc_fri_fold(data, N, sc.fe_bytes(alpha), sc.fe_bytes(offset), sc.fe_bytes(om), out))
+        assert out.raw == C.fold(data, N, alpha, offset, om), logn
+        tree = sc.MerkleTree.from_bytes(data)
+        assert tree.root == C.merkle_commit(data, N)
+        idx = [rng.randrange(N) for _ in range(5)]
+        assert tree.open_batch(idx) == [C.merkle_open(data, N, i) for i in idx]
+        tree.free()
+
+
+def test_fuzz_subproduct_tree(sc):
+    rng = random.Random(104)
+    lib = sc.lib()
+    for _ in range(25):
+        k = rng.randrange(1, 120)
+        pts = rng.sample(range(1, 1 << 20), k)         # distinct
+        if rng.random() < 0.3:
+            pts[rng.randrange(k)] = 0
+        pts = [p_ if rng.random() < 0.5 else (p_ * 0x9E3779B97F4A7C15) % P for p_ in pts]
+        if len(set(pts)) != k:
+            continue
+        vals = rand_vals(rng, k)
+        m = rng.randrange(0, 3 * k + 2)
+        f = rand_vals(rng, m)
+        order = 256
+        root = po.primitive_nth_root(order)
+        out = ctypes.create_string_buffer(16 * (k + 1))
+        sc._check(lib.sc_zerofier(synth.pack_ints(pts), k, out))
+        assert synth.unpack_ints(out.raw) == po.fast_zerofier(pts, root, order), k
+        sc._check(lib.sc_evaluate(synth.pack_ints(f), m, synth.pack_ints(pts), k, out))
+        assert synth.unpack_ints(out.raw)[:k] == [po.evaluate(f, x) for x in pts], (k, m)
+        sc._check(lib.sc_interpolate(synth.pack_ints(pts), synth.pack_ints(vals), k, out))
+        assert synth.unpack_ints(out.raw)[:k] == po.fast_interpolate(pts, vals, root, order), k
