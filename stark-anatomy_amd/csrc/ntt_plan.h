@@ -36,6 +36,9 @@ struct NttTables {
     const Fe* twd[4] = {nullptr, nullptr, nullptr, nullptr};   // optional direct twiddle table per column pass (see PassParams::twd)
 };
 
+// LDS behind the tile for the tile transform's twiddles (w_R^i, i < R/2)
+inline uint32_t tile_twiddle_bytes(int logR) { return logR > 0 ? (uint32_t)sizeof(Fe) << (logR - 1) : 0u; }
+
 struct NttPassDesc {
     PassParams p;
     int loge;
@@ -177,7 +180,7 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
         if (loge < 1) return false;
         pd.loge = loge;
         pd.threads = 1u << (logT - loge);
-        pd.lds_bytes = (uint32_t)sizeof(Fe) << logT;
+        pd.lds_bytes = ((uint32_t)sizeof(Fe) << logT) + tile_twiddle_bytes(pd.p.logR);   // the tile, then its twiddles
         logA += logR;
     }
     return true;
@@ -338,7 +341,7 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
         if (loge < 1) return false;
         pd.loge = loge;
         pd.threads = 1u << (logT - loge);
-        pd.lds_bytes = (uint32_t)sizeof(Fe) << logT;
+        pd.lds_bytes = ((uint32_t)sizeof(Fe) << logT) + tile_twiddle_bytes(pd.p.logR);   // the tile, then its twiddles
     }
     return true;
 }

@@ -96,8 +96,9 @@ SC_HD Fe pow_table_entry(Fe base_m, uint64_t i, uint64_t step, Fe scale_m) {
 // One round of one workgroup's tile, for thread `tid`: S radix-2 DIF stages on row bits [sh, sh+S).
 // GLR / GLC >= 0 fix the tile geometry at compile time (the hot shapes get their own kernel instantiation: all the
 // index math below then folds into immediates); -1 = read it from P.
+// tw: the tile transform's twiddles w_R^i, i < R/2, staged in LDS by the kernel (tile_twiddles_to_lds).
 template <int LOGE, int S, int GLR = -1, int GLC = -1>
-SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds) {
+SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds, const Fe* tw) {
     constexpr int E = 1 << LOGE;
     constexpr int F = 1 << S;          // elements per butterfly group
     const int logR = (GLR >= 0) ? GLR : P.logR, logC = (GLC >= 0) ? GLC : P.logC;
@@ -168,7 +169,7 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
             } else {
                 const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
                 const uint32_t e = ((fi_low << sh) | row_lo) << tau;     // < R/2
-                x[i1] = mont_mul(d, P.mt[(uint64_t)e << P.mt_shift]);
+                x[i1] = mont_mul(d, tw[e]);
             }
         }
     }
@@ -202,11 +203,20 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
 
 // dispatch on the (runtime) number of stages in this round
 template <int LOGE, int GLR = -1, int GLC = -1>
-SC_HD void ntt_round_dispatch(const PassParams& P, int s, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds) {
-    if constexpr (LOGE >= 4) { if (s == 4) { ntt_round<LOGE, 4, GLR, GLC>(P, sh, first, tile, tid, lds); return; } }
-    if constexpr (LOGE >= 3) { if (s == 3) { ntt_round<LOGE, 3, GLR, GLC>(P, sh, first, tile, tid, lds); return; } }
-    if constexpr (LOGE >= 2) { if (s == 2) { ntt_round<LOGE, 2, GLR, GLC>(P, sh, first, tile, tid, lds); return; } }
-    ntt_round<LOGE, 1, GLR, GLC>(P, sh, first, tile, tid, lds);
+SC_HD void ntt_round_dispatch(const PassParams& P, int s, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds, const Fe* tw) {
+    if constexpr (LOGE >= 4) { if (s == 4) { ntt_round<LOGE, 4, GLR, GLC>(P, sh, first, tile, tid, lds, tw); return; } }
+    if constexpr (LOGE >= 3) { if (s == 3) { ntt_round<LOGE, 3, GLR, GLC>(P, sh, first, tile, tid, lds, tw); return; } }
+    if constexpr (LOGE >= 2) { if (s == 2) { ntt_round<LOGE, 2, GLR, GLC>(P, sh, first, tile, tid, lds, tw); return; } }
+    ntt_round<LOGE, 1, GLR, GLC>(P, sh, first, tile, tid, lds, tw);
+}
+
+// The twiddles of the tile transform (w_R^i, i < R/2: 16 bytes x R/2, 8 KiB for R = 2^10) are read by every butterfly of
+// every round; staged once per workgroup in LDS behind the tile they cost a ds_read instead of a global load with 64-bit
+// address arithmetic (measured: 3-4 % on whole transforms at 2^22-2^24, profiles/r01/ab_lds_twiddles.txt).
+// Thread `tid` of `nthreads` copies its share; the caller puts a barrier between this and the first round.
+SC_HD void tile_twiddles_to_lds(const PassParams& P, int logR, uint32_t tid, uint32_t nthreads, Fe* tw) {
+    const uint32_t count = logR > 0 ? (1u << (logR - 1)) : 0u;
+    for (uint32_t i = tid; i < count; i += nthreads) tw[i] = P.mt[(uint64_t)i << P.mt_shift];
 }
 
 // Fully unrolled round schedule for a compile-time geometry (short round first, like make_rounds()): every `sh` is a
@@ -219,11 +229,11 @@ struct FixedRounds {
     static constexpr int DONE = (ROUND == 0) ? 0 : (GLR - LOGE * (NR - 1)) + LOGE * (ROUND - 1);
     static constexpr int SH = GLR - DONE - S;
     template <class Sync>
-    SC_HD static void run(const PassParams& P, uint32_t tile, uint32_t tid, Fe* lds, Sync sync) {
-        ntt_round<LOGE, S, GLR, GLC>(P, SH, ROUND == 0, tile, tid, lds);
+    SC_HD static void run(const PassParams& P, uint32_t tile, uint32_t tid, Fe* lds, Sync sync, const Fe* tw) {
+        ntt_round<LOGE, S, GLR, GLC>(P, SH, ROUND == 0, tile, tid, lds, tw);
         if constexpr (ROUND + 1 < NR) {
             sync();
-            FixedRounds<LOGE, GLR, GLC, ROUND + 1>::run(P, tile, tid, lds, sync);
+            FixedRounds<LOGE, GLR, GLC, ROUND + 1>::run(P, tile, tid, lds, sync, tw);
         }
     }
 };

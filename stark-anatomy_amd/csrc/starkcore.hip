@@ -30,13 +30,16 @@ __global__ void __launch_bounds__(PassThreads<LOGE>::value) ntt_pass_kernel(cons
     // that neighbouring tiles (which share twiddle rows and adjacent memory) stay within one L2.
     uint32_t tile = blockIdx.x;
     if (xcd_remap) tile = (blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3);
+    Fe* tw = lds + (1u << (P.logR + P.logC));
+    tile_twiddles_to_lds(P, P.logR, threadIdx.x, blockDim.x, tw);
+    __syncthreads();
     // same schedule as make_rounds() (short round first), computed inline to keep it in SGPRs
     const int nrounds = (P.logR + LOGE - 1) / LOGE;
     int sh = P.logR;
     for (int r = 0; r < nrounds; ++r) {
         const int s = (r == 0) ? (P.logR - LOGE * (nrounds - 1)) : LOGE;
         sh -= s;
-        ntt_round_dispatch<LOGE>(P, s, sh, r == 0, tile, threadIdx.x, lds);
+        ntt_round_dispatch<LOGE>(P, s, sh, r == 0, tile, threadIdx.x, lds, tw);
         if (r + 1 < nrounds) __syncthreads();
     }
 }
@@ -48,7 +51,10 @@ __global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed
     Fe* lds = reinterpret_cast<Fe*>(smem_raw);
     uint32_t tile = blockIdx.x;
     if (xcd_remap) tile = (blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3);
-    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, [] { __syncthreads(); });
+    Fe* tw = lds + (1u << (GLR + GLC));
+    tile_twiddles_to_lds(P, GLR, threadIdx.x, blockDim.x, tw);
+    __syncthreads();
+    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, [] { __syncthreads(); }, tw);
 }
 
 __global__ void __launch_bounds__(256) pow_table_kernel(Fe* out, uint64_t count, Fe base_m, uint64_t step, Fe scale_m) {

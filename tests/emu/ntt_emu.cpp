@@ -18,20 +18,24 @@ static void fill_table(std::vector<Fe>& t, uint64_t count, Fe base_m, uint64_t s
 // geometry-specialised path (FixedRounds): on the CPU each round must finish for all threads before the next starts,
 // so the per-round bodies are invoked directly with the same compile-time schedule the kernel unrolls
 template <int LOGE, int GLR, int GLC, int ROUND = 0>
-static void run_fixed_rounds(const NttPassDesc& pd, uint32_t tile, Fe* lds) {
+static void run_fixed_rounds(const NttPassDesc& pd, uint32_t tile, Fe* lds, const Fe* tw) {
     using FR = FixedRounds<LOGE, GLR, GLC, ROUND>;
-    for (uint32_t tid = 0; tid < pd.threads; ++tid) ntt_round<LOGE, FR::S, GLR, GLC>(pd.p, FR::SH, ROUND == 0, tile, tid, lds);
-    if constexpr (ROUND + 1 < FR::NR) run_fixed_rounds<LOGE, GLR, GLC, ROUND + 1>(pd, tile, lds);
+    for (uint32_t tid = 0; tid < pd.threads; ++tid) ntt_round<LOGE, FR::S, GLR, GLC>(pd.p, FR::SH, ROUND == 0, tile, tid, lds, tw);
+    if constexpr (ROUND + 1 < FR::NR) run_fixed_rounds<LOGE, GLR, GLC, ROUND + 1>(pd, tile, lds, tw);
 }
 
 template <int LOGE>
 static void run_pass(const NttPassDesc& pd) {
     const PassParams& P = pd.p;
-    std::vector<Fe> lds((size_t)1 << (P.logR + P.logC));
+    // LDS exactly as the kernel lays it out: the tile, then the staged twiddles (pd.lds_bytes covers both)
+    std::vector<Fe> lds(pd.lds_bytes / sizeof(Fe));
+    if (lds.size() < ((size_t)1 << (P.logR + P.logC)) + (P.logR > 0 ? ((size_t)1 << (P.logR - 1)) : 0)) abort();
+    Fe* tw = lds.data() + ((size_t)1 << (P.logR + P.logC));
+    for (uint32_t tid = 0; tid < pd.threads; ++tid) tile_twiddles_to_lds(P, P.logR, tid, pd.threads, tw);
     if constexpr (LOGE == 2) {
 #define EMU_FIXED(LR, LC)                                                                                   \
         if (P.logR == LR && P.logC == LC) {                                                                 \
-            for (uint32_t tile = 0; tile < pd.ntiles; ++tile) run_fixed_rounds<2, LR, LC>(pd, tile, lds.data()); \
+            for (uint32_t tile = 0; tile < pd.ntiles; ++tile) run_fixed_rounds<2, LR, LC>(pd, tile, lds.data(), tw); \
             return;                                                                                         \
         }
         EMU_FIXED(8, 3) EMU_FIXED(7, 4) EMU_FIXED(10, 2) EMU_FIXED(6, 5) EMU_FIXED(9, 3) EMU_FIXED(8, 4)
@@ -41,7 +45,7 @@ static void run_pass(const NttPassDesc& pd) {
     for (uint32_t tile = 0; tile < pd.ntiles; ++tile)
         for (int r = 0; r < rs.nrounds; ++r)
             for (uint32_t tid = 0; tid < pd.threads; ++tid)
-                ntt_round_dispatch<LOGE>(P, rs.s[r], rs.sh[r], r == 0, tile, tid, lds.data());
+                ntt_round_dispatch<LOGE>(P, rs.s[r], rs.sh[r], r == 0, tile, tid, lds.data(), tw);
 }
 
 extern "C" int emu_ntt(const uint64_t* in, uint64_t* out, int logn, const uint64_t* root, int inverse, uint64_t in_limit,
