@@ -204,6 +204,9 @@ struct BatchExtras {
     const Fe* outer_th = nullptr;
     uint64_t outer_col_base = 0;
     int chunks_log = 0;
+    // direct table of the inter-pass twiddles of a two-pass plan: [k < 2^digits[0]][b < len >> digits[0]] = w_len^(b*k)
+    // (one coalesced load + one modmul per element instead of the two-level lookup's two loads + two modmuls)
+    const Fe* inner_twd = nullptr;
 };
 
 inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, const NttTables& tb,
@@ -265,6 +268,7 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
             p.tw_col_shift = logbatch;
             p.tw_scale = 1ull << logA;
             p.tw_row_k = 1;
+            if (!lastp && ex.inner_twd) { p.twd = ex.inner_twd; p.twd_stride = 1ull << logBlow; }
             if (lastp && ex.outer_tl) {
                 // fused outer twiddle: natural output row = t_mid + N_1 * k (two passes) or k (one pass); column = local column
                 p.tw_enable = 1;
@@ -302,6 +306,7 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
             p.tw_enable = 1;
             p.tw_scale = 1;
             p.tw_row_k = 1;
+            if (ex.inner_twd) { p.twd = ex.inner_twd; p.twd_stride = 1ull << logB; }
             pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
         } else {
             // rows, last digit: C adjacent batch rows x R contiguous; output [k][batch row], k = k_1 + N_1 * k_2

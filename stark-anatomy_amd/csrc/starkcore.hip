@@ -229,6 +229,9 @@ struct PlanTables {      // power tables of one root of order n = 2^logn
     Fe* twd[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     int twd_digits[4] = {0, 0, 0, 0};
     int twd_passes = 0;
+    // direct inter-pass table of the two-pass BATCHED plans of this length (first digit twd_b_digit0)
+    Fe* twd_b = nullptr;
+    int twd_b_digit0 = 0;
 };
 struct PowKey {
     uint64_t lo, hi, hi_count;
@@ -373,6 +376,7 @@ void free_plans() {
         hipFree(kv.second.mt); hipFree(kv.second.tl); hipFree(kv.second.th);
         if (kv.second.th_ninv) hipFree(kv.second.th_ninv);
         for (int v = 0; v < 2; ++v) for (int i = 0; i < 4; ++i) if (kv.second.twd[v][i]) hipFree(kv.second.twd[v][i]);
+        if (kv.second.twd_b) hipFree(kv.second.twd_b);
     }
     g.plans.clear();
     for (auto& kv : g.pows) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
@@ -424,6 +428,30 @@ int get_pow(Fe base, uint64_t count, hipStream_t st, PowTables** out) {
         it = g.pows.emplace(key, t).first;
     }
     *out = &it->second;
+    return SC_OK;
+}
+
+// plan a batched transform; two-pass plans get the direct inter-pass twiddle table (built once per (root, length, split))
+int plan_batched_direct(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, PlanTables* pt, const Fe* in, Fe* work, Fe* out, BatchExtras ex, hipStream_t st, bool* ok) {
+    NttTables tb;
+    tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
+    *ok = plan_batched(d, kind, loglen, logbatch, tb, in, work, out, g.tuning, ex);
+    if (!*ok || d.npasses != 2 || loglen > g.tuning.direct_tw_max_log || g.tuning.direct_tw_max_log <= 0) return SC_OK;
+    if (pt->twd_b && pt->twd_b_digit0 != d.digits[0]) {
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(pt->twd_b);
+        pt->twd_b = nullptr;
+    }
+    if (!pt->twd_b) {
+        const uint64_t count = 1ull << loglen;
+        HIPCHK(hipMalloc((void**)&pt->twd_b, count * sizeof(Fe)));
+        hipLaunchKernelGGL(twiddle_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, pt->twd_b, loglen - d.digits[0], count, (uint64_t)1, pt->tl, pt->th);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        pt->twd_b_digit0 = d.digits[0];
+    }
+    ex.inner_twd = pt->twd_b;
+    *ok = plan_batched(d, kind, loglen, logbatch, tb, in, work, out, g.tuning, ex);
     return SC_OK;
 }
 
@@ -688,12 +716,12 @@ int ntt_cols(const Fe* in, Fe* out, int loglen, int logbatch, bool inverse, hipS
     if (logbatch == 0) return ntt_device(in, out, loglen, rt, false, NttOpts(), st);
     PlanTables* pt;
     SCCHK(get_plan(rt, loglen, false, st, &pt));
-    NttTables tb;
-    tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
     void* w;
     SCCHK(scratch(0, len * B * sizeof(Fe), &w));
     NttPlanDesc d;
-    if (plan_batched(d, BATCH_COLS, loglen, logbatch, tb, in, (Fe*)w, out, g.tuning)) return run_plan(d, st);
+    bool planned = false;
+    SCCHK(plan_batched_direct(d, BATCH_COLS, loglen, logbatch, pt, in, (Fe*)w, out, BatchExtras(), st, &planned));
+    if (planned) return run_plan(d, st);
     // columns longer than the batched plans take (only the top few levels of a big tree, a handful of columns each)
     void *a, *b;
     SCCHK(scratch(1, len * sizeof(Fe), &a));
@@ -1087,8 +1115,9 @@ int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t ba
     void* w;
     SCCHK(scratch(0, len * batch * sizeof(Fe), &w));
     NttPlanDesc d;
-    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)d_in, (Fe*)w, (Fe*)d_out, g.tuning, ex))
-        return fail(SC_ERR_UNSUPPORTED, "unsupported batched transform shape");
+    bool planned = false;
+    SCCHK(plan_batched_direct(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, pt, (const Fe*)d_in, (Fe*)w, (Fe*)d_out, ex, st, &planned));
+    if (!planned) return fail(SC_ERR_UNSUPPORTED, "unsupported batched transform shape");
     if (d.npasses == 2 && kind == 0 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "two-pass column transform must be out of place");
     if (kind == 1 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "transposing row transform must be out of place");
     return run_plan(d, st);

@@ -123,7 +123,7 @@ extern "C" void emu_field(const uint64_t* a, const uint64_t* b, uint64_t* out /*
 // batched transforms (multi-GPU building blocks): kind 0 = columns of [len][batch], kind 1 = rows of [batch][len] -> [len][batch]
 extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,
                                int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log,
-                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log) {
+                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log, int inner_direct) {
     const uint64_t len = 1ull << loglen, batch = 1ull << logbatch;
     Fe r_m = to_mont(Fe{root[0], root[1]});
     NttTuning tu;
@@ -149,6 +149,15 @@ extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int 
     }
     NttPlanDesc d;
     if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu, ex)) return -1;
+    std::vector<Fe> itw;
+    if (inner_direct && d.npasses == 2) {
+        // the library's direct inter-pass table (twiddle_table_kernel): [k][b] = w^(b*k), B = len >> digits[0]
+        const int logB = loglen - d.digits[0];
+        itw.resize(len);
+        for (uint64_t i = 0; i < len; ++i) itw[i] = pow2level(tb.tl, tb.th, (i & ((1ull << logB) - 1)) * (i >> logB));
+        ex.inner_twd = itw.data();
+        if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu, ex)) return -1;
+    }
     for (int i = 0; i < d.npasses; ++i) {
         switch (d.pass[i].loge) {
             case 1: run_pass<1>(d.pass[i]); break;

@@ -139,15 +139,16 @@ def test_emu_batched(emu, cfg):
     kind, loglen, logbatch, tile, loge, min_tiles, max_col, digit = cfg
     emu.emu_ntt_batched.restype = ctypes.c_int
     emu.emu_ntt_batched.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5 + \
-        [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     total = 1 << (loglen + logbatch)
     data = synth.synth_packed(900 + loglen + 7 * kind, total).tobytes()
     root = po.primitive_nth_root(1 << loglen)
     out = ctypes.create_string_buffer(16 * total)
-    rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, None, 0, 0, 0, 0)
-    assert rc > 0, rc
     expect = _batched_expect(data, kind, loglen, logbatch, root)
-    assert out.raw == expect, cfg
+    for inner_direct in (0, 1):                     # inter-pass twiddles by two-level lookup / from the direct table
+        rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, None, 0, 0, 0, 0, inner_direct)
+        assert rc > 0, rc
+        assert out.raw == expect, (cfg, inner_direct)
     import numpy as np
     ln, bt = 1 << loglen, 1 << logbatch
     if kind == 0:
@@ -156,7 +157,7 @@ def test_emu_batched(emu, cfg):
         w = po.primitive_nth_root(1 << ologn)
         for col_base, ninv in ((0, 0), (bt * 3, 1)):
             rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit,
-                                     w.to_bytes(16, "little"), ologn, col_base, ninv, 0)
+                                     w.to_bytes(16, "little"), ologn, col_base, ninv, 0, col_base & 1 or ninv)
             assert rc > 0
             ints = synth.unpack_ints(expect)
             sc_ = pow(1 << ologn, P - 2, P) if ninv else 1
@@ -171,6 +172,6 @@ def test_emu_batched(emu, cfg):
             ch = 1 << chunks_log
             a = np.frombuffer(data, dtype=np.uint64).reshape(bt, ch, ln // ch, 2)
             chunked = np.ascontiguousarray(a.transpose(1, 0, 2, 3)).tobytes()
-            rc = emu.emu_ntt_batched(chunked, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, None, 0, 0, 0, chunks_log)
+            rc = emu.emu_ntt_batched(chunked, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, None, 0, 0, 0, chunks_log, chunks_log & 1)
             assert rc > 0, (cfg, chunks_log)
             assert out.raw == expect, (cfg, chunks_log)
