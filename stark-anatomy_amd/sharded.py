@@ -292,6 +292,16 @@ class HipFriEngine:
         self.sc.synchronize()
         return dst
 
+    def lde(self, coeffs, offset, generator, order):
+        """fast_coset_evaluate (code/ntt.py:132-135) of packed coefficients (bytes) -> device tensor [order][2]"""
+        m = len(coeffs) // 16
+        src = self.sc.DeviceVector.from_bytes(coeffs) if m else self.sc.DeviceVector(1)
+        out = torch.empty((order, 2), dtype=torch.int64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        self.sc._check(self.lib.sc_coset_evaluate_dev(src.ptr, m, _fe(offset), _fe(generator), order, out.data_ptr(), None))
+        self.sc.synchronize()
+        return out
+
     def read(self, elems, flat_indices):
         """values (Python ints) of elems.view(-1, 2)[flat_indices]"""
         if len(flat_indices) == 0:
@@ -451,3 +461,37 @@ class ShardedFri:
                 proof_stream.push(paths[s + t])
                 proof_stream.push(next_paths[c_at + t])
         return top_level_indices
+
+
+# =====================================================================================================================
+# Independent columns: one register per GPU
+# =====================================================================================================================
+class ColumnReplicas:
+    """SURVEY.md 8(e), last row: the registers of a STARK (fast_stark.py:103-105, :113: one `fast_coset_evaluate` + one
+    `Merkle.commit` per trace / quotient column) are independent units.  When the domain is too small to be worth sharding,
+    column i goes to rank i % world: no element ever crosses a link, only the 64-byte roots are all-gathered (every rank
+    needs all of them, in column order, for the Fiat-Shamir transcript)."""
+
+    def __init__(self, rank, world, device, engine=None, group=None):
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.engine = engine if engine is not None else HipFriEngine(device)
+
+    def lde_and_commit(self, columns, offset, generator, order):
+        """columns: list of packed coefficient lists (bytes), identical on every rank.
+        Returns (mine, roots): mine = {column index: (codeword tensor, tree)} for this rank's columns; roots = the Merkle
+        roots of ALL columns in column order."""
+        mine = {}
+        for i, coeffs in enumerate(columns):
+            if i % self.world == self.rank:
+                codeword = self.engine.lde(coeffs, offset, generator, order)
+                mine[i] = (codeword, self.engine.tree(codeword))
+        local = {i: t.root for i, (_, t) in mine.items()}
+        if self.world == 1:
+            gathered = [local]
+        else:
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, local, group=self.group)
+        roots = {}
+        for part in gathered:
+            roots.update(part)
+        return mine, [roots[i] for i in range(len(columns))]

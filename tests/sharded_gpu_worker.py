@@ -93,6 +93,14 @@ def fri_check(rank, world, dev):
             if not good:
                 print("rank", rank, "FRI MISMATCH logN", logN, "R", R, flush=True)
             ok &= good
+    # independent columns, one register per rank (HIP LDE + Merkle commit), roots gathered in column order
+    from sharded import ColumnReplicas
+    order = 1 << 12
+    gen = po.primitive_nth_root(order)
+    cols = [synth.synth_packed(50 + i, 1000 + i).tobytes() for i in range(5)]
+    mine, roots = ColumnReplicas(rank, world, dev).lde_and_commit(cols, po.GENERATOR, gen, order)
+    want = [po.C.merkle_commit(po.C.coset_evaluate(c, len(c) // 16, po.GENERATOR, gen, order), order) for c in cols]
+    ok &= roots == want and sorted(mine) == [i for i in range(5) if i % world == rank]
     return ok
 
 

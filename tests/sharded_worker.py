@@ -123,6 +123,10 @@ class OracleFriEngine:
             allb.append(b"".join(level))
         return OracleFriEngine._Tree(b"".join(allb), n)
 
+    def lde(self, coeffs, offset, generator, order):
+        raw = po.C.coset_evaluate(coeffs, len(coeffs) // 16, offset, generator, order)
+        return torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(order, 2).copy())
+
     def read(self, elems, flat_indices):
         a = elems.contiguous().numpy().view(np.uint64).reshape(-1, 2)
         return [int(a[i, 0]) | (int(a[i, 1]) << 64) for i in flat_indices]
@@ -181,6 +185,14 @@ def fri_main():
             if not good:
                 print("rank", rank, "MISMATCH logN", logN, "R", R, top == rec["top_level_indices"], len(ser), rec["serialized_len"], flush=True)
             ok &= good
+    # independent columns: one register per rank, roots gathered in column order
+    from sharded import ColumnReplicas
+    order = 256
+    gen = po.primitive_nth_root(order)
+    cols = [synth.synth_packed(50 + i, 40 + i).tobytes() for i in range(5)]
+    mine, roots = ColumnReplicas(rank, world, torch.device("cpu"), engine=OracleFriEngine()).lde_and_commit(cols, po.GENERATOR, gen, order)
+    want = [po.C.merkle_commit(po.C.coset_evaluate(c, len(c) // 16, po.GENERATOR, gen, order), order) for c in cols]
+    ok &= roots == want and sorted(mine) == [i for i in range(5) if i % world == rank]
     dist.barrier()
     dist.destroy_process_group()
     if not ok:
