@@ -109,7 +109,10 @@ def _device_tree(domain):
     key = _pack(domain)
     tree = _tree_memo.get(key)
     if tree is None:
-        if len(_tree_memo) >= 8:
+        # a tree keeps ~1 KiB of HBM per point (all levels and their transforms): bound what the memo retains
+        if len(_tree_memo) >= 8 or sum(t.k for t in _tree_memo.values()) + len(domain) > (1 << 22):
+            for t in _tree_memo.values():
+                t.free()
             _tree_memo.clear()
         tree = _tree_memo[key] = _sc.PolyTree(key)
     return tree
