@@ -46,8 +46,13 @@ const char* sc_last_error(void);
 int sc_synchronize(void);              /* wait for the library stream */
 /* tuning knobs for experiments (defaults are the measured optimum; -1 = choose by size where applicable): key in
  * {"max_tile_log","loge","max_col_log","min_tiles_log","single_pass_max_log","max_digit_log","direct_tw_max_log",
- *  "xcd_remap","fixed_shapes","merkle_big_nlev"}.  Plans are re-derived on the next call; results never depend on the tuning. */
+ *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","tw_on_load"}.  Plans are re-derived on the next call; results
+ * never depend on the tuning. */
 int sc_set_tuning(const char* key, int value);
+/* diagnostics (tools/pass_trace.py): while d_buf != NULL every geometry-specialised NTT pass launch writes 16 u64 per wave
+ * (s_memtime at the phase boundaries of its workgroup; slot 15 = s_memrealtime at entry) to d_buf[(block*waves + wave)*16 ..];
+ * the caller sizes the buffer for the launch it traces and passes NULL afterwards. */
+int sc_debug_trace(void* d_buf);
 
 /* diagnostics: out[i] = op(a[i], b[i]) computed by the device field routines the kernels use.
  * op 0: a*b*2^-128 (Montgomery product, b < p), 1: a+b, 2: a-b, 3: a*b, 4: a/2, 5: a^-1, 6: portable Montgomery product */

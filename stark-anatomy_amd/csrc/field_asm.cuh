@@ -11,10 +11,10 @@
 //               64-bit addend of its first v_mad (which cannot overflow), so no carry ever needs propagating
 //   merge     : T = E + (O << 32): one 7-step v_addc chain
 //   reduction : p = 1 + 407*2^119  =>  p^-1 = 1 - 407*2^119 (mod 2^128), so with x = (T_lo*407) mod 2^9
-//               m = x*2^119 - T_lo (mod 2^128)   [borrow beta]
-//               (T + m*p) / 2^128 = T_hi + ((m*PHc + K) >> 32) + beta,   PHc = 407*2^23, K = 511*2^23
-//               -- a 4-step v_mad chain, no shifts
-//   final     : conditional subtraction of p on (carry | R >= p)
+//               m' = T_lo * p^-1 = T_lo - x*2^119 (mod 2^128): T_lo with x subtracted from its top 9 bits [borrow delta]
+//               (T - m'*p) / 2^128 = T_hi - (m'*PH >> 32) - delta,   PH = 407*2^23   (exact: m'*PH = x*2^23 mod 2^32)
+//               -- a 4-step v_mad chain whose first low word is x*2^23 itself, then one 4-limb subtraction
+//   final     : the result lies in (-p, p): add p back where the subtraction borrowed (5 instructions)
 //
 // Hazard: a VALU that writes an SGPR pair (carry-out) needs 2 wait states before a VALU reads it as
 // carry-in / select mask; hipcc does not look inside asm, so every consumer carries its own `s_nop 1`.
@@ -144,25 +144,27 @@ __device__ __forceinline__ Fe mont_mul_asm(Fe a, Fe b) {
     uint32_t t5 = a_addc(hi32(E2), lo32(O2), c, c);
     uint32_t t6 = a_addc(lo32(E3), hi32(O2), c, c);
     uint32_t t7 = a_addc_last(hi32(E3), nO2, c);
-    // ---- reduction: m = x*2^119 - T_lo, beta = borrow
-    const uint32_t x = (((t0 & 511u) * 407u) & 511u) << 23;
-    smask_t bw;
-    uint32_t m0 = a_sub_co(0u, t0, bw);
-    uint32_t m1 = a_negb(t1, bw, bw);
-    uint32_t m2 = a_negb(t2, bw, bw);
-    uint32_t m3 = a_subb(x, t3, bw, bw);           // bw = beta
-    // U = (m * PHc + K) >> 32
+    // ---- reduction (subtractive form): m' = T_lo * p^-1 mod 2^128 = T_lo - x*2^119 (mod 2^128) -- only the top limb of
+    // T_lo changes -- and  T * 2^-128 = T_hi - (floor(m' * PH / 2^32) + delta)  in (-p, p),  PH = 407 * 2^23,
+    // delta = borrow of the top-limb subtraction; the low word of t0 * PH IS x * 2^23, so x costs nothing.
     const uint32_t PHc = PH3;                       // 407 * 2^23
-    uint64_t s0 = a_mad(m0, PHc, (uint64_t)(511u << 23));
-    uint64_t s1 = a_mad(m1, PHc, (uint64_t)hi32(s0));
-    uint64_t s2 = a_mad(m2, PHc, (uint64_t)hi32(s1));
+    uint64_t s0 = a_mad(t0, PHc, 0);
+    smask_t bw;
+    uint32_t m3 = a_sub_co(t3, lo32(s0), bw);      // bw = delta
+    uint64_t s1 = a_mad(t1, PHc, (uint64_t)hi32(s0));
+    uint64_t s2 = a_mad(t2, PHc, (uint64_t)hi32(s1));
     uint64_t s3 = a_mad(m3, PHc, (uint64_t)hi32(s2));
-    // R = T_hi + U + beta
-    uint32_t r0 = a_addc(t4, lo32(s1), bw, c);
-    uint32_t r1 = a_addc(t5, lo32(s2), c, c);
-    uint32_t r2 = a_addc(t6, lo32(s3), c, c);
-    uint32_t r3 = a_addc(t7, hi32(s3), c, c);
-    return a_cond_sub_p(r0, r1, r2, r3, c);
+    // R = T_hi - Q - delta; negative -> add p back (same tail as fe_sub)
+    uint32_t r0 = a_subb(t4, lo32(s1), bw, bw);
+    uint32_t r1 = a_subb(t5, lo32(s2), bw, bw);
+    uint32_t r2 = a_subb(t6, lo32(s3), bw, bw);
+    uint32_t r3 = a_subb(t7, hi32(s3), bw, bw);
+    uint32_t ph = a_cnd(0u, PH3, bw);
+    uint32_t o0 = a_addc(r0, 0u, bw, c);
+    uint32_t o1 = a_addc(r1, 0u, c, c);
+    uint32_t o2 = a_addc(r2, 0u, c, c);
+    uint32_t o3 = a_addc_last(r3, ph, c);
+    return Fe{((uint64_t)o1 << 32) | o0, ((uint64_t)o3 << 32) | o2};
 }
 
 __device__ __forceinline__ Fe fe_add_asm(Fe a, Fe b) {

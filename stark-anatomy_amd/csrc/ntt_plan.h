@@ -16,6 +16,7 @@ struct NttTuning {
     int single_pass_max_log = 11;
     int max_digit_log = -1;  // passes = ceil(logn / max_digit_log)
     int direct_tw_max_log = 22;  // direct four-step twiddle tables up to 2^this entries per pass (bigger ones cost more HBM than they save)
+    int tw_on_load = 1;          // a pass whose predecessor has a direct table applies that table on LOAD (see PassParams::twd_in)
 };
 
 inline NttTuning resolve_tuning(const NttTuning& in, int logn) {
@@ -182,6 +183,21 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
         pd.threads = 1u << (logT - loge);
         pd.lds_bytes = ((uint32_t)sizeof(Fe) << logT) + tile_twiddle_bytes(pd.p.logR);   // the tile, then its twiddles
         logA += logR;
+    }
+    if (tu.tw_on_load) {
+        // twiddle-on-load: the table of pass i-1 is indexed like the work buffer it wrote (index mod R*B), so pass i can fetch
+        // it with the same addresses as its data
+        int logAi = 0;
+        for (int i = 0; i + 1 < m; ++i) {
+            const int logR = d.digits[i], logB = logn - logAi - logR;
+            if (tb.twd[i]) {
+                d.pass[i].p.tw_enable = 0;
+                d.pass[i].p.twd = nullptr;
+                d.pass[i + 1].p.twd_in = tb.twd[i];
+                d.pass[i + 1].p.twd_in_mask = (1ull << (logR + logB)) - 1;
+            }
+            logAi += logR;
+        }
     }
     return true;
 }

@@ -53,6 +53,11 @@ struct PassParams {
     // laid out like the pass's output tile, so the load coalesces exactly like the store (nullptr = two-level lookup)
     const Fe* twd;
     uint64_t twd_stride;
+    // the SAME four-step twiddles applied by the NEXT pass on load instead (twd_in[j & twd_in_mask], j = memory index of the
+    // element in the work buffer): the loads go out together with the data loads at the start of the workgroup, where the
+    // latency is paid anyway, instead of sitting between the last butterfly and the store of the producing pass
+    const Fe* twd_in;
+    uint64_t twd_in_mask;
     // final constant multiply (Montgomery form), e.g. n^-1 for a single-pass inverse transform
     int scale_enable;
     Fe scale;
@@ -61,6 +66,8 @@ struct PassParams {
     int coset_enable;          // x[j] *= offset^j (Polynomial.scale, univariate.py:153-154): ol[j & 4095] * oh[j >> 12]
     const Fe* ol;
     const Fe* oh;
+    // diagnostics (tools/pass_trace.py): per-wave s_memtime stamps of the phases of a workgroup; nullptr in production
+    unsigned long long* trace;
 };
 
 SC_HD uint32_t bitrev32(uint32_t x, int bits) {
@@ -93,94 +100,121 @@ SC_HD Fe pow_table_entry(Fe base_m, uint64_t i, uint64_t step, Fe scale_m) {
     return mont_mul(mont_pow(base_m, i * step), scale_m);   // (x~ * s~) R^-1 = (x s)~
 }
 
-// One round of one workgroup's tile, for thread `tid`: S radix-2 DIF stages on row bits [sh, sh+S).
+// One round of one workgroup's tile, for thread `tid`: S radix-2 DIF stages on row bits [sh, sh+S), in three steps the
+// kernel can place separately (the geometry-specialised kernel issues the first round's global loads before it stages the
+// tile twiddles, so both latencies overlap): round_gather -> round_butterflies -> round_scatter.
 // GLR / GLC >= 0 fix the tile geometry at compile time (the hot shapes get their own kernel instantiation: all the
 // index math below then folds into immediates); -1 = read it from P.
-// tw: the tile transform's twiddles w_R^i, i < R/2, staged in LDS by the kernel (tile_twiddles_to_lds).
 template <int LOGE, int S, int GLR = -1, int GLC = -1>
-SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds, const Fe* tw) {
-    constexpr int E = 1 << LOGE;
-    constexpr int F = 1 << S;          // elements per butterfly group
-    const int logR = (GLR >= 0) ? GLR : P.logR, logC = (GLC >= 0) ? GLC : P.logC;
-    const uint32_t T = 1u << (logR + logC - LOGE);   // threads per workgroup
-    const bool last = (sh == 0);
+struct Round {
+    static constexpr int E = 1 << LOGE;
+    static constexpr int F = 1 << S;          // elements per butterfly group
+    static constexpr int G = E >> S;          // groups per thread
+    uint32_t rr[G];   // per group: row bits outside the field, packed (rrem)
+    uint32_t cc[G];   // per group: column
+    uint32_t t_lo, t_mid, t_hi;
+    int logR, logC;
 
-    const uint32_t t_lo = tile & ((1u << P.lo_log) - 1u);
-    const uint32_t t_mid = (tile >> P.lo_log) & ((1u << P.mid_log) - 1u);
-    const uint32_t t_hi = tile >> (P.lo_log + P.mid_log);
-
-    Fe x[E];
-    uint32_t rr[E >> S];   // per group: row bits outside the field, packed (rrem)
-    uint32_t cc[E >> S];   // per group: column
-
+    SC_HD void setup(const PassParams& P, bool first, uint32_t tile, uint32_t tid) {
+        logR = (GLR >= 0) ? GLR : P.logR;
+        logC = (GLC >= 0) ? GLC : P.logC;
+        const uint32_t T = 1u << (logR + logC - LOGE);   // threads per workgroup
+        t_lo = tile & ((1u << P.lo_log) - 1u);
+        t_mid = (tile >> P.lo_log) & ((1u << P.mid_log) - 1u);
+        t_hi = tile >> (P.lo_log + P.mid_log);
 #pragma unroll
-    for (int g = 0; g < (E >> S); ++g) {
-        uint32_t rem = (uint32_t)g * T + tid;      // < 2^(logR+logC-S)
-        uint32_t rrem, c;
-        if (first && P.rfast_load) {
-            rrem = rem & ((1u << (logR - S)) - 1u);
-            c = rem >> (logR - S);
-        } else {
-            c = rem & ((1u << logC) - 1u);
-            rrem = rem >> logC;
-        }
-        rr[g] = rrem;
-        cc[g] = c;
-    }
-
-    // ---- gather
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-        const int g = i >> S, fi = i & (F - 1);
-        const uint32_t rrem = rr[g], c = cc[g];
-        const uint32_t r = ((rrem >> sh) << (sh + S)) | ((uint32_t)fi << sh) | (rrem & ((1u << sh) - 1u));
-        if (first) {
-            uint64_t j = (uint64_t)t_hi * P.in_hi + (uint64_t)t_mid * P.in_mid + (uint64_t)t_lo * P.in_lo + (uint64_t)c * P.in_cs;
-            if (P.in_split) j += (uint64_t)(r & ((1u << P.in_split) - 1u)) * P.in_rs + (uint64_t)(r >> P.in_split) * P.in_rs_hi;
-            else j += (uint64_t)r * P.in_rs;
-            Fe v = fe_zero();
-            if (j < P.in_limit) {
-                v = P.in[j];
-                if (P.coset_enable) v = mont_mul(v, pow2level(P.ol, P.oh, j));
-            }
-            x[i] = v;
-        } else {
-            x[i] = lds[lds_index(r, c, logC)];
-        }
-    }
-
-    // ---- S radix-2 DIF stages on the field bits, highest bit first
-#pragma unroll
-    for (int q = 0; q < S; ++q) {
-        const int bit = S - 1 - q;          // field bit
-        const int b = sh + bit;             // row bit
-        const int tau = logR - 1 - b;       // twiddle exponent scale: w_R^(2^tau * (r mod 2^b))
-#pragma unroll
-        for (int i0 = 0; i0 < E; ++i0) {
-            if (i0 & (1 << bit)) continue;
-            const int i1 = i0 | (1 << bit);
-            const int g = i0 >> S;
-            const uint32_t fi_low = (uint32_t)(i0 & (F - 1)) & ((1u << bit) - 1u);
-            Fe u = x[i0], v = x[i1];
-            x[i0] = fe_add(u, v);
-            Fe d = fe_sub(u, v);
-            if (b == 0 || (last && fi_low == 0)) {
-                x[i1] = d;                  // twiddle is w^0 = 1
+        for (int g = 0; g < G; ++g) {
+            uint32_t rem = (uint32_t)g * T + tid;      // < 2^(logR+logC-S)
+            uint32_t rrem, c;
+            if (first && P.rfast_load) {
+                rrem = rem & ((1u << (logR - S)) - 1u);
+                c = rem >> (logR - S);
             } else {
-                const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
-                const uint32_t e = ((fi_low << sh) | row_lo) << tau;     // < R/2
-                x[i1] = mont_mul(d, tw[e]);
+                c = rem & ((1u << logC) - 1u);
+                rrem = rem >> logC;
+            }
+            rr[g] = rrem;
+            cc[g] = c;
+        }
+    }
+    SC_HD uint32_t row(int i, int sh) const {
+        const int g = i >> S, fi = i & (F - 1);
+        const uint32_t rrem = rr[g];
+        return ((rrem >> sh) << (sh + S)) | ((uint32_t)fi << sh) | (rrem & ((1u << sh) - 1u));
+    }
+    // memory index of element i of the first round
+    SC_HD uint64_t in_index(const PassParams& P, int i, int sh) const {
+        const uint32_t r = row(i, sh), c = cc[i >> S];
+        uint64_t j = (uint64_t)t_hi * P.in_hi + (uint64_t)t_mid * P.in_mid + (uint64_t)t_lo * P.in_lo + (uint64_t)c * P.in_cs;
+        if (P.in_split) j += (uint64_t)(r & ((1u << P.in_split) - 1u)) * P.in_rs + (uint64_t)(r >> P.in_split) * P.in_rs_hi;
+        else j += (uint64_t)r * P.in_rs;
+        return j;
+    }
+    // first round: issue the global loads (data, and the previous pass's four-step twiddles when they are applied on load)
+    SC_HD void gather_global(const PassParams& P, int sh, Fe* x, Fe* tin) const {
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint64_t j = in_index(P, i, sh);
+            Fe v = fe_zero();
+            if (j < P.in_limit) v = P.in[j];
+            x[i] = v;
+            if (P.twd_in) tin[i] = P.twd_in[j & P.twd_in_mask];
+        }
+    }
+    // first round: the multiplications that belong to the load (coset scaling, twiddle-on-load)
+    SC_HD void finish_global(const PassParams& P, int sh, Fe* x, const Fe* tin) const {
+        if (P.coset_enable) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const uint64_t j = in_index(P, i, sh);
+                if (j < P.in_limit) x[i] = mont_mul(x[i], pow2level(P.ol, P.oh, j));
+            }
+        }
+        if (P.twd_in) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) x[i] = mont_mul(x[i], tin[i]);
+        }
+    }
+    SC_HD void gather_lds(int sh, Fe* x, const Fe* lds) const {
+#pragma unroll
+        for (int i = 0; i < E; ++i) x[i] = lds[lds_index(row(i, sh), cc[i >> S], logC)];
+    }
+    // S radix-2 DIF stages on the field bits, highest bit first; tw[e << tw_shift] = w_R^e (LDS copy: shift 0)
+    SC_HD void butterflies(int sh, Fe* x, const Fe* tw, int tw_shift) const {
+        const bool last = (sh == 0);
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            const int bit = S - 1 - q;          // field bit
+            const int b = sh + bit;             // row bit
+            const int tau = logR - 1 - b;       // twiddle exponent scale: w_R^(2^tau * (r mod 2^b))
+#pragma unroll
+            for (int i0 = 0; i0 < E; ++i0) {
+                if (i0 & (1 << bit)) continue;
+                const int i1 = i0 | (1 << bit);
+                const int g = i0 >> S;
+                const uint32_t fi_low = (uint32_t)(i0 & (F - 1)) & ((1u << bit) - 1u);
+                Fe u = x[i0], v = x[i1];
+                x[i0] = fe_add(u, v);
+                Fe d = fe_sub(u, v);
+                if (b == 0 || (last && fi_low == 0)) {
+                    x[i1] = d;                  // twiddle is w^0 = 1
+                } else {
+                    const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
+                    const uint32_t e = ((fi_low << sh) | row_lo) << tau;     // < R/2
+                    x[i1] = mont_mul(d, tw[(uint64_t)e << tw_shift]);
+                }
             }
         }
     }
-
-    // ---- scatter
+    SC_HD void scatter_lds(int sh, const Fe* x, Fe* lds) const {
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-        const int g = i >> S, fi = i & (F - 1);
-        const uint32_t rrem = rr[g], c = cc[g];
-        const uint32_t r = ((rrem >> sh) << (sh + S)) | ((uint32_t)fi << sh) | (rrem & ((1u << sh) - 1u));
-        if (last) {
+        for (int i = 0; i < E; ++i) lds[lds_index(row(i, sh), cc[i >> S], logC)] = x[i];
+    }
+    // last round (sh == 0): four-step twiddle (unless the next pass applies it on load), final scale, store
+    SC_HD void scatter_global(const PassParams& P, const Fe* x) const {
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t r = row(i, 0), c = cc[i >> S];
             const uint32_t k = bitrev32(r, logR);
             Fe v = x[i];
             if (P.tw_enable) {
@@ -195,10 +229,27 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
             if (P.scale_enable) v = mont_mul(v, P.scale);
             uint64_t j = (uint64_t)t_hi * P.out_hi + (uint64_t)t_mid * P.out_mid + (uint64_t)t_lo * P.out_lo + (uint64_t)k * P.out_rs + (uint64_t)c * P.out_cs;
             P.out[j] = v;
-        } else {
-            lds[lds_index(r, c, logC)] = x[i];
         }
     }
+};
+
+// the three steps in order (generic kernel and the CPU emulation)
+template <int LOGE, int S, int GLR = -1, int GLC = -1>
+SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uint32_t tid, Fe* lds, const Fe* tw) {
+    constexpr int E = 1 << LOGE;
+    Round<LOGE, S, GLR, GLC> R;
+    R.setup(P, first, tile, tid);
+    Fe x[E];
+    if (first) {
+        Fe tin[E];
+        R.gather_global(P, sh, x, tin);
+        R.finish_global(P, sh, x, tin);
+    } else {
+        R.gather_lds(sh, x, lds);
+    }
+    R.butterflies(sh, x, tw, 0);
+    if (sh == 0) R.scatter_global(P, x);
+    else R.scatter_lds(sh, x, lds);
 }
 
 // dispatch on the (runtime) number of stages in this round
@@ -220,20 +271,54 @@ SC_HD void tile_twiddles_to_lds(const PassParams& P, int logR, uint32_t tid, uin
 }
 
 // Fully unrolled round schedule for a compile-time geometry (short round first, like make_rounds()): every `sh` is a
-// constant, so row/LDS indices become base + immediate.  SYNC() is the workgroup barrier (no-op in the CPU emulation,
-// which runs one round for all threads at a time instead).
+// constant, so row/LDS indices become base + immediate.  The CPU emulation calls ntt_round() per round with the same
+// S / SH constants; the kernel uses run(), which differs only in WHEN things are issued and in how rounds are fenced:
+//
+//   * the first round's global loads (data, twiddle-on-load table) and the tile-twiddle staging loads are all issued
+//     before the first barrier, so the workgroup pays one memory latency, not three in a row;
+//   * threads that exchange elements between the round at shift SH and the next one differ only in the thread-id bits
+//     [SH - LOGE + GLC, SH + GLC) (derivation in DESIGN.md 3.1): once SH + GLC <= 6 every later exchange stays inside
+//     one 64-lane wave, each wave owns a closed set of LDS rows, and the workgroup barrier is replaced by a wave-level
+//     fence -- the waves of a workgroup then drift apart and overlap each other's LDS traffic, arithmetic and stores.
 template <int LOGE, int GLR, int GLC, int ROUND = 0>
 struct FixedRounds {
+    static constexpr int E = 1 << LOGE;
     static constexpr int NR = (GLR + LOGE - 1) / LOGE;
     static constexpr int S = (ROUND == 0) ? (GLR - LOGE * (NR - 1)) : LOGE;
     static constexpr int DONE = (ROUND == 0) ? 0 : (GLR - LOGE * (NR - 1)) + LOGE * (ROUND - 1);
     static constexpr int SH = GLR - DONE - S;
-    template <class Sync>
-    SC_HD static void run(const PassParams& P, uint32_t tile, uint32_t tid, Fe* lds, Sync sync, const Fe* tw) {
-        ntt_round<LOGE, S, GLR, GLC>(P, SH, ROUND == 0, tile, tid, lds, tw);
-        if constexpr (ROUND + 1 < NR) {
+    static constexpr bool NEXT_WAVE_LOCAL = (ROUND >= 1) && (SH + GLC <= 6);
+    static constexpr uint32_t TW_COUNT = 1u << (GLR - 1);     // tile twiddles; <= threads per workgroup for GLC >= 1
+
+    // sync(): workgroup barrier; wsync(): wave-level fence; stamp(i): diagnostics hook (no-op in production)
+    template <class Sync, class WSync, class Stamp>
+    SC_HD static void run(const PassParams& P, uint32_t tile, uint32_t tid, Fe* lds, Fe* tw, Sync sync, WSync wsync, Stamp stamp, bool wave_local) {
+        Round<LOGE, S, GLR, GLC> R;
+        R.setup(P, ROUND == 0, tile, tid);
+        Fe x[E];
+        if constexpr (ROUND == 0) {
+            Fe tin[E];
+            Fe twv = fe_zero();
+            if (tid < TW_COUNT) twv = P.mt[(uint64_t)tid << P.mt_shift];
+            R.gather_global(P, SH, x, tin);
+            if (tid < TW_COUNT) tw[tid] = twv;
+            stamp(1);
             sync();
-            FixedRounds<LOGE, GLR, GLC, ROUND + 1>::run(P, tile, tid, lds, sync, tw);
+            stamp(2);
+            R.finish_global(P, SH, x, tin);
+        } else {
+            R.gather_lds(SH, x, lds);
+        }
+        R.butterflies(SH, x, tw, 0);
+        stamp(3 + 2 * ROUND);
+        if constexpr (ROUND + 1 < NR) {
+            R.scatter_lds(SH, x, lds);
+            if (NEXT_WAVE_LOCAL && wave_local) wsync(); else sync();
+            stamp(4 + 2 * ROUND);
+            FixedRounds<LOGE, GLR, GLC, ROUND + 1>::run(P, tile, tid, lds, tw, sync, wsync, stamp, wave_local);
+        } else {
+            R.scatter_global(P, x);
+            stamp(4 + 2 * ROUND);
         }
     }
 };

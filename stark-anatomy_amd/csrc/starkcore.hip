@@ -44,17 +44,38 @@ __global__ void __launch_bounds__(PassThreads<LOGE>::value) ntt_pass_kernel(cons
     }
 }
 
-// the same kernel with the tile geometry fixed at compile time (hot shapes of the default plans)
-template <int LOGE, int GLR, int GLC>
-__global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed(const PassParams P, uint32_t ntiles, int xcd_remap) {
+// the same kernel with the tile geometry fixed at compile time (hot shapes of the default plans); see FixedRounds for what
+// it does differently (one memory latency per workgroup, wave-level fences once the exchanges stay inside a wave).
+// TRACE instantiations stamp s_memtime per wave at every phase boundary into P.trace (tools/pass_trace.py).
+constexpr int TRACE_STAMPS = 16;
+template <int LOGE, int GLR, int GLC, bool TRACE>
+__global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed(const PassParams P, uint32_t ntiles, int xcd_remap, int wave_local) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fe* lds = reinterpret_cast<Fe*>(smem_raw);
+    unsigned long long* trow = nullptr;
+    if constexpr (TRACE) {
+        if (P.trace) {
+            trow = P.trace + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TRACE_STAMPS;
+            if ((threadIdx.x & 63u) == 0) { trow[0] = __builtin_amdgcn_s_memtime(); trow[15] = __builtin_amdgcn_s_memrealtime(); }
+        }
+    }
     uint32_t tile = blockIdx.x;
     if (xcd_remap) tile = (blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3);
     Fe* tw = lds + (1u << (GLR + GLC));
-    tile_twiddles_to_lds(P, GLR, threadIdx.x, blockDim.x, tw);
-    __syncthreads();
-    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, [] { __syncthreads(); }, tw);
+    auto stamp = [&](int i) {
+        if constexpr (TRACE) {
+            if (trow) {
+                if (i == 2) __builtin_amdgcn_s_waitcnt(0);          // loads landed (trace only: separates latency from arithmetic)
+                if ((threadIdx.x & 63u) == 0 && i < 13) trow[i] = __builtin_amdgcn_s_memtime();
+            }
+        }
+    };
+    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, tw, [] { __syncthreads(); },
+                                     [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); },
+                                     stamp, wave_local != 0);
+    if constexpr (TRACE) {
+        if (trow && (threadIdx.x & 63u) == 0) { __builtin_amdgcn_s_waitcnt(0); trow[14] = __builtin_amdgcn_s_memtime(); trow[13] = __builtin_amdgcn_s_memrealtime(); }
+    }
 }
 
 __global__ void __launch_bounds__(256) pow_table_kernel(Fe* out, uint64_t count, Fe base_m, uint64_t step, Fe scale_m) {
@@ -253,6 +274,8 @@ struct Ctx {
     DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
     int xcd_remap = 1;
     int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
+    int wave_local = 1;      // wave-level fences instead of workgroup barriers once a tile's exchanges stay inside one wave
+    unsigned long long* trace = nullptr;   // diagnostics: phase stamps of the next fixed-shape pass launches (sc_debug_trace)
     int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)
 };
 
@@ -464,7 +487,10 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
             const int lr = pd.p.logR, lc = pd.p.logC;
 #define SC_FIXED(LR, LC)                                                                                                             \
             if (lr == LR && lc == LC) {                                                                                              \
-                hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap); \
+                if (pd.p.trace)                                                                                                      \
+                    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, true>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local); \
+                else                                                                                                                 \
+                    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, false>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local); \
                 return;                                                                                                              \
             }
             SC_FIXED(8, 3) SC_FIXED(7, 4) SC_FIXED(10, 2) SC_FIXED(6, 5) SC_FIXED(9, 3) SC_FIXED(8, 4)
@@ -474,8 +500,11 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
     hipLaunchKernelGGL(ntt_pass_kernel<LOGE>, dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap);
 }
 
-int run_plan(const NttPlanDesc& d, hipStream_t st) {
+int run_plan(NttPlanDesc& d, hipStream_t st) {
+    size_t trace_off = 0;    // diagnostics: pass i writes its stamps behind those of the passes before it
     for (int i = 0; i < d.npasses; ++i) {
+        d.pass[i].p.trace = g.trace ? g.trace + trace_off : nullptr;
+        trace_off += (size_t)d.pass[i].ntiles * (d.pass[i].threads >> 6) * TRACE_STAMPS;
         switch (d.pass[i].loge) {
             case 1: launch_pass<1>(d.pass[i], st); break;
             case 2: launch_pass<2>(d.pass[i], st); break;
@@ -986,8 +1015,16 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "direct_tw_max_log") g.tuning.direct_tw_max_log = value;
     else if (k == "xcd_remap") g.xcd_remap = value;
     else if (k == "fixed_shapes") g.fixed_shapes = value;
+    else if (k == "wave_local") g.wave_local = value;
+    else if (k == "tw_on_load") g.tuning.tw_on_load = value;
     else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);
     else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
+    return SC_OK;
+}
+
+int sc_debug_trace(void* d_buf) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.trace = (unsigned long long*)d_buf;
     return SC_OK;
 }
 

@@ -27,6 +27,7 @@ SIGNATURES = {
     "sc_last_error": (ctypes.c_char_p, []),
     "sc_synchronize": (_int, []),
     "sc_set_tuning": (_int, [ctypes.c_char_p, _int]),
+    "sc_debug_trace": (_int, [_vp]),
     "sc_field_selftest": (_int, [_int, _vp, _vp, _vp, _u64]),
     "sc_vec_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
     "sc_vec_free": (_int, [_vp]),

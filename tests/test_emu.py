@@ -84,11 +84,13 @@ def test_emu_multi_pass(emu, cfg):
     assert out == po.C.ntt(root, data, n), cfg
     out, _ = run_emu(emu, data, logn, root, inverse=1, **kw)
     assert out == po.C.intt(root, data, n), cfg
-    # two-level twiddle lookup instead of the direct tables
-    out, _ = run_emu(emu, data, logn, root, direct=0, **kw)
-    assert out == po.C.ntt(root, data, n), cfg
-    out, _ = run_emu(emu, data, logn, root, inverse=1, direct=0, **kw)
-    assert out == po.C.intt(root, data, n), cfg
+    # two-level twiddle lookup instead of the direct tables (0); direct tables applied at the store of the producing pass
+    # instead of on load by the next one (2)
+    for direct in (0, 2):
+        out, _ = run_emu(emu, data, logn, root, direct=direct, **kw)
+        assert out == po.C.ntt(root, data, n), (cfg, direct)
+        out, _ = run_emu(emu, data, logn, root, inverse=1, direct=direct, **kw)
+        assert out == po.C.intt(root, data, n), (cfg, direct)
 
 
 def test_emu_pass_counts(emu):
