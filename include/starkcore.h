@@ -15,6 +15,13 @@
  *   - *_dev entry points take device pointers (hipMalloc / torch tensor storage, 16-byte aligned) and
  *     a hipStream_t (NULL = the library's own stream) and are asynchronous on that stream.
  *   - sc_vec_t / sc_merkle_t are library-owned device objects behind opaque handles.
+ *   - one context per PROCESS: sc_init(device) binds the process to one GPU (one process per GPU is the multi-GPU model,
+ *     stark-anatomy_amd/sharded.py + torch.distributed/RCCL; there is no sc_init(ndev) and no sc_ntt_sharded -- the
+ *     sharded transform is the Python class sharded.ShardedNtt over sc_ntt_batch_ex_dev).
+ *   - streams: the library keeps a few scratch buffers (transform work space, temporaries) that every call reuses.  Calls
+ *     that pass the SAME stream (or NULL) are ordered by that stream and need nothing else.  Calls on DIFFERENT streams must
+ *     not overlap in time: order them with events, or synchronize, before switching streams (sharded.py does).  Frees of
+ *     library objects wait for the whole device once a caller stream has been seen.
  */
 #ifndef STARKCORE_H
 #define STARKCORE_H

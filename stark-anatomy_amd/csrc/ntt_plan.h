@@ -16,7 +16,10 @@ struct NttTuning {
     int single_pass_max_log = 11;
     int max_digit_log = -1;  // passes = ceil(logn / max_digit_log)
     int direct_tw_max_log = 22;  // direct four-step twiddle tables up to 2^this entries per pass (bigger ones cost more HBM than they save)
-    int tw_on_load = 1;          // a pass whose predecessor has a direct table applies that table on LOAD (see PassParams::twd_in)
+    // a pass whose predecessor has a direct table applies that table on LOAD (PassParams::twd_in).  Measured (profiles/r02/
+    // ab_redc_waveLocal_twOnLoad.txt): +1-2 % from 2^22 up, where other workgroups hide the longer load phase; -5 % at 2^20,
+    // where the grid is a single wave of workgroups and the doubled load burst (table + data) is exposed.  -1 = by size.
+    int tw_on_load = -1;
 };
 
 inline NttTuning resolve_tuning(const NttTuning& in, int logn) {
@@ -25,6 +28,7 @@ inline NttTuning resolve_tuning(const NttTuning& in, int logn) {
     if (t.max_digit_log < 0) t.max_digit_log = small ? 10 : 8;
     if (t.max_tile_log < 0) t.max_tile_log = small ? 12 : 11;
     if (t.max_col_log < 0) t.max_col_log = small ? 4 : 6;
+    if (t.tw_on_load < 0) t.tw_on_load = small ? 0 : 1;
     return t;
 }
 

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -253,6 +254,7 @@ struct PlanTables {      // power tables of one root of order n = 2^logn
     // direct inter-pass table of the two-pass BATCHED plans of this length (first digit twd_b_digit0)
     Fe* twd_b = nullptr;
     int twd_b_digit0 = 0;
+    uint64_t last_use = 0;   // lookup tick (eviction order; see evict_tables)
 };
 struct PowKey {
     uint64_t lo, hi, hi_count;
@@ -261,6 +263,7 @@ struct PowKey {
 struct PowTables {
     Fe* lo = nullptr;
     Fe* hi = nullptr;
+    uint64_t last_use = 0;
 };
 
 struct Ctx {
@@ -271,6 +274,8 @@ struct Ctx {
     NttTuning tuning;
     std::map<PlanKey, PlanTables> plans;
     std::map<PowKey, PowTables> pows;
+    uint64_t tick = 0;       // bumped by every table lookup
+    bool foreign_streams = false;   // a caller-owned stream has been used (see pick_stream)
     DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
     int xcd_remap = 1;
     int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
@@ -368,7 +373,16 @@ int scratch(int slot, size_t bytes, void** out) {
     return SC_OK;
 }
 
-inline hipStream_t pick_stream(void* s) { return s ? (hipStream_t)s : g.stream; }
+// A caller stream (the *_dev entries take one; sharded.py passes torch's) may still be reading a pooled buffer when it is
+// freed: once any foreign stream has been seen, frees wait for the whole device instead of the library stream only.
+inline hipStream_t pick_stream(void* s) {
+    if (s && (hipStream_t)s != g.stream) g.foreign_streams = true;
+    return s ? (hipStream_t)s : g.stream;
+}
+inline void sync_before_free() {
+    if (g.foreign_streams) (void)hipDeviceSynchronize();
+    else (void)hipStreamSynchronize(g.stream);
+}
 inline Fe fe_from(const uint64_t v[2]) { return Fe{v[0], v[1]}; }
 inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 inline int ilog2(uint64_t n) { int l = 0; while ((1ull << l) < n) ++l; return l; }
@@ -394,16 +408,40 @@ int build_pow_table(Fe** out, uint64_t count, Fe base_m, uint64_t step, Fe scale
     return SC_OK;
 }
 
+void free_plan_tables(PlanTables& t) {
+    hipFree(t.mt); hipFree(t.tl); hipFree(t.th);
+    if (t.th_ninv) hipFree(t.th_ninv);
+    for (int v = 0; v < 2; ++v) for (int i = 0; i < 4; ++i) if (t.twd[v][i]) hipFree(t.twd[v][i]);
+    if (t.twd_b) hipFree(t.twd_b);
+}
+
 void free_plans() {
-    for (auto& kv : g.plans) {
-        hipFree(kv.second.mt); hipFree(kv.second.tl); hipFree(kv.second.th);
-        if (kv.second.th_ninv) hipFree(kv.second.th_ninv);
-        for (int v = 0; v < 2; ++v) for (int i = 0; i < 4; ++i) if (kv.second.twd[v][i]) hipFree(kv.second.twd[v][i]);
-        if (kv.second.twd_b) hipFree(kv.second.twd_b);
-    }
+    for (auto& kv : g.plans) free_plan_tables(kv.second);
     g.plans.clear();
     for (auto& kv : g.pows) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     g.pows.clear();
+}
+
+// Cache eviction, least recently used first and NEVER an entry looked up recently: one API call makes at most a handful of
+// table lookups and keeps raw pointers to what it got (NttOpts::coset, PlanTables*), so the PIN_WINDOW most recent lookups
+// are off limits -- an eviction in the middle of a call cannot free what the call still uses.  std::map nodes are stable, so
+// erasing other entries leaves the kept pointers valid.  One device sync per batch, not per entry.
+constexpr uint64_t PIN_WINDOW = 64;
+constexpr size_t PLAN_CAP = 256, POW_CAP = 64;
+
+template <class Map, class FreeFn>
+int evict_tables(Map& m, size_t cap, FreeFn free_entry) {
+    if (m.size() < cap) return SC_OK;
+    std::vector<std::pair<uint64_t, typename Map::iterator>> old;
+    for (auto it = m.begin(); it != m.end(); ++it)
+        if (it->second.last_use + PIN_WINDOW < g.tick) old.emplace_back(it->second.last_use, it);
+    if (old.empty()) return SC_OK;                       // everything is in recent use: let the cache grow
+    std::sort(old.begin(), old.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    size_t drop = cap / 4 ? cap / 4 : 1;
+    if (drop > old.size()) drop = old.size();
+    HIPCHK(hipDeviceSynchronize());
+    for (size_t i = 0; i < drop; ++i) { free_entry(old[i].second->second); m.erase(old[i].second); }
+    return SC_OK;
 }
 
 // tables for a primitive n-th root (Montgomery form entries)
@@ -411,8 +449,9 @@ int get_plan(Fe root, int logn, bool need_ninv, hipStream_t st, PlanTables** out
     PlanKey key{logn, root.lo, root.hi};
     auto it = g.plans.find(key);
     bool built = false;
+    ++g.tick;
     if (it == g.plans.end()) {
-        if (g.plans.size() >= 256) { HIPCHK(hipDeviceSynchronize()); free_plans(); }
+        SCCHK(evict_tables(g.plans, PLAN_CAP, free_plan_tables));
         const uint64_t n = 1ull << logn;
         Fe rm = to_mont(root);
         PlanTables t;
@@ -430,6 +469,7 @@ int get_plan(Fe root, int logn, bool need_ninv, hipStream_t st, PlanTables** out
         built = true;
     }
     if (built) HIPCHK(hipStreamSynchronize(st));   // tables are shared across streams afterwards
+    it->second.last_use = g.tick;
     *out = &it->second;
     return SC_OK;
 }
@@ -441,8 +481,9 @@ int get_pow(Fe base, uint64_t count, hipStream_t st, PowTables** out) {
     uint64_t hc = 1; while (hc < hi_count) hc <<= 1;
     PowKey key{base.lo, base.hi, hc};
     auto it = g.pows.find(key);
+    ++g.tick;
     if (it == g.pows.end()) {
-        if (g.pows.size() >= 64) { HIPCHK(hipDeviceSynchronize()); free_plans(); }
+        SCCHK(evict_tables(g.pows, POW_CAP, [](PowTables& t) { hipFree(t.lo); hipFree(t.hi); }));
         Fe bm = to_mont(base);
         PowTables t;
         SCCHK(build_pow_table(&t.lo, 4096, bm, 1, fe_mont_one(), st));
@@ -450,6 +491,7 @@ int get_pow(Fe base, uint64_t count, hipStream_t st, PowTables** out) {
         HIPCHK(hipStreamSynchronize(st));
         it = g.pows.emplace(key, t).first;
     }
+    it->second.last_use = g.tick;
     *out = &it->second;
     return SC_OK;
 }
@@ -1041,7 +1083,7 @@ int sc_vec_alloc(uint64_t n, sc_vec_t** out) {
 int sc_vec_free(sc_vec_t* v) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!v) return SC_OK;
-    hipStreamSynchronize(g.stream);
+    sync_before_free();
     pool_free(v->d, (v->n ? v->n : 1) * sizeof(Fe));
     delete v;
     return SC_OK;
@@ -1501,7 +1543,7 @@ uint64_t sc_merkle_leaves(const sc_merkle_t* tree) { return tree ? tree->N : 0; 
 int sc_merkle_free(sc_merkle_t* tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree) return SC_OK;
-    hipStreamSynchronize(g.stream);
+    sync_before_free();
     pool_free(tree->d_levels, (2 * tree->N - 1) * 64);
     delete tree;
     return SC_OK;
@@ -1550,7 +1592,7 @@ int sc_polytree_interpolate_dev(sc_polytree_t* tree, const void* d_values, void*
 int sc_polytree_free(sc_polytree_t* tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree) return SC_OK;
-    hipStreamSynchronize(g.stream);
+    sync_before_free();
     pool_free(tree->zc, tree->zc_bytes);
     pool_free(tree->zf, tree->zf_bytes);
     if (tree->invg_f) pool_free(tree->invg_f, 2 * tree->K * sizeof(Fe));

@@ -24,6 +24,8 @@ class Merkle:
     def _tree(data_array):
         if isinstance(data_array, DeviceCodeword):
             return data_array.tree()
+        # leaves travel as 16-byte residues; a field wider than that has no device leaf format (and no CPU fallback)
+        assert(len(data_array) == 0 or data_array[0].field.p <= (1 << 128)), "the MI355X Merkle kernels take residues below 2^128 only"
         return MerkleTree.from_bytes(b"".join(da.value.to_bytes(16, "little") for da in data_array))
 
     def commit(data_array):

@@ -155,7 +155,12 @@ class MPolynomial:
         vals = _sc.DeviceVector(nvars * n)
         lib = _sc.lib()
         keep = []
+        # only variables that occur in a live term are transformed: an unused one may be longer than the domain (n is sized
+        # from the variables that do appear), and mpoly_eval_kernel never reads the values of a variable whose exponent is 0
+        used = [any(k[j] for k, _ in terms) for j in range(nvars)]
         for j, q in enumerate(point):
+            if not used[j]:
+                continue
             m = degs[j] + 1
             src = _sc.DeviceVector.from_bytes(b"".join(c.value.to_bytes(16, "little") for c in q.coefficients[:m])) if m else _sc.DeviceVector(1)
             keep.append(src)

@@ -19,6 +19,15 @@ _ROOT_ORDER_MSG = "supplied root does not have supplied order"
 _ROOT_PRIM_MSG = "supplied root is not primitive root of supplied order"
 
 
+_FIELD_MSG = "the MI355X polynomial core implements the field p = 1 + 407 * 2^119 only"
+
+
+def _require_main_field(field):
+    """The kernels are hard-wired to p = 1 + 407*2^119 (the only field whose primitive_nth_root the reference supports,
+    algebra.py:104-114).  There is no CPU fallback, so any other modulus is refused loudly instead of being mis-reduced."""
+    assert(field.p == Field.P_MAIN), _FIELD_MSG
+
+
 def _pack(elements):
     return b"".join(e.value.to_bytes(16, "little") for e in elements)
 
@@ -44,6 +53,7 @@ def _check_root(primitive_root, root_order):
 def _transform(primitive_root, values, inverse):
     n = len(values)
     field = values[0].field
+    _require_main_field(field)
     if isinstance(values, DeviceCodeword):
         out = DeviceVector(n)
         _sc._check(_sc.lib().sc_ntt_dev(values.vec.ptr, out.ptr, n, _sc.fe_bytes(primitive_root.value), inverse, None))
@@ -91,6 +101,7 @@ def fast_multiply(lhs, rhs, primitive_root, root_order):
     degree = dl + dr
     if degree < 8:
         return lhs * rhs
+    _require_main_field(field)
     root, order = _shrink_order(primitive_root, root_order, degree)
     out = ctypes.create_string_buffer(16 * (degree + 1))
     _sc._check(_sc.lib().sc_poly_mul(_pack(lhs.coefficients[:dl + 1]), dl + 1, _pack(rhs.coefficients[:dr + 1]), dr + 1,
@@ -106,6 +117,7 @@ _tree_memo = {}           # points (as packed bytes) -> PolyTree; fast_interpola
 
 
 def _device_tree(domain):
+    _require_main_field(domain[0].field)
     key = _pack(domain)
     tree = _tree_memo.get(key)
     if tree is None:
@@ -200,6 +212,7 @@ class DeviceDomain:
         else:
             vec, field = DeviceVector.from_bytes(_pack(points)), points[0].field
         assert(vec.n > 0), "empty domain"
+        _require_main_field(field)
         self.field = field
         self.tree = _sc.PolyTree(vec)
 
@@ -227,6 +240,7 @@ def fast_coset_evaluate_device(polynomial, offset, generator, order):
     """fast_coset_evaluate with the result left in HBM as a DeviceCodeword."""
     coeffs = polynomial.coefficients
     m = len(coeffs)
+    _require_main_field(offset.field)
     out = DeviceVector(order)
     src = DeviceVector.from_bytes(_pack(coeffs)) if m else DeviceVector(1)
     _sc._check(_sc.lib().sc_coset_evaluate_dev(src.ptr, m, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out.ptr, None))
@@ -245,6 +259,7 @@ def fast_coset_evaluate(polynomial, offset, generator, order):
     field = offset.field
     assert(generator ^ order == field.one()), "primitive root must be nth root of unity, where n is len(values)"
     assert(generator ^ (order // 2) != field.one()), "primitive root is not primitive nth root of unity, where n is len(values)"
+    _require_main_field(field)
     out = ctypes.create_string_buffer(16 * order)
     _sc._check(_sc.lib().sc_coset_evaluate(_pack(coeffs), m, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out))
     return _unpack(out.raw, order, field)
@@ -261,6 +276,7 @@ def fast_coset_divide(lhs, rhs, offset, primitive_root, root_order):  # clean di
     degree = max(dl, dr)
     if degree < 8:
         return lhs / rhs
+    _require_main_field(field)
     root, order = _shrink_order(primitive_root, root_order, degree)
     n_out = dl - dr + 1
     out = ctypes.create_string_buffer(16 * n_out)

@@ -78,15 +78,24 @@ class Polynomial:
         if self.coefficients == [] or other.coefficients == []:
             return Polynomial([])
         field = self.coefficients[0].field
+        if min(len(self.coefficients), len(other.coefficients)) >= Polynomial.FAST_MUL_MIN_LEN and field.p == Field.P_MAIN:
+            # Decide on DEGREES, not list lengths: lists may carry trailing zeros, and fast_multiply hands products of
+            # degree < 8 straight back to `lhs * rhs` (ntt.py:44-45) -- taking the fast path for those would recurse forever.
+            dl, dr = self.degree(), other.degree()
+            if dl + dr >= 8:
+                # Polynomial.__mul__ dominates MPolynomial.evaluate_symbolic (fast_stark.py:109-110) at scale; the product is
+                # the same polynomial, so only the time changes
+                from ntt import fast_multiply
+                full_len = len(self.coefficients) + len(other.coefficients) - 1
+                order = 1 << max(1, (dl + dr).bit_length())
+                product = fast_multiply(self, other, field.primitive_nth_root(order), order).coefficients
+                return Polynomial(product + [field.zero()] * (full_len - len(product)))
+        return self._schoolbook_mul(other)
+
+    def _schoolbook_mul(self, other):
+        """univariate.py:48-57: len(a) + len(b) - 1 coefficients, trailing zeros included"""
+        field = self.coefficients[0].field
         p = field.p
-        if min(len(self.coefficients), len(other.coefficients)) >= Polynomial.FAST_MUL_MIN_LEN and p == Field.P_MAIN:
-            # Polynomial.__mul__ dominates MPolynomial.evaluate_symbolic (fast_stark.py:109-110) at scale; the product is
-            # the same polynomial, so only the time changes
-            from ntt import fast_multiply
-            full_len = len(self.coefficients) + len(other.coefficients) - 1
-            order = 1 << max(1, (full_len - 1).bit_length())
-            product = fast_multiply(self, other, field.primitive_nth_root(order), order).coefficients
-            return Polynomial(product + [field.zero()] * (full_len - len(product)))
         b = [c.value for c in other.coefficients]
         out = [0] * (len(self.coefficients) + len(b) - 1)
         for i, c in enumerate(self.coefficients):

@@ -61,7 +61,7 @@ extern "C" int emu_ntt(const uint64_t* in, uint64_t* out, int logn, const uint64
     NttTuning tu;
     tu.max_tile_log = max_tile_log; tu.loge = loge; tu.single_pass_max_log = single_pass_max_log;
     tu.min_tiles_log = min_tiles_log; tu.max_col_log = max_col_log; tu.max_digit_log = max_digit_log;
-    tu.tw_on_load = (direct_tw != 2);      // direct_tw: 0 = two-level lookup, 1 = direct tables applied on load by the next pass, 2 = direct tables at the store
+    tu.tw_on_load = (direct_tw != 2) ? 1 : 0;      // direct_tw: 0 = two-level lookup, 1 = direct tables applied on load by the next pass, 2 = direct tables at the store
     const int m = plan_num_passes(logn, tu);
     NttTables tb;
     std::vector<Fe> mt, tl, th, ths, ol, oh;

@@ -21,7 +21,7 @@ def sc():
     assert starkcore.device_count() > 0, "no GPU visible: the HIP path is mandatory for these tests"
     starkcore.init()
     yield starkcore
-    for k, v in (("max_tile_log", -1), ("loge", 2), ("max_col_log", -1), ("min_tiles_log", 8), ("single_pass_max_log", 11), ("max_digit_log", -1), ("xcd_remap", 1), ("direct_tw_max_log", 22), ("fixed_shapes", 1)):
+    for k, v in (("max_tile_log", -1), ("loge", 2), ("max_col_log", -1), ("min_tiles_log", 8), ("single_pass_max_log", 11), ("max_digit_log", -1), ("xcd_remap", 1), ("direct_tw_max_log", 22), ("fixed_shapes", 1), ("wave_local", 1), ("tw_on_load", -1)):
         starkcore.set_tuning(k, v)
 
 
@@ -74,12 +74,15 @@ def test_ntt_big_golden(sc):
 
 TUNINGS = [dict(max_tile_log=12, loge=3, max_digit_log=8), dict(max_tile_log=11, loge=3, max_digit_log=8, max_col_log=6), dict(max_tile_log=10, loge=2), dict(max_tile_log=12, loge=3, max_col_log=4),
            dict(max_tile_log=12, loge=3, min_tiles_log=0), dict(max_tile_log=9, loge=2, max_digit_log=5), dict(max_tile_log=12, loge=3, xcd_remap=0),
-           dict(max_tile_log=12, loge=3, single_pass_max_log=12), dict(direct_tw_max_log=0), dict(direct_tw_max_log=16, max_tile_log=11), dict(fixed_shapes=0)]
+           dict(max_tile_log=12, loge=3, single_pass_max_log=12), dict(direct_tw_max_log=0), dict(direct_tw_max_log=16, max_tile_log=11), dict(fixed_shapes=0),
+           # round 2: workgroup barriers everywhere / four-step tables applied on load by the next pass / at the store
+           dict(wave_local=0), dict(tw_on_load=1), dict(tw_on_load=0), dict(tw_on_load=1, wave_local=0, max_tile_log=11, max_digit_log=8)]
 
 
 @pytest.mark.parametrize("tune", TUNINGS)
 def test_ntt_tunings_agree_with_oracle(sc, tune):
-    defaults = dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1)
+    defaults = dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1,
+                    wave_local=1, tw_on_load=-1)
     defaults.update(tune)
     for k, v in defaults.items():
         sc.set_tuning(k, v)
@@ -91,8 +94,31 @@ def test_ntt_tunings_agree_with_oracle(sc, tune):
             assert gpu_ntt(sc, data, n, root) == C.ntt(root, data, n), (tune, logn)
             assert gpu_ntt(sc, data, n, root, 1) == C.intt(root, data, n), (tune, logn)
     finally:
-        for k, v in dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1).items():
+        for k, v in dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1,
+                         wave_local=1, tw_on_load=-1).items():
             sc.set_tuning(k, v)
+
+
+def test_table_cache_eviction_keeps_tables_in_use(sc):
+    """the plan / power-table caches evict (256 plans, 64 power tables).  Registering more distinct roots and
+    offsets than that must never free tables the running call still points to: every result stays bit-exact."""
+    lib = sc.lib()
+    n, m = 1 << 10, 200
+    w = po.primitive_nth_root(n)
+    data, coeffs = packed(4100, n), packed(4101, m)
+    expect_ntt = {}
+    for i in range(300):                                   # 300 distinct primitive 1024-th roots -> 300 plan entries
+        root = pow(w, 2 * i + 1, P)
+        got = gpu_ntt(sc, data, n, root)
+        if i % 37 == 0:
+            assert got == C.ntt(root, data, n), i
+    for i in range(80):                                    # 80 distinct coset offsets -> 80 power-table entries, each with a fresh plan too
+        off, gen = 3 + i, pow(w, 2 * (300 + i) + 1, P)
+        out = ctypes.create_string_buffer(16 * n)
+        sc._check(lib.sc_coset_evaluate(coeffs, m, sc.fe_bytes(off), sc.fe_bytes(gen), n, out))
+        if i % 9 == 0 or i >= 76:
+            assert out.raw == C.coset_evaluate(coeffs, m, off, gen, n), i
+    assert gpu_ntt(sc, data, n, w) == C.ntt(w, data, n)     # the very first (long evicted) root is rebuilt on demand
 
 
 @pytest.mark.parametrize("logn", [22, 24])

@@ -107,3 +107,33 @@ def test_fri_index_sampling_and_rounds():
     f0 = Fri(field.generator(), field.primitive_nth_root(256), 256, 4, 17)
     for rec in g["sample_indices"]:
         assert f0.sample_indices(bytes.fromhex(rec["seed_hex"]), rec["size"], rec["reduced_size"], rec["number"]) == rec["out"]
+
+
+def test_mul_trailing_zero_operands_do_not_recurse():
+    """both lists long (>= 32 entries) but the product's degree < 8 -- fast_multiply hands such products back to
+    `lhs * rhs` (ntt.py:44-45), so __mul__ has to decide on degrees.  The reference returns len(a) + len(b) - 1 coefficients."""
+    a = Polynomial([fe(1), fe(1)] + [fe(0)] * 40)
+    b = Polynomial([fe(1), fe(1), fe(1)] + [fe(0)] * 40)
+    prod = a * b
+    assert len(prod.coefficients) == 42 + 43 - 1 == 84
+    assert [c.value for c in prod.coefficients[:5]] == [1, 2, 2, 1, 0] and all(c.value == 0 for c in prod.coefficients[4:])
+    from ntt import fast_multiply
+    r64 = field.primitive_nth_root(64)
+    assert [c.value for c in fast_multiply(a, b, r64, 64).coefficients] == [1, 2, 2, 1] + [0] * 80     # ntt.py:44-45: `lhs * rhs` of the untrimmed operands (checked against the reference)
+    # all-zero long operands
+    z = Polynomial([fe(0)] * 40)
+    assert (z * a).coefficients == [fe(0)] * (40 + 42 - 1)
+
+
+def test_other_fields_are_refused_not_misreduced():
+    """the device path is hard-wired to p = 1 + 407*2^119; another modulus must fail loudly before any kernel runs."""
+    import pytest
+    from ntt import ntt, fast_coset_evaluate, _FIELD_MSG
+    f97 = Field(97)
+    root = FieldElement(22, f97)            # 22 has order 4 mod 97? checked below
+    assert (root ^ 4).value == 1 and (root ^ 2).value != 1
+    vals = [FieldElement(v, f97) for v in (1, 2, 3, 4)]
+    with pytest.raises(AssertionError, match="p = 1 \\+ 407"):
+        ntt(root, vals)
+    with pytest.raises(AssertionError, match="p = 1 \\+ 407"):
+        fast_coset_evaluate(Polynomial(vals[:2]), FieldElement(3, f97), root, 4)
