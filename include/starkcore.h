@@ -112,6 +112,10 @@ int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, cons
 int sc_pointwise_mul_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream);
 int sc_pointwise_div_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream); /* sync; SC_ERR_DIV_ZERO */
 int sc_scale_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t factor[2], void* stream); /* out[i] = in[i] * factor^i */
+/* the same scaling (univariate.py:153-154) on one rank's column slab [rows][cols] of a vector viewed as a rows x row_len
+ * matrix (multi-GPU fast_coset_evaluate / fast_coset_divide, ntt.py:132-135, :159-176):
+ * out[r][c] = in[r][c] * factor^(r * row_len + col_base + c); cols a power of two */
+int sc_scale_slab_dev(const void* d_in, void* d_out, uint64_t rows, uint64_t cols, uint64_t row_len, uint64_t col_base, const uint64_t factor[2], void* stream);
 
 /* ---- fast_zerofier / fast_evaluate / fast_interpolate : code/ntt.py:66-80, :82-100, :102-130 -- */
 /* The reference recurses node by node (split at len//2, schoolbook remainders, zerofiers recomputed per node); zerofier,

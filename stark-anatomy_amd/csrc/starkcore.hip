@@ -133,6 +133,16 @@ __global__ void __launch_bounds__(256) scale_pow_kernel(const Fe* __restrict__ i
     if (i < n) out[i] = mont_mul(in[i], pow2level(lo, hi, i));
 }
 
+// the same scaling on a column slab [rows][2^logcols] of a vector viewed as a rows x row_len matrix:
+// out[r][c] = in[r][c] * base^(r * row_len + col_base + c)   (Polynomial.scale on the rank's columns, multi-GPU LDE / coset division)
+__global__ void __launch_bounds__(256) scale_slab_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, uint64_t rows, int logcols, uint64_t row_len, uint64_t col_base,
+                                                         const Fe* __restrict__ lo, const Fe* __restrict__ hi) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (rows << logcols)) return;
+    uint64_t r = t >> logcols, c = t & ((1ull << logcols) - 1);
+    out[t] = mont_mul(in[t], pow2level(lo, hi, r * row_len + col_base + c));
+}
+
 // split-and-fold (code/fri.py:85) rewritten as
 //   out[i] = (a + b)/2 + (a - b) * c * w^-i,   a = in[i], b = in[i + N/2], c = alpha / (2 * offset)
 // lo/hi are the power tables of omega^-1, c_m is c in Montgomery form.
@@ -1293,6 +1303,20 @@ int sc_scale_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t facto
     PowTables* pw;
     SCCHK(get_pow(fe_from(factor), n, st, &pw));
     hipLaunchKernelGGL(scale_pow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fe*)d_in, (Fe*)d_out, n, pw->lo, pw->hi);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+int sc_scale_slab_dev(const void* d_in, void* d_out, uint64_t rows, uint64_t cols, uint64_t row_len, uint64_t col_base, const uint64_t factor[2], void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!rows || !cols) return SC_OK;
+    if (!is_pow2(cols) || col_base + cols > row_len) return fail(SC_ERR_BAD_ARG, "slab columns must be a power of two inside the row");
+    hipStream_t st = pick_stream(stream);
+    PowTables* pw;
+    SCCHK(get_pow(fe_from(factor), rows * row_len, st, &pw));
+    const uint64_t cnt = rows * cols;
+    hipLaunchKernelGGL(scale_slab_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const Fe*)d_in, (Fe*)d_out, rows, ilog2(cols), row_len, col_base, pw->lo, pw->hi);
     HIPCHK(hipGetLastError());
     return SC_OK;
 }

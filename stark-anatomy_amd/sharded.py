@@ -24,6 +24,43 @@ def _fe(v):
     return int(v).to_bytes(16, "little")
 
 
+def _exchange_single(recv, send, group=None):
+    """all_to_all_single on [G][...] blocks.  Backend "nccl" (= RCCL) moves device buffers directly; under gloo with device
+    tensors (functional tests: several ranks sharing one GPU) the exchange is staged through the host."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        host_recv = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(host_recv.view(-1), send.cpu().contiguous().view(-1), group=group)
+        recv.copy_(host_recv)
+        return
+    dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1), group=group)
+
+
+def rows_to_column_slab(chunk, rows, cols, rank, world, group=None):
+    """A vector that arrives in NATURAL contiguous layout -- rank g holds x[g*n/G : (g+1)*n/G], i.e. rows [g*rows/G, (g+1)*rows/G)
+    of the row-major rows x cols matrix -- re-laid out as column slabs [rows][cols/G] with ONE all-to-all (the corner turn
+    itself).  This is how a codeword in the contiguous-slab layout of SURVEY.md 8(e)-2 enters the zero-exchange FRI layout:
+    one exchange up front instead of one neighbour exchange per fold (same total bytes: (G-1)/G of the vector)."""
+    rw, cw = rows // world, cols // world
+    assert tuple(chunk.shape) == (rw, cols, 2)
+    if world == 1:
+        return chunk
+    send = chunk.view(rw, world, cw, 2).permute(1, 0, 2, 3).contiguous()       # block h = my rows x columns of rank h
+    recv = torch.empty((world, rw, cw, 2), dtype=chunk.dtype, device=chunk.device)
+    _exchange_single(recv, send, group)
+    return recv.view(rows, cw, 2)                                              # block g = rows of rank g, my columns
+
+
+def column_slab_to_rows(slab, rows, cols, rank, world, group=None):
+    """inverse of rows_to_column_slab: [rows][cols/G] -> this rank's contiguous rows [rows/G][cols]"""
+    rw, cw = rows // world, cols // world
+    assert tuple(slab.shape) == (rows, cw, 2)
+    if world == 1:
+        return slab
+    recv = torch.empty((world, rw, cw, 2), dtype=slab.dtype, device=slab.device)
+    _exchange_single(recv, slab.contiguous().view(world, rw, cw, 2), group)
+    return recv.permute(1, 0, 2, 3).contiguous().view(rw, cols, 2)
+
+
 class HipEngine:
     """Local stages through the C-ABI (libstarkcore.so) on torch-owned device memory."""
 
@@ -48,6 +85,18 @@ class HipEngine:
     def scale_powers(self, src, dst, count, factor):
         """dst[j] = src[j] * factor^j (Polynomial.scale, code/univariate.py:153-154)"""
         self.sc._check(self.lib.sc_scale_dev(src.data_ptr(), dst.data_ptr(), count, _fe(factor), self.sptr))
+
+    def scale_slab(self, src, dst, rows, cols, row_len, col_base, factor):
+        """dst[r][c] = src[r][c] * factor^(r*row_len + col_base + c): Polynomial.scale on this rank's columns"""
+        self.sc._check(self.lib.sc_scale_slab_dev(src.data_ptr(), dst.data_ptr(), rows, cols, row_len, col_base, _fe(factor), self.sptr))
+
+    def pointwise_mul(self, a, b, out, count):
+        """Hadamard product (code/ntt.py:61)"""
+        self.sc._check(self.lib.sc_pointwise_mul_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), count, self.sptr))
+
+    def pointwise_div(self, a, b, out, count):
+        """pointwise quotient (code/ntt.py:172); a zero divisor raises the reference's AssertionError("divide by zero")"""
+        self.sc._check(self.lib.sc_pointwise_div_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), count, self.sptr))
 
     # fused variants (one kernel sequence each; no separate twiddle pass, no reassembly copy)
     def cols_ntt_twiddled(self, src, dst, length, batch, root, outer_root, order, col_base, scale_ninv):
@@ -91,6 +140,7 @@ class ShardedNtt:
         self.engine = engine
         self._bufs = {}
         self._a2a_single = True
+        self.bytes_exchanged = 0                   # bytes this rank has sent through the corner turn so far
 
     # -- helpers ---------------------------------------------------------------------------------
     def local_shape(self, forward_input=True):
@@ -139,23 +189,19 @@ class ShardedNtt:
     def _all_to_all(self, recv, a):
         """recv[g'] <- rows [rank*rw, (rank+1)*rw) of rank g's slab.  One collective; the list form is only a fallback for
         backends without all_to_all_single."""
-        if a.is_cuda and dist.get_backend(self.group) == "gloo":
-            # functional-test configuration only (several ranks sharing one GPU, tests/sharded_gpu_worker.py): gloo has no
-            # device all-to-all, so the exchange is staged through the host.  Production is backend "nccl" (= RCCL).
-            host_recv = torch.empty(recv.shape, dtype=recv.dtype)
-            self._exchange(host_recv, a.cpu())
-            recv.copy_(host_recv)
-            return
-        self._exchange(recv, a)
-
-    def _exchange(self, recv, a):
+        self.bytes_exchanged += a.numel() * 8 * (self.world - 1) // self.world
         if self._a2a_single:
             try:
-                dist.all_to_all_single(recv.view(-1), a.view(-1), group=self.group)
+                _exchange_single(recv, a, self.group)
                 return
             except (RuntimeError, NotImplementedError):
                 self._a2a_single = False
         G = self.world
+        if a.is_cuda and dist.get_backend(self.group) == "gloo":
+            host_recv, host_a = torch.empty(recv.shape, dtype=recv.dtype), a.cpu()
+            dist.all_to_all(list(host_recv.view(G, -1).unbind(0)), list(host_a.view(G, -1).unbind(0)), group=self.group)
+            recv.copy_(host_recv)
+            return
         dist.all_to_all(list(recv.view(G, -1).unbind(0)), list(a.view(G, -1).unbind(0)), group=self.group)
 
     def assemble_rows(self, recv, R, C):
@@ -192,27 +238,80 @@ class ShardedNtt:
             return
         self.stage_rows(self.assemble_rows(recv, R, C), dst, R, C, root)
 
-    def coset_evaluate(self, coeffs, offset, y_local):
-        """Sharded fast_coset_evaluate (code/ntt.py:132-135): `coeffs` [m][2] is the WHOLE coefficient vector, replicated on
-        every rank (it is only 1/blowup of the domain); each rank scales it by offset^j, keeps the columns of its slab,
-        zero-pads to n1 rows and runs forward().  y_local [n2][n1/G] receives this rank's slab of the codeword on
-        { offset * root^i }."""
+    def slab_of(self, coeffs, key="slab_of"):
+        """This rank's column slab [n1][n2/G] (zero-padded) of a coefficient vector `coeffs` [m][2] that is REPLICATED on every
+        rank (polynomials are 1/blowup of the domain): coefficient j sits at row j // n2, column j % n2."""
         m = coeffs.shape[0]
         R, C, G = self.n1, self.n2, self.world
         assert m <= self.n and tuple(coeffs.shape) == (m, 2)
         cw = C // G
-        scaled = self._buf("lde_scaled", (m, 2))
-        self._run(lambda: self.engine.scale_powers(coeffs.contiguous(), scaled, m, int(offset)))
-        x = self._buf("lde_x", (R, cw, 2))
+        x = self._buf(key, (R, cw, 2))
         x.zero_()
-        full_rows, rest = divmod(m, C)                          # coefficient j sits at row j // C, column j % C
+        full_rows, rest = divmod(m, C)
         lo = self.rank * cw
         if full_rows:
-            x[:full_rows] = scaled[:full_rows * C].view(full_rows, C, 2)[:, lo:lo + cw]
+            x[:full_rows] = coeffs[:full_rows * C].view(full_rows, C, 2)[:, lo:lo + cw]
         if rest > lo:
             take = min(rest - lo, cw)
-            x[full_rows, :take] = scaled[full_rows * C + lo:full_rows * C + lo + take]
+            x[full_rows, :take] = coeffs[full_rows * C + lo:full_rows * C + lo + take]
+        return x
+
+    def coset_scale(self, x_local, factor, out=None, rows=None):
+        """x[j] * factor^j on a slab in the forward-input layout (Polynomial.scale, code/univariate.py:153-154)"""
+        out = x_local if out is None else out
+        R, C, cw = self.n1, self.n2, self.n2 // self.world
+        rows = R if rows is None else rows
+        if rows < R and out is not x_local:
+            out[rows:].copy_(x_local[rows:])
+        if rows:
+            self._run(lambda: self.engine.scale_slab(x_local, out, rows, cw, C, self.rank * cw, int(factor)))
+        return out
+
+    def coset_evaluate(self, coeffs, offset, y_local):
+        """Sharded fast_coset_evaluate (code/ntt.py:132-135): `coeffs` [m][2] is the WHOLE coefficient vector, replicated on
+        every rank (it is only 1/blowup of the domain); each rank keeps the columns of its slab, scales them by offset^j,
+        zero-pads to n1 rows and runs forward().  y_local [n2][n1/G] receives this rank's slab of the codeword on
+        { offset * root^i }."""
+        m = coeffs.shape[0]
+        x = self.slab_of(coeffs.contiguous(), "lde_x")
+        self.coset_scale(x, offset, rows=min(self.n1, -(-m // self.n2)) if m else 0)
         self.forward(x, y_local)
+
+    def multiply(self, a_local, b_local, out_local):
+        """Sharded fast_multiply core (code/ntt.py:58-64) on coefficient slabs [n1][n2/G] (zero-padded to the transform
+        length by the caller, like ntt.py:51-56): forward both, Hadamard product on the slab -- the pointwise stage needs no
+        exchange, every rank owns the same index set of both operands -- and inverse.  Two all-to-alls in, one out."""
+        fa = self._buf("mul_a", self.local_shape(False))
+        fb = self._buf("mul_b", self.local_shape(False))
+        self.forward(a_local, fa)
+        self.forward(b_local, fb)
+        self._run(lambda: self.engine.pointwise_mul(fa, fb, fa, fa.numel() // 2))
+        self.inverse(fa, out_local)
+
+    def coset_divide(self, a_local, b_local, offset, out_local):
+        """Sharded fast_coset_divide core (code/ntt.py:159-176) on coefficient slabs [n1][n2/G]: scale both by offset^j, forward,
+        pointwise division on the slab (a zero of the divisor on the coset raises "divide by zero" like algebra.py:92),
+        inverse, unscale by offset^-j.  The quotient's coefficients come back in the same slab layout."""
+        sa = self.coset_scale(a_local, offset, self._buf("div_sa", self.local_shape(True)))
+        sb = self.coset_scale(b_local, offset, self._buf("div_sb", self.local_shape(True)))
+        fa = self._buf("div_a", self.local_shape(False))
+        fb = self._buf("div_b", self.local_shape(False))
+        self.forward(sa, fa)
+        self.forward(sb, fb)
+        failed = 0
+        try:
+            self._run(lambda: self.engine.pointwise_div(fa, fb, fa, fa.numel() // 2))
+        except AssertionError:
+            failed = 1
+        if self.world > 1:
+            # the zero may sit in another rank's slab: agree on the outcome (4 bytes) before anyone enters the next collective
+            backend = dist.get_backend(self.group)
+            flag = torch.tensor([failed], dtype=torch.int32, device=self.device if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            failed = int(flag.item())
+        assert(not failed), "divide by zero"
+        self.inverse(fa, out_local)
+        self.coset_scale(out_local, pow(int(offset), P - 2, P))
 
     def forward(self, x_local, y_local):
         """x_local [n1][n2/G] -> y_local [n2][n1/G]  (column slab of X[k2*n1 + k1])."""
@@ -361,6 +460,11 @@ class ShardedFri:
         top_leaves = self._all_gather(sub).permute(1, 0, 2).contiguous()    # natural order: node (row, rank)
         top = eng.tree_from_digests(top_leaves.reshape(C * G, 8))
         return {"kind": "sharded", "slab": slab, "C": C, "local": local, "top": top, "root": top.root, "length": C * self.R, "cache": {}}
+
+    def commit(self, slab, C):
+        """Merkle.commit (code/merkle.py:13-14) of a codeword held as column slabs [C][R/G]: local subtrees + one all-gather
+        of C sub-roots per rank; returns the layer record `_open` answers openings from (its "root" is the commitment)."""
+        return self._commit_sharded(slab, C)
 
     def _natural(self, slab, C):
         """the whole codeword in natural order on every rank: [C][R/G] slabs -> [C*R]"""

@@ -48,6 +48,7 @@ SIGNATURES = {
     "sc_pointwise_mul_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "sc_pointwise_div_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "sc_scale_dev": (_int, [_vp, _vp, _u64, _vp, _vp]),
+    "sc_scale_slab_dev": (_int, [_vp, _vp, _u64, _u64, _u64, _u64, _vp, _vp]),
     "sc_fri_fold": (_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
     "sc_fri_fold_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "sc_merkle_commit": (_int, [_vp, _u64, _vp]),

@@ -15,7 +15,7 @@ for p in (os.path.join(REPO, "stark-anatomy_amd"), REPO):
 
 from oracle import py_oracle as po          # noqa: E402
 import synth                                 # noqa: E402
-from sharded import ShardedNtt, gather_natural, P   # noqa: E402
+from sharded import ShardedNtt, gather_natural, rows_to_column_slab, column_slab_to_rows, P   # noqa: E402
 
 
 class OracleEngine:
@@ -37,6 +37,22 @@ class OracleEngine:
     def scale_powers(self, src, dst, count, factor):
         raw = po.C.scale(src.contiguous().numpy().tobytes(), count, factor)
         dst.copy_(torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(count, 2).copy()))
+
+    def scale_slab(self, src, dst, rows, cols, row_len, col_base, factor):
+        a = self._np(src).reshape(-1, cols, 2)
+        out = self._np(dst).reshape(-1, cols, 2)
+        for r in range(rows):
+            for c in range(cols):
+                v = (int(a[r, c, 0]) | (int(a[r, c, 1]) << 64)) * pow(factor, r * row_len + col_base + c, P) % P
+                out[r, c, 0], out[r, c, 1] = v & ((1 << 64) - 1), v >> 64
+
+    def pointwise_mul(self, a, b, out, count):
+        raw = po.C.pointwise_mul(a.contiguous().numpy().tobytes(), b.contiguous().numpy().tobytes(), count)
+        out.view(-1).copy_(torch.from_numpy(np.frombuffer(raw, dtype=np.int64).copy()))
+
+    def pointwise_div(self, a, b, out, count):
+        raw = po.C.pointwise_div(a.contiguous().numpy().tobytes(), b.contiguous().numpy().tobytes(), count)
+        out.view(-1).copy_(torch.from_numpy(np.frombuffer(raw, dtype=np.int64).copy()))
 
     def twiddle(self, buf, rows, cols, row_base, col_base, root, order, scale):
         a = self._np(buf).reshape(rows, cols, 2)
@@ -75,11 +91,50 @@ def main():
             eng.coset_evaluate(torch.from_numpy(coeffs.view(np.int64).copy()), po.GENERATOR, lde)
             got_lde = gather_natural(lde, eng.n2, eng.n1, world).numpy().tobytes()
             ok &= got_lde == po.C.coset_evaluate(coeffs.tobytes(), m, po.GENERATOR, root, n)
+        ok &= poly_checks(eng, rank, world, n, root)
     dist.barrier()
     dist.destroy_process_group()
     if not ok:
         sys.exit(3)
     print("rank", rank, "ok")
+
+
+def poly_checks(eng, rank, world, n, root):
+    """SURVEY 8(e)-5 on slabs: fast_multiply / fast_coset_divide cores (code/ntt.py:58-64, :159-176), and 8(e)-2's contiguous
+    layout entering / leaving the column-slab layout with one exchange."""
+    ok = True
+    ints = lambda seed, k: synth.synth_ints(seed, k)
+    as_t = lambda vals: torch.from_numpy(np.frombuffer(synth.pack_ints(vals), dtype=np.int64).reshape(len(vals), 2).copy())
+    # product of two polynomials whose degrees add up to < n
+    la, lb = n // 2 - 3, n // 2 + 1
+    a, b = ints(21, la), ints(22, lb)
+    out = torch.empty(eng.local_shape(True), dtype=torch.int64)
+    eng.multiply(eng.slab_of(as_t(a), "ta").clone(), eng.slab_of(as_t(b), "tb").clone(), out)
+    got = synth.unpack_ints(gather_natural(out, eng.n1, eng.n2, world).numpy().tobytes())
+    want = po.schoolbook_mul(a, b)
+    ok &= got[:len(want)] == want and not any(got[len(want):])
+    # exact quotient (a * b) / b on the coset of offset = generator, like fast_stark.py:113
+    prod = want
+    q = torch.empty(eng.local_shape(True), dtype=torch.int64)
+    eng.coset_divide(eng.slab_of(as_t(prod), "ta").clone(), eng.slab_of(as_t(b), "tb").clone(), po.GENERATOR, q)
+    gq = synth.unpack_ints(gather_natural(q, eng.n1, eng.n2, world).numpy().tobytes())
+    ok &= gq[:la] == a and not any(gq[la:])
+    # divisor vanishing on the coset: the reference's field division asserts (algebra.py:92)
+    zero_at = po.GENERATOR                                   # (X - offset*root^0) has a zero on the coset
+    try:
+        eng.coset_divide(eng.slab_of(as_t(prod), "ta").clone(), eng.slab_of(as_t([(-zero_at) % P, 1]), "tb").clone(), po.GENERATOR, q)
+        ok = False
+    except AssertionError as e:
+        ok &= "divide by zero" in str(e)
+    # natural contiguous chunks <-> column slabs
+    full = np.frombuffer(synth.synth_packed(31, n).tobytes(), dtype=np.int64).reshape(eng.n1, eng.n2, 2)
+    rw = eng.n1 // world
+    chunk = torch.from_numpy(full[rank * rw:(rank + 1) * rw].copy())
+    slab = rows_to_column_slab(chunk, eng.n1, eng.n2, rank, world)
+    cw = eng.n2 // world
+    ok &= torch.equal(slab, torch.from_numpy(full[:, rank * cw:(rank + 1) * cw].copy()))
+    ok &= torch.equal(column_slab_to_rows(slab, eng.n1, eng.n2, rank, world), chunk)
+    return bool(ok)
 
 
 if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "fri"):

@@ -213,3 +213,45 @@ def test_sharded_lde_then_sharded_fri_one_rank(sc):
     top = ShardedFri(fr, eng.n1, 0, 1, dev).prove(slab, ps)
     assert top == rec["top_level_indices"]
     assert hashlib.sha256(ps.serialize()).hexdigest() == rec["serialized_sha256"]
+
+
+def _run_bench(args, timeout=900):
+    """bench.py from a BARE shell (no RANK / WORLD_SIZE in the environment), exactly as the driver's `python3 bench.py --gpus N`"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_bare_launch_two_ranks_and_census_parity(sc):
+    """`python bench.py --gpus 2` must launch itself (one rank per GPU; on this 1-GPU box the two ranks share
+    the device and exchange through gloo, labelled as such), carry the config-5 census on the sharded layout, and the census
+    must produce the SAME commitments and the SAME proof whatever the world size -- and the oracle's commitment."""
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--log2n", "16", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["roundtrip_bit_exact"] is True
+    assert "fourstep_2gpu" in out["config"]["workload"] and out["value"] > 0
+    assert "gloo" in out["config"]["collective_backend"] and "NOT a scaling measurement" in out["config"]["collective_backend"]
+    assert out["config"]["all_to_all_bytes_sent_per_rank_per_step"] == 2 * (1 << 15) * 16 // 2
+    c2 = out["extras"]["stark_census_sharded"]
+    assert "error" not in c2, c2
+    for k in ("lde_and_commit_ms", "coset_divide_ms", "fri_prove_ms", "openings_ms", "total_ms"):
+        assert c2[k] > 0
+    assert c2["world_size"] == 2 and c2["all_to_all_bytes_sent_per_rank"] > 0
+    # the same census as the timed workload on 1 and 4 ranks
+    c1 = _run_bench(["--gpus", "1", "--workload", "stark_census", "--log2n", "16", "--steps", "1", "--warmup", "1"])
+    c4 = _run_bench(["--gpus", "4", "--workload", "stark_census", "--log2n", "16", "--steps", "1", "--warmup", "1"])
+    assert c1["metric"] == "stark_census_ms" and c1["higher_is_better"] is False and c4["n_gpus"] == 4
+    s1, s4 = c1["stages_best_run"], c4["stages_best_run"]
+    assert s1["proof_sha256_16"] == s4["proof_sha256_16"] == c2["proof_sha256_16"]
+    assert s1["roots"] == s4["roots"] == c2["roots"] and s1["fri_rounds"] == s4["fri_rounds"] == 9
+    assert s1["all_to_all_bytes_sent_per_rank"] == 0 and s4["all_to_all_bytes_sent_per_rank"] > 0
+    # commitment of the first LDE against the oracle (code/fast_stark.py:104-105 on code/ntt.py:132-135)
+    Nf, No = 1 << 16, 1 << 14
+    coeffs = synth.synth_packed(60, No // 2).tobytes()
+    lde = po.C.coset_evaluate(coeffs, No // 2, po.GENERATOR, po.primitive_nth_root(Nf), Nf)
+    assert po.C.merkle_commit(lde, Nf).hex()[:16] == s1["roots"][0]
