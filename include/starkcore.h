@@ -90,6 +90,10 @@ int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch
  * kind 1 may read its input as [chunks][batch][len/chunks] (the layout all_to_all_single delivers) instead of [batch][len]. */
 int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2],
                         const uint64_t outer_root[2], uint64_t outer_order, uint64_t outer_col_base, int outer_scale_ninv, uint64_t chunks, void* stream);
+/* kind 1 for ONE ROW BLOCK of the corner turn (overlap of the all-to-all with the row stage): transforms `batch` rows given as
+ * [chunks][batch][len/chunks] and writes them as `batch` adjacent columns of a wider transposed output [len][out_ld]
+ * (d_out points at the block's first column). */
+int sc_ntt_rows_t_ld_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, const uint64_t root[2], uint64_t chunks, uint64_t out_ld, void* stream);
 /* d_data[r][c] *= root^((row_base + r) * (col_base + c)) * scale, root of order `order` (scale may be NULL = 1) */
 int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t row_base, uint64_t col_base, const uint64_t root[2], uint64_t order,
                           const uint64_t scale[2], void* stream);

@@ -227,6 +227,9 @@ struct BatchExtras {
     // direct table of the inter-pass twiddles of a two-pass plan: [k < 2^digits[0]][b < len >> digits[0]] = w_len^(b*k)
     // (one coalesced load + one modmul per element instead of the two-level lookup's two loads + two modmuls)
     const Fe* inner_twd = nullptr;
+    // BATCH_ROWS_T: leading dimension of the transposed output (0 = batch): the rows of this call are `batch` adjacent columns
+    // of a wider [len][out_ld] matrix -- a row block of the corner turn transformed as soon as it has landed (overlap)
+    uint64_t out_ld = 0;
 };
 
 inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, const NttTables& tb,
@@ -349,10 +352,11 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
                 p.in_split = logR - ex.chunks_log;
                 p.in_rs_hi = (len >> ex.chunks_log) << logbatch;
             }
+            const uint64_t ld = ex.out_ld ? ex.out_ld : batch;
             p.out_cs = 1;
             p.out_hi = 1ull << logC;
-            p.out_mid = batch;
-            p.out_rs = batch << logA;
+            p.out_mid = ld;
+            p.out_rs = ld << logA;
             p.rfast_load = 1;
             p.tw_enable = 0;
             pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));

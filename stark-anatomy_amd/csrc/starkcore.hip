@@ -1168,8 +1168,8 @@ int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int in
 }
 
 // ---- batched transforms + outer twiddle (building blocks of the multi-GPU four-step NTT)
-int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2],
-                        const uint64_t outer_root[2], uint64_t outer_order, uint64_t outer_col_base, int outer_scale_ninv, uint64_t chunks, void* stream) {
+static int batch_ex_impl(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2],
+                         const uint64_t outer_root[2], uint64_t outer_order, uint64_t outer_col_base, int outer_scale_ninv, uint64_t chunks, uint64_t out_ld, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     hipStream_t st = pick_stream(stream);
@@ -1187,6 +1187,10 @@ int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t ba
     tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
     BatchExtras ex;
     ex.chunks_log = ilog2(chunks);
+    if (out_ld) {
+        if (kind != 1 || out_ld < batch) return fail(SC_ERR_BAD_ARG, "an output leading dimension belongs to kind 1 and must be >= batch");
+        ex.out_ld = out_ld;
+    }
     if (outer_root) {
         if (!is_pow2(outer_order) || outer_order < len * batch) return fail(SC_ERR_BAD_ARG, "outer twiddle order too small");
         if ((len - 1) * (outer_col_base + batch - 1) >= outer_order) return fail(SC_ERR_BAD_ARG, "outer twiddle exponent out of range");
@@ -1210,6 +1214,15 @@ int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t ba
     if (d.npasses == 2 && kind == 0 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "two-pass column transform must be out of place");
     if (kind == 1 && d_in == d_out) return fail(SC_ERR_BAD_ARG, "transposing row transform must be out of place");
     return run_plan(d, st);
+}
+
+int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2],
+                        const uint64_t outer_root[2], uint64_t outer_order, uint64_t outer_col_base, int outer_scale_ninv, uint64_t chunks, void* stream) {
+    return batch_ex_impl(d_in, d_out, len, batch, kind, root, outer_root, outer_order, outer_col_base, outer_scale_ninv, chunks, 0, stream);
+}
+
+int sc_ntt_rows_t_ld_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, const uint64_t root[2], uint64_t chunks, uint64_t out_ld, void* stream) {
+    return batch_ex_impl(d_in, d_out, len, batch, 1, root, nullptr, 0, 0, 0, chunks, out_ld, stream);
 }
 
 int sc_ntt_batch_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, int kind, const uint64_t root[2], void* stream) {

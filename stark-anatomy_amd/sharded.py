@@ -115,14 +115,32 @@ class HipEngine:
         return True
 
 
+    def rows_ntt_t_block(self, src, dst, col0, length, batch, chunks, root, out_ld):
+        """one ROW BLOCK of the corner turn: `batch` rows given as [chunks][batch][length/chunks] -> columns [col0, col0 + batch)
+        of the transposed output dst [length][out_ld]"""
+        rc = self.lib.sc_ntt_rows_t_ld_dev(src.data_ptr(), dst.data_ptr() + 16 * col0, length, batch, _fe(root), chunks, out_ld, self.sptr)
+        if rc == -7:
+            return False
+        self.sc._check(rc)
+        return True
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
 class ShardedNtt:
-    def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False):
+    def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False, overlap_chunks=4):
         assert world & (world - 1) == 0, "world size must be a power of two"
         self.log2n, self.n = log2n, 1 << log2n
         self.root = int(root)
         assert pow(self.root, self.n, P) == 1 and pow(self.root, self.n // 2, P) != 1, "root must be a primitive n-th root"
         self.rank, self.world, self.device, self.group = rank, world, device, group
         self.always_exchange = always_exchange     # run the all-to-all even for a world of one rank (exercises the RCCL path)
+        # the corner turn is issued as this many row blocks; the row stage of block q runs while blocks q+1.. are still in
+        # flight on the collective's own stream (1 = one blocking all_to_all_single)
+        self.overlap_chunks = overlap_chunks
         # n = n1 * n2.  Small domains: square split.  Large ones: n1 = 2^8, so that the column stage of forward() is ONE
         # pass (256-point transforms) and the row stage two, and the other way round for inverse(): 3 passes per
         # transform instead of 4 (measured per-rank compute at 2^21 local elements: 138 us -> see profiles/).
@@ -231,12 +249,59 @@ class ShardedNtt:
         if G == 1 and not self.always_exchange:
             self.stage_rows(a, dst, R, C, root)
             return
+        if fused and self._transform_overlapped(a, dst, R, C, root):
+            return
         recv = self._buf("recv", (G, rw, cw, 2))
         self._all_to_all(recv, a)
         # (4) row transforms straight from the chunked layout the all-to-all left behind
         if fused and eng.rows_ntt_t_chunked(recv, dst, C, rw, G, pow(root, R, P)):
             return
         self.stage_rows(self.assemble_rows(recv, R, C), dst, R, C, root)
+
+    def _transform_overlapped(self, a, dst, R, C, root):
+        """(3)+(4) pipelined: the rows each rank receives are split into K blocks; block q's exchange is a grouped send/recv
+        of G messages (all links busy, like the single collective), issued asynchronously one after the other, and the row
+        transforms of block q start as soon as it has landed -- while blocks q+1.. are still on the wire.  Returns False
+        (nothing issued) when the shapes do not allow it; the caller then runs the blocking form."""
+        eng, G, K = self.engine, self.world, self.overlap_chunks
+        rw, cw = R // G, C // G
+        if K <= 1 or rw % K or not hasattr(eng, "rows_ntt_t_block"):
+            return False
+        rk = rw // K
+        if rk & (rk - 1):
+            return False
+        a5 = a.view(G, K, rk, cw, 2)
+        recv = self._buf("recv_blocks", (K, G, rk, cw, 2))
+        works = [self._all_to_all_blocks(recv[q], [a5[h, q] for h in range(G)]) for q in range(K)]
+        root_rows = pow(root, R, P)
+        done = True
+        for q in range(K):
+            works[q].wait()
+            if done and not eng.rows_ntt_t_block(recv[q], dst, q * rk, C, rk, G, root_rows, rw):
+                done = False                              # shape not supported by the fused kernel: finish the exchange, then
+        if not done:                                      # transform from the reassembled rows
+            rows = self._buf("rows", (rw, G, cw, 2))
+            rows.view(K, rk, G, cw, 2).copy_(recv.permute(0, 2, 1, 3, 4))
+            self.stage_rows(rows.view(rw, C, 2), dst, R, C, root)
+        return True
+
+    def _all_to_all_blocks(self, recv_q, send_blocks):
+        """one row block of the corner turn: block h of `send_blocks` goes to rank h, recv_q[g] comes from rank g.  Asynchronous on
+        the collective's own stream (RCCL) / thread (gloo on CPU tensors); returns a work handle with wait()."""
+        G = self.world
+        self.bytes_exchanged += sum(b.numel() for b in send_blocks) * 8 * (G - 1) // G
+        if dist.get_backend(self.group) == "gloo":
+            # gloo has no list all-to-all: gather the G blocks into one contiguous send buffer and use the single form.
+            # Device tensors (functional tests: ranks sharing one GPU) are staged through the host, synchronously.
+            send = torch.stack([b for b in send_blocks], dim=0)
+            if recv_q.is_cuda:
+                host = torch.empty(recv_q.shape, dtype=recv_q.dtype)
+                dist.all_to_all_single(host.view(-1), send.cpu().view(-1), group=self.group)
+                recv_q.copy_(host)
+                return _DoneWork()
+            return dist.all_to_all_single(recv_q.view(-1), send.view(-1), group=self.group, async_op=True)
+        # RCCL: grouped send/recv straight from the strided blocks of the slab (no staging copy)
+        return dist.all_to_all(list(recv_q.unbind(0)), list(send_blocks), group=self.group, async_op=True)
 
     def slab_of(self, coeffs, key="slab_of"):
         """This rank's column slab [n1][n2/G] (zero-padded) of a coefficient vector `coeffs` [m][2] that is REPLICATED on every
@@ -359,36 +424,49 @@ class HipFriEngine:
         def open(self, indices):
             return self.tree.open_batch(list(indices))
 
+    def _stream(self):
+        """The primitives run on torch's CURRENT stream, so they are ordered with the tensor ops and collectives around them and
+        need no synchronization of their own.  Only under torch's null stream (which the library cannot share) they run on the
+        library stream between two explicit synchronizations."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == 0:
+            cur.synchronize()
+            return None
+        return self.ctypes.c_void_p(cur.cuda_stream)
+
+    def _done(self, sptr):
+        if sptr is None:
+            self.sc.synchronize()
+
     def tree(self, elems):
         """Merkle tree over a contiguous tensor of field elements [..., 2]."""
         elems = elems.contiguous()
-        torch.cuda.current_stream(self.device).synchronize()
-        return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr(elems.data_ptr(), elems.numel() // 2), elems)
+        return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr(elems.data_ptr(), elems.numel() // 2, self._stream()), elems)
 
     def level(self, tree, level):
         count = tree.tree.n >> level
         out = torch.empty((count, 8), dtype=torch.int64, device=self.device)
-        tree.tree.copy_level(level, out.data_ptr())
-        self.sc.synchronize()
+        sptr = self._stream()
+        tree.tree.copy_level(level, out.data_ptr(), sptr)
+        self._done(sptr)
         return out
 
     def tree_from_digests(self, digests):
         digests = digests.contiguous()
-        torch.cuda.current_stream(self.device).synchronize()
-        return HipFriEngine._Tree(self.sc.MerkleTree.from_digests_ptr(digests.data_ptr(), digests.numel() // 8), digests)
+        return HipFriEngine._Tree(self.sc.MerkleTree.from_digests_ptr(digests.data_ptr(), digests.numel() // 8, self._stream()), digests)
 
     def fold_slab(self, src, rows, cols, R, col_base, alpha, offset, omega):
         dst = torch.empty((rows // 2, cols, 2), dtype=torch.int64, device=self.device)
-        torch.cuda.current_stream(self.device).synchronize()
-        self.sc._check(self.lib.sc_fri_fold_slab_dev(src.data_ptr(), rows, cols, R, col_base, _fe(alpha), _fe(offset), _fe(omega), dst.data_ptr(), None))
-        self.sc.synchronize()
+        sptr = self._stream()
+        self.sc._check(self.lib.sc_fri_fold_slab_dev(src.data_ptr(), rows, cols, R, col_base, _fe(alpha), _fe(offset), _fe(omega), dst.data_ptr(), sptr))
+        self._done(sptr)
         return dst
 
     def fold_full(self, src, N, alpha, offset, omega):
         dst = torch.empty((N // 2, 2), dtype=torch.int64, device=self.device)
-        torch.cuda.current_stream(self.device).synchronize()
-        self.sc._check(self.lib.sc_fri_fold_dev(src.data_ptr(), N, _fe(alpha), _fe(offset), _fe(omega), dst.data_ptr(), None))
-        self.sc.synchronize()
+        sptr = self._stream()
+        self.sc._check(self.lib.sc_fri_fold_dev(src.data_ptr(), N, _fe(alpha), _fe(offset), _fe(omega), dst.data_ptr(), sptr))
+        self._done(sptr)
         return dst
 
     def lde(self, coeffs, offset, generator, order):
@@ -396,9 +474,10 @@ class HipFriEngine:
         m = len(coeffs) // 16
         src = self.sc.DeviceVector.from_bytes(coeffs) if m else self.sc.DeviceVector(1)
         out = torch.empty((order, 2), dtype=torch.int64, device=self.device)
-        torch.cuda.current_stream(self.device).synchronize()
-        self.sc._check(self.lib.sc_coset_evaluate_dev(src.ptr, m, _fe(offset), _fe(generator), order, out.data_ptr(), None))
-        self.sc.synchronize()
+        sptr = self._stream()
+        self.sc._check(self.lib.sc_coset_evaluate_dev(src.ptr, m, _fe(offset), _fe(generator), order, out.data_ptr(), sptr))
+        torch.cuda.current_stream(self.device).synchronize()      # `src` is freed on return: its reader must be done
+        self._done(sptr)
         return out
 
     def read(self, elems, flat_indices):
@@ -470,35 +549,52 @@ class ShardedFri:
         """the whole codeword in natural order on every rank: [C][R/G] slabs -> [C*R]"""
         return self._all_gather(slab).permute(1, 0, 2, 3).reshape(C * self.R, 2).contiguous()
 
-    def _open_raw(self, layer, indices):
-        """(values, paths) for global indices of one committed codeword; collective for sharded layers."""
+    def _open_many_raw(self, requests):
+        """[(values, paths)] for a list of (layer, global indices).  ONE collective for all of them: every rank answers the
+        entries whose columns it owns (value + the bottom of the path, from its local subtree); the tops of the paths come
+        from the replicated top tree."""
         eng = self.engine
-        if layer["kind"] == "local":
-            return eng.read(layer["vec"], indices), layer["tree"].open(indices) if layer["length"] > 1 else [[] for _ in indices]
         R, Rw, G, g = self.R, self.Rw, self.world, self.rank
         sub_level = Rw.bit_length() - 1
-        mine = [(pos, i) for pos, i in enumerate(indices) if (i % R) // Rw == g]
-        local_idx = [(i // R) * Rw + (i % R) % Rw for _, i in mine]
-        vals = eng.read(layer["slab"], local_idx)
-        bottoms = [p[:sub_level] for p in layer["local"].open(local_idx)] if mine else []
-        shared = self._all_gather_object([(pos, v, b) for (pos, _), v, b in zip(mine, vals, bottoms)])
-        values, bottom = [None] * len(indices), [None] * len(indices)
-        for part in shared:
-            for pos, v, b in part:
-                values[pos], bottom[pos] = v, b
-        tops = layer["top"].open([(i // R) * G + (i % R) // Rw for i in indices]) if layer["C"] * G > 1 else [[] for _ in indices]
-        return values, [list(b) + list(t) for b, t in zip(bottom, tops)]
+        mine_all = []
+        for layer, indices in requests:
+            if layer["kind"] != "sharded":
+                mine_all.append(None)
+                continue
+            mine = [(pos, i) for pos, i in enumerate(indices) if (i % R) // Rw == g]
+            local_idx = [(i // R) * Rw + (i % R) % Rw for _, i in mine]
+            vals = eng.read(layer["slab"], local_idx)
+            bottoms = [p[:sub_level] for p in layer["local"].open(local_idx)] if mine else []
+            mine_all.append([(pos, v, b) for (pos, _), v, b in zip(mine, vals, bottoms)])
+        shared = self._all_gather_object(mine_all) if any(m is not None for m in mine_all) else [mine_all]
+        out = []
+        for q, (layer, indices) in enumerate(requests):
+            if layer["kind"] == "local":
+                out.append((eng.read(layer["vec"], indices), layer["tree"].open(indices) if layer["length"] > 1 else [[] for _ in indices]))
+                continue
+            values, bottom = [None] * len(indices), [None] * len(indices)
+            for part in shared:
+                for pos, v, b in part[q]:
+                    values[pos], bottom[pos] = v, b
+            tops = layer["top"].open([(i // R) * G + (i % R) // Rw for i in indices]) if layer["C"] * G > 1 else [[] for _ in indices]
+            out.append((values, [list(b) + list(t) for b, t in zip(bottom, tops)]))
+        return out
+
+    def _open_many(self, requests):
+        """entries as FieldElement objects (one object per index and layer, reused) + fresh path objects per request"""
+        from algebra import FieldElement
+        res = []
+        for (layer, indices), (values, paths) in zip(requests, self._open_many_raw(requests)):
+            cache, ents = layer["cache"], []
+            for i, v in zip(indices, values):
+                if i not in cache:
+                    cache[i] = FieldElement(v, self.fri.field)
+                ents.append(cache[i])
+            res.append((ents, paths))
+        return res
 
     def _open(self, layer, indices):
-        """entries as FieldElement objects (one object per index, reused) + fresh path objects per request"""
-        from algebra import FieldElement
-        values, paths = self._open_raw(layer, indices)
-        cache, out = layer["cache"], []
-        for i, v in zip(indices, values):
-            if i not in cache:
-                cache[i] = FieldElement(v, self.fri.field)
-            out.append(cache[i])
-        return out, paths
+        return self._open_many([(layer, indices)])[0]
 
     # -- the protocol -----------------------------------------------------------------------------
     def prove(self, slab, proof_stream):
@@ -546,14 +642,15 @@ class ShardedFri:
         for i in range(nq):
             indices = [index % (layers[i]["length"] // 2) for index in indices]
             per_round.append(indices)
-        fetched = []
+        requests = []
         for j, layer in enumerate(layers):
             request = []
             if j < nq:
                 request += per_round[j][:s] + [index + layer["length"] // 2 for index in per_round[j][:s]]
             if j > 0:
                 request += per_round[j - 1][:s]
-            fetched.append(self._open(layer, request))
+            requests.append((layer, request))
+        fetched = self._open_many(requests)                 # one collective for the whole query phase
         for i in range(nq):
             entries, paths = fetched[i]
             next_entries, next_paths = fetched[i + 1]

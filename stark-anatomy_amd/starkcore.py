@@ -40,6 +40,7 @@ SIGNATURES = {
     "sc_ntt_dev": (_int, [_vp, _vp, _u64, _vp, _int, _vp]),
     "sc_ntt_batch_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp]),
     "sc_ntt_batch_ex_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _u64, _int, _u64, _vp]),
+    "sc_ntt_rows_t_ld_dev": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _vp]),
     "sc_twiddle_matrix_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _u64, _vp, _vp]),
     "sc_coset_evaluate": (_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     "sc_coset_evaluate_dev": (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
@@ -300,19 +301,20 @@ class MerkleTree:
         return cls(h, root.raw, n)
 
     @classmethod
-    def from_device_ptr(cls, ptr, n):
-        """tree over n field elements at a raw device pointer (e.g. a torch tensor's storage)"""
+    def from_device_ptr(cls, ptr, n, stream=None):
+        """tree over n field elements at a raw device pointer (e.g. a torch tensor's storage); built on `stream` (a
+        ctypes.c_void_p hipStream_t; None = the library's), which is synchronized before the root is returned"""
         root = ctypes.create_string_buffer(64)
         h = _vp()
-        _check(lib().sc_merkle_build_dev(ptr, n, root, ctypes.byref(h), None))
+        _check(lib().sc_merkle_build_dev(ptr, n, root, ctypes.byref(h), stream))
         return cls(h, root.raw, n)
 
     @classmethod
-    def from_digests_ptr(cls, ptr, count):
+    def from_digests_ptr(cls, ptr, count, stream=None):
         """tree whose level 0 is `count` given 64-byte digests at a raw device pointer"""
         root = ctypes.create_string_buffer(64)
         h = _vp()
-        _check(lib().sc_merkle_from_digests_dev(ptr, count, root, ctypes.byref(h), None))
+        _check(lib().sc_merkle_from_digests_dev(ptr, count, root, ctypes.byref(h), stream))
         return cls(h, root.raw, count)
 
     def copy_level(self, level, dst_ptr, stream=None):

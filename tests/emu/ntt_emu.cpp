@@ -122,9 +122,9 @@ extern "C" void emu_field(const uint64_t* a, const uint64_t* b, uint64_t* out /*
 }
 
 // batched transforms (multi-GPU building blocks): kind 0 = columns of [len][batch], kind 1 = rows of [batch][len] -> [len][batch]
-extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,
+static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,
                                int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log,
-                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log, int inner_direct) {
+                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log, int inner_direct, uint64_t out_ld) {
     const uint64_t len = 1ull << loglen, batch = 1ull << logbatch;
     Fe r_m = to_mont(Fe{root[0], root[1]});
     NttTuning tu;
@@ -139,6 +139,7 @@ extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int 
     std::vector<Fe> work(len * batch);
     BatchExtras ex;
     ex.chunks_log = chunks_log;
+    ex.out_ld = out_ld;
     std::vector<Fe> otl, oth;
     if (outer_root) {
         Fe o_m = to_mont(Fe{outer_root[0], outer_root[1]});
@@ -169,4 +170,18 @@ extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int 
         }
     }
     return d.npasses;
+}
+
+extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,
+                               int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log,
+                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log, int inner_direct) {
+    return emu_batched_impl(in, out, kind, loglen, logbatch, root, max_tile_log, loge, min_tiles_log, max_col_log, max_digit_log,
+                            outer_root, outer_logorder, outer_col_base, outer_ninv, chunks_log, inner_direct, 0);
+}
+
+// one row block of the overlapped corner turn: kind 1, chunked input, `2^logbatch` adjacent columns of a [len][out_ld] output
+extern "C" int emu_ntt_rows_ld(const uint64_t* in, uint64_t* out, int loglen, int logbatch, const uint64_t* root,
+                               int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log, int chunks_log, int inner_direct, uint64_t out_ld) {
+    return emu_batched_impl(in, out, 1, loglen, logbatch, root, max_tile_log, loge, min_tiles_log, max_col_log, max_digit_log,
+                            nullptr, 0, 0, 0, chunks_log, inner_direct, out_ld);
 }

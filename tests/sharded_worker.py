@@ -63,14 +63,39 @@ class OracleEngine:
                 a[r, c, 0], a[r, c, 1] = v & ((1 << 64) - 1), v >> 64
 
 
+class FusedOracleEngine(OracleEngine):
+    """The fused / chunked entry points of the HIP engine, served by the oracle: lets the overlapped corner turn (row blocks
+    exchanged asynchronously, each transformed as it lands) run under gloo on the CPU."""
+
+    def cols_ntt_twiddled(self, src, dst, length, batch, root, outer_root, order, col_base, scale_ninv):
+        self.cols_ntt(src, dst, length, batch, root)
+        self.twiddle(dst, length, batch, 0, col_base, outer_root, order, pow(order, P - 2, P) if scale_ninv else 1)
+        return True
+
+    def _rows_from_chunks(self, src, length, batch, chunks):
+        a = self._np(src).reshape(chunks, batch, length // chunks, 2)
+        return np.ascontiguousarray(a.transpose(1, 0, 2, 3)).reshape(batch, length, 2)
+
+    def rows_ntt_t_chunked(self, src, dst, length, batch, chunks, root):
+        self.rows_ntt_t(torch.from_numpy(self._rows_from_chunks(src, length, batch, chunks).view(np.int64)), dst, length, batch, root)
+        return True
+
+    def rows_ntt_t_block(self, src, dst, col0, length, batch, chunks, root, out_ld):
+        rows = self._rows_from_chunks(src, length, batch, chunks)
+        out = self._np(dst).reshape(length, out_ld, 2)
+        for r in range(batch):
+            out[:, col0 + r, :] = np.frombuffer(po.C.ntt(root, rows[r].tobytes(), length), dtype=np.uint64).reshape(length, 2)
+        return True
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ok = True
-    for log2n in (6, 7, 10):
+    for log2n, engine, chunks in ((6, OracleEngine(), 4), (7, FusedOracleEngine(), 2), (10, FusedOracleEngine(), 4), (10, FusedOracleEngine(), 1), (10, OracleEngine(), 4)):
         n = 1 << log2n
         root = po.primitive_nth_root(n)
-        eng = ShardedNtt(log2n, root, rank, world, torch.device("cpu"), engine=OracleEngine())
+        eng = ShardedNtt(log2n, root, rank, world, torch.device("cpu"), engine=engine, overlap_chunks=chunks)
         x = eng.synthetic_input(seed=3)
         assert tuple(x.shape) == eng.local_shape(True)
         y = torch.empty(eng.local_shape(False), dtype=torch.int64)

@@ -177,3 +177,16 @@ def test_emu_batched(emu, cfg):
             rc = emu.emu_ntt_batched(chunked, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, None, 0, 0, 0, chunks_log, chunks_log & 1)
             assert rc > 0, (cfg, chunks_log)
             assert out.raw == expect, (cfg, chunks_log)
+            # the same rows as ROW BLOCKS of an overlapped corner turn: each block of bt/2 rows is transformed on its own and
+            # written as bt/2 adjacent columns of the full [len][bt] output (leading dimension bt)
+            if bt >= 2:
+                emu.emu_ntt_rows_ld.restype = ctypes.c_int
+                emu.emu_ntt_rows_ld.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_uint64]
+                wide = ctypes.create_string_buffer(16 * total)
+                half = bt // 2
+                for blk in range(2):
+                    part = np.ascontiguousarray(a[blk * half:(blk + 1) * half].transpose(1, 0, 2, 3)).tobytes()
+                    dst = ctypes.c_void_p(ctypes.addressof(wide) + 16 * blk * half)
+                    rc = emu.emu_ntt_rows_ld(part, dst, loglen, logbatch - 1, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, chunks_log, 1, bt)
+                    assert rc > 0, (cfg, chunks_log, blk)
+                assert wide.raw == expect, (cfg, chunks_log, "row blocks")
