@@ -1,0 +1,88 @@
+"""Full-size parity for BASELINE configs[3] and configs[4]: the workloads bench.py times, checked against
+the oracle at their real sizes.
+
+configs[3]  Fri.prove on a 2^22 codeword (ef 4, 40 checks; reference code/fri.py:115-130, code/test_fri.py:36-47):
+            the LDE, EVERY round's Merkle root, every folded codeword (through its root) and the last codeword against the C
+            oracle; the Fiat-Shamir indices recomputed; the whole proof through Fri.verify (1 680 openings re-hashed with hashlib).
+configs[4]  the FastStark call census at a 2^24 FRI domain (code/fast_stark.py:101-151): the four-step (sharded-layout) path
+            and the plain single-GPU path must produce the same commitments and the same proof bytes; one commitment
+            against the C oracle's LDE + Merkle tree of 2^24 leaves."""
+import hashlib
+import os
+import sys
+
+import pytest
+
+from conftest import REPO
+from oracle import py_oracle as po
+import synth
+
+pytestmark = pytest.mark.gpu
+C = po.C
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import starkcore
+    assert starkcore.device_count() > 0, "no GPU visible"
+    starkcore.init()
+    return starkcore
+
+
+def test_fri_prove_2p22_against_oracle(sc):
+    from algebra import Field
+    from fri import Fri
+    from ip import ProofStream
+    field = Field.main()
+    N, m = 1 << 22, 1 << 20
+    om = field.primitive_nth_root(N)
+    coeffs = synth.synth_packed(4002, m).tobytes()
+    cwv = sc.DeviceVector(N)
+    src = sc.DeviceVector.from_bytes(coeffs)
+    sc._check(sc.lib().sc_coset_evaluate_dev(src.ptr, m, sc.fe_bytes(po.GENERATOR), sc.fe_bytes(om.value), N, cwv.ptr, None))
+    sc.synchronize()
+    codeword = C.coset_evaluate(coeffs, m, po.GENERATOR, om.value, N)          # oracle LDE (code/ntt.py:132-135)
+    assert cwv.to_bytes() == codeword
+    fr = Fri(field.generator(), om, N, 4, 40)
+    assert fr.num_rounds() == 15
+    ps = ProofStream()
+    top = fr.prove(sc.DeviceCodeword(cwv, field), ps)
+    # the commit phase replayed by the oracle: root, alpha from the transcript so far, fold (code/fri.py:56-96)
+    replay = ProofStream()
+    omega, offset, cur, n = om.value, po.GENERATOR, codeword, N
+    for r in range(15):
+        root = C.merkle_commit(cur, n)
+        assert ps.objects[r] == root, "round %d root" % r
+        replay.push(root)
+        if r == 14:
+            break
+        alpha = field.sample(replay.prover_fiat_shamir()).value
+        cur = C.fold(cur, n, alpha, offset, omega)
+        omega, offset, n = omega * omega % po.P, offset * offset % po.P, n // 2
+    assert n == 256 and [e.value for e in ps.objects[15]] == synth.unpack_ints(cur)        # last codeword in the clear (fri.py:91)
+    replay.push(ps.objects[15])
+    assert top == fr.sample_indices(replay.prover_fiat_shamir(), N // 2, 256, 40)
+    assert len(ps.objects) == 15 + 1 + 14 * 40 * 4                                          # 14 query rounds x (40 triples + 120 paths)
+    assert fr.verify(ps, []) is True                                                        # colinearity + 1 680 Merkle paths (hashlib)
+
+
+def test_stark_census_2p24_two_paths_and_oracle(sc):
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    from algebra import Field
+    field = Field.main()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        times, info = bench.sharded_census(24, 0, 1, dev, stream)
+    plain = bench.stark_census(sc, sc.lib(), field, 24)
+    assert info["fri_rounds"] == plain["fri_rounds"] == 17
+    assert info["roots"] == plain["roots"]
+    assert info["proof_objects"] == plain["proof_objects"] == 3 + 17 + 1 + 16 * 40 * 4 + 3 * 160 * 2
+    assert info["proof_sha256_16"] == plain["proof_sha256_16"]          # four-step slab path == plain path, byte for byte
+    # one commitment against the oracle at full size
+    Nf, No = 1 << 24, 1 << 22
+    coeffs = synth.synth_packed(60, No // 2).tobytes()
+    lde = C.coset_evaluate(coeffs, No // 2, po.GENERATOR, po.primitive_nth_root(Nf), Nf)
+    assert C.merkle_commit(lde, Nf).hex()[:16] == info["roots"][0]
