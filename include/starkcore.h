@@ -53,7 +53,7 @@ const char* sc_last_error(void);
 int sc_synchronize(void);              /* wait for the library stream */
 /* tuning knobs for experiments (defaults are the measured optimum; -1 = choose by size where applicable): key in
  * {"max_tile_log","loge","max_col_log","min_tiles_log","single_pass_max_log","max_digit_log","direct_tw_max_log",
- *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","tw_on_load"}.  Plans are re-derived on the next call; results
+ *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune"}.  Plans are re-derived on the next call; results
  * never depend on the tuning. */
 int sc_set_tuning(const char* key, int value);
 /* diagnostics (tools/pass_trace.py): while d_buf != NULL every geometry-specialised NTT pass launch writes 16 u64 per wave

@@ -20,6 +20,7 @@ struct NttTuning {
     // ab_redc_waveLocal_twOnLoad.txt): +1-2 % from 2^22 up, where other workgroups hide the longer load phase; -5 % at 2^20,
     // where the grid is a single wave of workgroups and the doubled load burst (table + data) is exposed.  -1 = by size.
     int tw_on_load = -1;
+    int prune = 1;               // skip the degenerate top stages of a zero-padded first pass (PassParams::prune_log)
 };
 
 inline NttTuning resolve_tuning(const NttTuning& in, int logn) {
@@ -187,6 +188,20 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
         pd.threads = 1u << (logT - loge);
         pd.lds_bytes = ((uint32_t)sizeof(Fe) << logT) + tile_twiddle_bytes(pd.p.logR);   // the tile, then its twiddles
         logA += logR;
+    }
+    if (tu.prune && io.in_limit < n && m > 1) {
+        // zero-padded input: rows j_1 >= ceil(in_limit / B) of the first pass are zero.  The fixed-shape kernels handle
+        // degenerate stages in their first two rounds only, so the count is capped at what those cover.
+        const int logR = d.digits[0];
+        const uint64_t B = n >> logR;
+        const uint64_t rows_nz = (io.in_limit + B - 1) / B;
+        int k = 0;
+        while (k < logR - 1 && ((uint64_t)1 << (logR - k - 1)) >= rows_nz && rows_nz > 0) ++k;
+        const int loge = d.pass[0].loge;
+        const int nr = (logR + loge - 1) / loge;
+        const int cap = (logR - loge * (nr - 1)) + (nr > 1 ? loge : 0);
+        if (k > cap) k = cap;
+        d.pass[0].p.prune_log = k;
     }
     if (tu.tw_on_load) {
         // twiddle-on-load: the table of pass i-1 is indexed like the work buffer it wrote (index mod R*B), so pass i can fetch

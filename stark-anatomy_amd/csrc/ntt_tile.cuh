@@ -66,6 +66,14 @@ struct PassParams {
     int coset_enable;          // x[j] *= offset^j (Polynomial.scale, univariate.py:153-154): ol[j & 4095] * oh[j >> 12]
     const Fe* ol;
     const Fe* oh;
+    // zero-padded input (LDE, fast_multiply): only the first R >> prune_log rows of every column are non-zero, so in the top
+    // prune_log stages every butterfly has v = 0 and degenerates to (u, u * w): no add/sub, and nothing at all where u is a
+    // zero row too (whole waves skip).  0 = off.
+    int prune_log;
+    // the grid is a single wave of workgroups (<= one per CU, e.g. 2^20): a wave lowers its priority as it advances through a
+    // round, so the waves of a SIMD reach the barrier together instead of the oldest always winning the VALU arbitration and
+    // the youngest finishing alone at half the issue rate (+2-4 % at 2^20; -3..5 % when other workgroups fill the gaps anyway)
+    int prio_balance;
     // diagnostics (tools/pass_trace.py): per-wave s_memtime stamps of the phases of a workgroup; nullptr in production
     unsigned long long* trace;
 };
@@ -179,14 +187,41 @@ struct Round {
 #pragma unroll
         for (int i = 0; i < E; ++i) x[i] = lds[lds_index(row(i, sh), cc[i >> S], logC)];
     }
-    // S radix-2 DIF stages on the field bits, highest bit first; tw[e << tw_shift] = w_R^e (LDS copy: shift 0)
-    SC_HD void butterflies(int sh, Fe* x, const Fe* tw, int tw_shift) const {
-        const bool last = (sh == 0);
+    // S radix-2 DIF stages on the field bits, highest bit first; tw[e << tw_shift] = w_R^e (LDS copy: shift 0).
+    // prune_log > 0: stages whose index from the top (0-based) is below it are the degenerate ones of a zero-padded input.
+    // last_hint: 1 / 0 when the caller knows whether this is the last round (sh == 0), -1 = look at sh.
+    SC_HD void butterflies(int sh, Fe* x, const Fe* tw, int tw_shift, int prune_log = 0, int last_hint = -1, int prio = 0) const {
+        const bool last = last_hint < 0 ? (sh == 0) : (last_hint != 0);
+        set_prio(prio, 3);
 #pragma unroll
         for (int q = 0; q < S; ++q) {
             const int bit = S - 1 - q;          // field bit
             const int b = sh + bit;             // row bit
-            const int tau = logR - 1 - b;       // twiddle exponent scale: w_R^(2^tau * (r mod 2^b))
+            const int tau = logR - 1 - b;       // twiddle exponent scale: w_R^(2^tau * (r mod 2^b)); also the stage index from the top
+            if (tau < prune_log) {
+                // v = 0 everywhere: (u, 0) -> (u, u * w).  Before this stage row r is non-zero iff (r mod 2^(b+1)) < R >> prune_log.
+                const uint32_t nz = 1u << (logR - prune_log);
+#pragma unroll
+                for (int i0 = 0; i0 < E; ++i0) {
+                    if (i0 & (1 << bit)) continue;
+                    const int i1 = i0 | (1 << bit);
+                    const int g = i0 >> S;
+                    const uint32_t fi_low = (uint32_t)(i0 & (F - 1)) & ((1u << bit) - 1u);
+                    const Fe u = x[i0];
+                    Fe d = fe_zero();
+                    if ((row(i0, sh) & ((2u << b) - 1u)) < nz) {
+                        if (last && (bit == 0 || fi_low == 0)) {
+                            d = u;
+                        } else {
+                            const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
+                            const uint32_t e = ((fi_low << sh) | row_lo) << tau;
+                            d = mont_mul(u, tw[(uint64_t)e << tw_shift]);
+                        }
+                    }
+                    x[i1] = d;
+                }
+                continue;
+            }
 #pragma unroll
             for (int i0 = 0; i0 < E; ++i0) {
                 if (i0 & (1 << bit)) continue;
@@ -196,15 +231,30 @@ struct Round {
                 Fe u = x[i0], v = x[i1];
                 x[i0] = fe_add(u, v);
                 Fe d = fe_sub(u, v);
-                if (b == 0 || (last && fi_low == 0)) {
-                    x[i1] = d;                  // twiddle is w^0 = 1
+                if (last && (bit == 0 || fi_low == 0)) {
+                    x[i1] = d;                  // twiddle is w^0 = 1 (row bit 0, or no low field bits in the last round)
                 } else {
                     const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
                     const uint32_t e = ((fi_low << sh) | row_lo) << tau;     // < R/2
                     x[i1] = mont_mul(d, tw[(uint64_t)e << tw_shift]);
                 }
+                if (q == 0 && i0 == 0) set_prio(prio, 2);
+                if (q == S - 1 && i0 == 0) set_prio(prio, 1);
+            }
+            if (q == S - 1) set_prio(prio, 0);
+        }
+    }
+    SC_HD static void set_prio(int enable, int level) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (enable) {
+            switch (level) {      // s_setprio takes an immediate
+                case 3: __builtin_amdgcn_s_setprio(3); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
             }
         }
+#endif
     }
     SC_HD void scatter_lds(int sh, const Fe* x, Fe* lds) const {
 #pragma unroll
@@ -247,7 +297,7 @@ SC_HD void ntt_round(const PassParams& P, int sh, bool first, uint32_t tile, uin
     } else {
         R.gather_lds(sh, x, lds);
     }
-    R.butterflies(sh, x, tw, 0);
+    R.butterflies(sh, x, tw, 0, P.prune_log, -1, P.prio_balance);
     if (sh == 0) R.scatter_global(P, x);
     else R.scatter_lds(sh, x, lds);
 }
@@ -309,7 +359,9 @@ struct FixedRounds {
         } else {
             R.gather_lds(SH, x, lds);
         }
-        R.butterflies(SH, x, tw, 0);
+        // the degenerate stages of a zero-padded input lie in the first two rounds (the planner caps prune_log accordingly)
+        const int prune = (ROUND <= 1) ? P.prune_log : 0;
+        R.butterflies(SH, x, tw, 0, prune, ROUND + 1 == NR ? 1 : 0, P.prio_balance);
         stamp(3 + 2 * ROUND);
         if constexpr (ROUND + 1 < NR) {
             R.scatter_lds(SH, x, lds);

@@ -71,9 +71,9 @@ __global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed
             }
         }
     };
-    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, tw, [] { __syncthreads(); },
-                                     [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); },
-                                     stamp, wave_local != 0);
+    auto sync = [] { __syncthreads(); };
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, tw, sync, wsync, stamp, wave_local != 0);
     if constexpr (TRACE) {
         if (trow && (threadIdx.x & 63u) == 0) { __builtin_amdgcn_s_waitcnt(0); trow[14] = __builtin_amdgcn_s_memtime(); trow[13] = __builtin_amdgcn_s_memrealtime(); }
     }
@@ -287,8 +287,10 @@ struct Ctx {
     uint64_t tick = 0;       // bumped by every table lookup
     bool foreign_streams = false;   // a caller-owned stream has been used (see pick_stream)
     DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
+    int num_cus = 256;
     int xcd_remap = 1;
     int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
+    int prio_balance = -1;   // -1: on for launches of at most one workgroup per CU, 0 / 1: force
     int wave_local = 1;      // wave-level fences instead of workgroup barriers once a tile's exchanges stay inside one wave
     unsigned long long* trace = nullptr;   // diagnostics: phase stamps of the next fixed-shape pass launches (sc_debug_trace)
     int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)
@@ -366,6 +368,7 @@ int ensure_init() {
     if (const char* sd = getenv("STARKCORE_DEVICE")) dev = atoi(sd) % n;
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g.num_cus = cus; }
     g.device = dev;
     g.init = true;
     return SC_OK;
@@ -537,13 +540,13 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
         // hot shapes of the default plans get geometry-specialised instantiations
         if (g.fixed_shapes) {
             const int lr = pd.p.logR, lc = pd.p.logC;
-#define SC_FIXED(LR, LC)                                                                                                             \
-            if (lr == LR && lc == LC) {                                                                                              \
-                if (pd.p.trace)                                                                                                      \
-                    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, true>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local); \
-                else                                                                                                                 \
-                    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, false>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local); \
-                return;                                                                                                              \
+#define SC_LAUNCH_FIXED(LR, LC, TR) \
+    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, TR>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local)
+#define SC_FIXED(LR, LC)                                              \
+            if (lr == LR && lc == LC) {                               \
+                if (pd.p.trace) SC_LAUNCH_FIXED(LR, LC, true);        \
+                else SC_LAUNCH_FIXED(LR, LC, false);                  \
+                return;                                               \
             }
             SC_FIXED(8, 3) SC_FIXED(7, 4) SC_FIXED(10, 2) SC_FIXED(6, 5) SC_FIXED(9, 3) SC_FIXED(8, 4)
 #undef SC_FIXED
@@ -555,6 +558,7 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
 int run_plan(NttPlanDesc& d, hipStream_t st) {
     size_t trace_off = 0;    // diagnostics: pass i writes its stamps behind those of the passes before it
     for (int i = 0; i < d.npasses; ++i) {
+        d.pass[i].p.prio_balance = g.prio_balance >= 0 ? g.prio_balance : (d.pass[i].ntiles <= (uint32_t)g.num_cus ? 1 : 0);
         d.pass[i].p.trace = g.trace ? g.trace + trace_off : nullptr;
         trace_off += (size_t)d.pass[i].ntiles * (d.pass[i].threads >> 6) * TRACE_STAMPS;
         switch (d.pass[i].loge) {
@@ -1068,7 +1072,9 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "xcd_remap") g.xcd_remap = value;
     else if (k == "fixed_shapes") g.fixed_shapes = value;
     else if (k == "wave_local") g.wave_local = value;
+    else if (k == "prio_balance") g.prio_balance = value;
     else if (k == "tw_on_load") g.tuning.tw_on_load = value;
+    else if (k == "prune") g.tuning.prune = value;
     else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);
     else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
     return SC_OK;

@@ -115,6 +115,28 @@ def test_emu_coset_evaluate(emu, cfg):
         assert out == po.C.coset_evaluate(coeffs, m, offset, gen, n), cfg
 
 
+# zero-padded inputs through the geometry-specialised shapes: the degenerate top stages of the first pass are pruned
+# (logn, m, tile, loge, single, min_tiles, max_col, digit): blowup 8 / 4 / 2 / 16 and ragged lengths on (8,3), (7,4), (10,2), (9,3)
+PRUNE = [(16, 1 << 13, 11, 2, 11, 0, 6, 8), (16, (1 << 13) - 5, 11, 2, 11, 0, 6, 8), (14, 1 << 12, 11, 2, 11, 0, 6, 8), (14, 1 << 13, 11, 2, 11, 0, 6, 8),
+         (16, 1 << 12, 11, 2, 11, 0, 6, 8), (16, 3, 11, 2, 11, 0, 6, 8), (18, 1 << 15, 12, 2, 11, 8, 4, 10), (20, 1 << 17, 12, 2, 11, 8, 4, 10), (18, 40000, 12, 2, 11, 8, 4, 10)]
+
+
+@pytest.mark.parametrize("cfg", PRUNE)
+def test_emu_pruned_first_pass(emu, cfg):
+    logn, m, tile, loge, single, min_tiles, max_col, digit = cfg
+    n = 1 << logn
+    coeffs = synth.synth_packed(350 + logn, m).tobytes()
+    gen = po.primitive_nth_root(n)
+    kw = dict(tile=tile, loge=loge, single=single, min_tiles=min_tiles, max_col=max_col, digit=digit)
+    want = po.C.coset_evaluate(coeffs, m, po.GENERATOR, gen, n)
+    for direct in (1, 2):
+        out, npass = run_emu(emu, coeffs + bytes(16), logn, gen, in_limit=m, offset=po.GENERATOR, direct=direct, **kw)
+        assert npass >= 2 and out == want, (cfg, direct)
+    # plain zero padding without the coset scaling (fast_multiply's operands, code/ntt.py:51-56)
+    out, _ = run_emu(emu, coeffs + bytes(16), logn, gen, in_limit=m, **kw)
+    assert out == po.C.ntt(gen, coeffs + bytes(16 * (n - m)), n), cfg
+
+
 def _batched_expect(data, kind, loglen, logbatch, root):
     """oracle: transform every column (kind 0) or every row with transposed output (kind 1)."""
     import numpy as np

@@ -63,7 +63,8 @@ def test_stub_functions_reproduce_reference_goldens(tmp_path):
         else:
             cw = synth.synth_ints(rec["seed"], rec["n"])
         out = stub.fold_gpu([fe(v) for v in cw], fe(rec["alpha"]), fe(rec["offset"]), fe(rec["omega"]))
-        assert [str(x.value) for x in out[:len(rec["out"])]] == rec["out"]
+        if "out" in rec:
+            assert [str(x.value) for x in out[:len(rec["out"])]] == rec["out"]
         import hashlib
         assert hashlib.sha256(synth.pack_ints([x.value for x in out])).hexdigest() == rec["sha256"]
     for rec in load_golden("poly.json")["interpolate"]:
