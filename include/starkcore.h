@@ -70,6 +70,7 @@ int sc_vec_alloc(uint64_t n, sc_vec_t** out);
 int sc_vec_free(sc_vec_t* v);
 uint64_t sc_vec_len(const sc_vec_t* v);
 void* sc_vec_ptr(sc_vec_t* v);         /* raw device pointer */
+int sc_vec_zero(sc_vec_t* v);                                   /* all elements = 0 (library stream) */
 int sc_vec_upload(sc_vec_t* v, uint64_t offset, const void* host, uint64_t count);
 int sc_vec_download(const sc_vec_t* v, uint64_t offset, void* host, uint64_t count);
 int sc_vec_gather(const sc_vec_t* v, const uint64_t* indices, uint64_t k, void* host_out); /* host_out[i] = v[indices[i]] */
@@ -111,11 +112,21 @@ int sc_poly_mul(const void* a, uint64_t na, const void* b, uint64_t nb, const ui
 /* ---- NTT core of fast_coset_divide : code/ntt.py:159-176 ----------------------------------- */
 /* out[0..n_out) = unscale( intt( ntt(scale(a)) / ntt(scale(b)) ) ); SC_ERR_DIV_ZERO if a divisor value is 0 */
 int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order, void* out, uint64_t n_out);
+/* the same on coefficient vectors in HBM (d_out: n_out coefficients).  *exact (may be NULL; makes the call synchronous) is set to 1
+ * iff the interpolant's coefficients [n_out, order) all vanish: with order > deg(a), exactly the condition "b divides a and the
+ * quotient has fewer than n_out coefficients" that Polynomial.__truediv__ asserts (code/univariate.py:99-103) */
+int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order,
+                        void* d_out, uint64_t n_out, int* exact, void* stream);
+/* Polynomial.degree (code/univariate.py:7-17) of a coefficient vector in HBM: index of the last non-zero entry, -1 if none (synchronous) */
+int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* stream);
 
 /* ---- pointwise helpers (ntt.py:61, :172; univariate.py:153-154) ------------------------------ */
 int sc_pointwise_mul_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream);
 int sc_pointwise_div_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream); /* sync; SC_ERR_DIV_ZERO */
 int sc_scale_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t factor[2], void* stream); /* out[i] = in[i] * factor^i */
+/* acc[shift + j] += weight * src[j], j < n_src: one term `Polynomial([weight]) * (x ^ shift) * term` of the nonlinear combination
+ * of code/fast_stark.py:130-145 on coefficient vectors in HBM (shift + n_src <= n_acc) */
+int sc_axpy_shift_dev(void* d_acc, uint64_t n_acc, const void* d_src, uint64_t n_src, uint64_t shift, const uint64_t weight[2], void* stream);
 /* the same scaling (univariate.py:153-154) on one rank's column slab [rows][cols] of a vector viewed as a rows x row_len
  * matrix (multi-GPU fast_coset_evaluate / fast_coset_divide, ntt.py:132-135, :159-176):
  * out[r][c] = in[r][c] * factor^(r * row_len + col_base + c); cols a power of two */

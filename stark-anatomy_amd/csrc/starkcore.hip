@@ -143,6 +143,20 @@ __global__ void __launch_bounds__(256) scale_slab_kernel(const Fe* __restrict__ 
     out[t] = mont_mul(in[t], pow2level(lo, hi, r * row_len + col_base + c));
 }
 
+// acc[shift + j] += weight * src[j]: one term of the nonlinear combination of code/fast_stark.py:130-145 -- `Polynomial([w]) * term`
+// and `(x ^ shift) * term` are a scaling and an index shift of the coefficient vector (w_m: weight in Montgomery form)
+__global__ void __launch_bounds__(256) axpy_shift_kernel(Fe* __restrict__ acc, const Fe* __restrict__ src, uint64_t n_src, uint64_t shift, Fe w_m) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_src) return;
+    acc[shift + j] = fe_add(acc[shift + j], mont_mul(src[j], w_m));
+}
+
+// out[0] = max index of a non-zero element, or -1 (Polynomial.degree, code/univariate.py:7-17, on a coefficient vector in HBM)
+__global__ void __launch_bounds__(256) vec_degree_kernel(const Fe* __restrict__ v, uint64_t n, long long* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !fe_is_zero(v[i])) atomicMax(out, (long long)i);
+}
+
 // split-and-fold (code/fri.py:85) rewritten as
 //   out[i] = (a + b)/2 + (a - b) * c * w^-i,   a = in[i], b = in[i + N/2], c = alpha / (2 * offset)
 // lo/hi are the power tables of omega^-1, c_m is c in Montgomery form.
@@ -286,7 +300,7 @@ struct Ctx {
     std::map<PowKey, PowTables> pows;
     uint64_t tick = 0;       // bumped by every table lookup
     bool foreign_streams = false;   // a caller-owned stream has been used (see pick_stream)
-    DevBuf scratch[6];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging
+    DevBuf scratch[8];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging, 6: uploaded operands, 7: degree / exactness flag
     int num_cus = 256;
     int xcd_remap = 1;
     int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
@@ -1106,6 +1120,13 @@ int sc_vec_free(sc_vec_t* v) {
 }
 uint64_t sc_vec_len(const sc_vec_t* v) { return v ? v->n : 0; }
 void* sc_vec_ptr(sc_vec_t* v) { return v ? v->d : nullptr; }
+int sc_vec_zero(sc_vec_t* v) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!v) return fail(SC_ERR_BAD_ARG, "null vector");
+    SCCHK(ensure_init());
+    if (v->n) HIPCHK(hipMemsetAsync(v->d, 0, v->n * sizeof(Fe), g.stream));
+    return SC_OK;
+}
 int sc_vec_upload(sc_vec_t* v, uint64_t offset, const void* host, uint64_t count) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
@@ -1326,6 +1347,18 @@ int sc_scale_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t facto
     return SC_OK;
 }
 
+int sc_axpy_shift_dev(void* d_acc, uint64_t n_acc, const void* d_src, uint64_t n_src, uint64_t shift, const uint64_t weight[2], void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!n_src) return SC_OK;
+    if (shift + n_src > n_acc || shift + n_src < shift) return fail(SC_ERR_BAD_ARG, "shifted term does not fit the accumulator");
+    Fe w = fe_from(weight);
+    if (fe_ge_p(w)) return fail(SC_ERR_BAD_ARG, "weight is not a canonical residue");
+    hipLaunchKernelGGL(axpy_shift_kernel, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, pick_stream(stream), (Fe*)d_acc, (const Fe*)d_src, n_src, shift, to_mont(w));
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
 int sc_scale_slab_dev(const void* d_in, void* d_out, uint64_t rows, uint64_t cols, uint64_t row_len, uint64_t col_base, const uint64_t factor[2], void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
@@ -1368,15 +1401,9 @@ int sc_poly_mul(const void* a, uint64_t na, const void* b, uint64_t nb, const ui
 }
 
 // ---- coset divide
-int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order, void* out, uint64_t n_out) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    SCCHK(ensure_init());
-    if (!is_pow2(order) || order < 2) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
-    if (na > order || nb > order || n_out > order || na == 0 || nb == 0) return fail(SC_ERR_BAD_ARG, "operand longer than the transform order");
-    Fe rt = fe_from(root), off = fe_from(offset);
-    SCCHK(check_root(rt, order));
-    if (fe_is_zero(off) || fe_ge_p(off)) return fail(SC_ERR_BAD_ARG, "bad coset offset");
-    hipStream_t st = g.stream;
+// core of fast_coset_divide (code/ntt.py:159-176) on device operands: ALL `order` coefficients of the unscaled interpolant of
+// ntt(scale(a)) / ntt(scale(b)) land in scratch slot 2 (returned in *full)
+static int coset_divide_core(const Fe* d_a, uint64_t na, const Fe* d_b, uint64_t nb, Fe off, Fe rt, uint64_t order, Fe** full, hipStream_t st) {
     void *da, *db, *dc;
     SCCHK(scratch(1, order * sizeof(Fe), &da));
     SCCHK(scratch(2, order * sizeof(Fe), &db));
@@ -1386,23 +1413,93 @@ int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, cons
     SCCHK(get_pow(off, order, st, &pw));
     NttOpts o;
     o.coset = pw;
-    SCCHK(upload(dc, a, na * sizeof(Fe), st));
     o.in_limit = na;
-    SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, rt, false, o, st));
-    SCCHK(upload(dc, b, nb * sizeof(Fe), st));
+    SCCHK(ntt_device(d_a, (Fe*)da, logn, rt, false, o, st));
     o.in_limit = nb;
-    SCCHK(ntt_device((const Fe*)dc, (Fe*)db, logn, rt, false, o, st));
+    SCCHK(ntt_device(d_b, (Fe*)db, logn, rt, false, o, st));
     SCCHK(pointwise_div_device((const Fe*)da, (const Fe*)db, (Fe*)dc, order, st));
     SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, root_inverse(rt, order), true, NttOpts{}, st));
     // unscale by offset^-1 (ntt.py:176)
     Fe off_inv = from_mont(mont_inv(to_mont(off)));
     PowTables* pinv;
-    SCCHK(get_pow(off_inv, n_out ? n_out : 1, st, &pinv));
-    if (n_out) {
-        hipLaunchKernelGGL(scale_pow_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, (const Fe*)da, (Fe*)db, n_out, pinv->lo, pinv->hi);
+    SCCHK(get_pow(off_inv, order, st, &pinv));
+    hipLaunchKernelGGL(scale_pow_kernel, dim3((unsigned)((order + 255) / 256)), dim3(256), 0, st, (const Fe*)da, (Fe*)db, order, pinv->lo, pinv->hi);
+    HIPCHK(hipGetLastError());
+    *full = (Fe*)db;
+    return SC_OK;
+}
+
+static int coset_divide_args(uint64_t na, uint64_t nb, uint64_t n_out, const uint64_t offset[2], const uint64_t root[2], uint64_t order, Fe* rt, Fe* off) {
+    if (!is_pow2(order) || order < 2) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    if (na > order || nb > order || n_out > order || na == 0 || nb == 0) return fail(SC_ERR_BAD_ARG, "operand longer than the transform order");
+    *rt = fe_from(root); *off = fe_from(offset);
+    SCCHK(check_root(*rt, order));
+    if (fe_is_zero(*off) || fe_ge_p(*off)) return fail(SC_ERR_BAD_ARG, "bad coset offset");
+    return SC_OK;
+}
+
+int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order, void* out, uint64_t n_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    Fe rt, off;
+    SCCHK(coset_divide_args(na, nb, n_out, offset, root, order, &rt, &off));
+    hipStream_t st = g.stream;
+    void *ua, *ub;
+    SCCHK(scratch(6, (na + nb) * sizeof(Fe), &ua));
+    ub = (Fe*)ua + na;
+    SCCHK(upload(ua, a, na * sizeof(Fe), st));
+    SCCHK(upload(ub, b, nb * sizeof(Fe), st));
+    Fe* full;
+    SCCHK(coset_divide_core((const Fe*)ua, na, (const Fe*)ub, nb, off, rt, order, &full, st));
+    return download(out, full, n_out * sizeof(Fe), st);
+}
+
+// the same on coefficient vectors in HBM, for callers that keep their polynomials on the device.  `exact` (may be NULL): set to
+// 1 iff the coefficients [n_out, order) of the interpolant vanish -- with order > deg(a) that is exactly "b divides a with
+// quotient degree < n_out", the condition Polynomial.__truediv__ asserts (code/univariate.py:99-103).
+int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order,
+                        void* d_out, uint64_t n_out, int* exact, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    Fe rt, off;
+    SCCHK(coset_divide_args(na, nb, n_out, offset, root, order, &rt, &off));
+    hipStream_t st = pick_stream(stream);
+    Fe* full;
+    SCCHK(coset_divide_core((const Fe*)d_a, na, (const Fe*)d_b, nb, off, rt, order, &full, st));
+    if (n_out) HIPCHK(hipMemcpyAsync(d_out, full, n_out * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+    if (exact) {
+        void* fl;
+        SCCHK(scratch(7, 256, &fl));
+        long long deg = -1;
+        HIPCHK(hipMemcpyAsync(fl, &deg, sizeof deg, hipMemcpyHostToDevice, st));
+        if (order > n_out) {
+            const uint64_t cnt = order - n_out;
+            hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const Fe*)full + n_out, cnt, (long long*)fl);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(&deg, fl, sizeof deg, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        *exact = deg < 0 ? 1 : 0;
+    }
+    return SC_OK;
+}
+
+int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    void* fl;
+    SCCHK(scratch(7, 256, &fl));
+    long long deg = -1;
+    HIPCHK(hipMemcpyAsync(fl, &deg, sizeof deg, hipMemcpyHostToDevice, st));
+    if (n) {
+        hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fe*)d_v, n, (long long*)fl);
         HIPCHK(hipGetLastError());
     }
-    return download(out, db, n_out * sizeof(Fe), st);
+    HIPCHK(hipMemcpyAsync(&deg, fl, sizeof deg, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *degree_out = (int64_t)deg;
+    return SC_OK;
 }
 
 // ---- fold

@@ -14,6 +14,7 @@ from fri import *
 from univariate import *
 from multivariate import *
 from ntt import *
+from ntt import _View
 
 
 class FastStark:
@@ -48,6 +49,12 @@ class FastStark:
         transition_zerofier_codeword = self._lde(transition_zerofier)
         transition_zerofier_root = Merkle.commit(transition_zerofier_codeword)
         return transition_zerofier, transition_zerofier_codeword, transition_zerofier_root
+
+    # Traces of at least this many rows (randomizers included) are proved with every polynomial resident in HBM (see prove());
+    # shorter ones follow the reference's host-list data flow with the GPU behind each fast_* call.  Same polynomials, same
+    # objects pushed in the same order -- the proofs are byte-identical either way (tests/test_gpu_stark.py runs both settings
+    # against the reference's golden proofs).
+    DEVICE_MIN = 32
 
     def _lde(self, polynomial):
         """Low-degree extension onto the FRI coset  generator * omega^i  (the LDE kernel)."""
@@ -93,30 +100,54 @@ class FastStark:
         for _ in range(self.num_randomizers):
             trace = trace + [[field.sample(os.urandom(17)) for s in registers]]
 
-        # trace polynomials through {omicron^i}
-        trace_domain = [self.omicron ^ i for i in range(len(trace))]
-        trace_polynomials = [fast_interpolate(trace_domain, [row[s] for row in trace], self.omicron, self.omicron_domain_length) for s in registers]
-
-        # boundary quotients (exact schoolbook division by the small boundary zerofiers)
+        on_device = len(trace) >= FastStark.DEVICE_MIN and field.p == Field.P_MAIN
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)
-        boundary_quotients = [(trace_polynomials[s] - interpolants[s]) / zerofiers[s] for s in registers]
+        if on_device:
+            # Polynomials live in HBM from here on (DevicePolynomial): interpolation, boundary quotients (exact coset division,
+            # exactness decided on the device), the AIR substitution in the value domain, the transition quotients, the LDEs and
+            # the combination.  The host keeps what byte parity ties to it: os.urandom draws, Fiat-Shamir, the proof stream.
+            dom, acc = [], 1
+            for _ in range(len(trace)):
+                dom.append(acc)
+                acc = acc * self.omicron.value % field.p
+            trace_domain = DeviceDomain(DeviceVector.from_ints(dom), field)
+            trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, DeviceCodeword.from_list([row[s] for row in trace], field)))
+                                 for s in registers]
+            zerofiers_dev = [DevicePolynomial.from_polynomial(z, field) for z in zerofiers]
+            boundary_quotients = [coset_divide_device(trace_polynomials[s].minus(interpolants[s]), zerofiers_dev[s], self.generator, self.omicron,
+                                                      self.omicron_domain_length, exact=True) for s in registers]
+            lde = lambda poly: poly.coset_evaluate(self.generator, self.omega, self.fri_domain_length)
+        else:
+            # trace polynomials through {omicron^i}
+            trace_domain = [self.omicron ^ i for i in range(len(trace))]
+            trace_polynomials = [fast_interpolate(trace_domain, [row[s] for row in trace], self.omicron, self.omicron_domain_length) for s in registers]
+            # boundary quotients (exact schoolbook division by the small boundary zerofiers)
+            boundary_quotients = [(trace_polynomials[s] - interpolants[s]) / zerofiers[s] for s in registers]
+            lde = self._lde
 
         # commit to their low-degree extensions
         boundary_quotient_codewords = []
         for s in registers:
-            boundary_quotient_codewords.append(self._lde(boundary_quotients[s]))
+            boundary_quotient_codewords.append(lde(boundary_quotients[s]))
             proof_stream.push(Merkle.commit(boundary_quotient_codewords[s]))
 
         # transition polynomials: AIR evaluated symbolically in (X, trace(X), trace(omicron X)), then quotients
-        point = [Polynomial([field.zero(), field.one()])] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
+        x = Polynomial([field.zero(), field.one()])
+        point = [DevicePolynomial.from_polynomial(x, field) if on_device else x] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
         transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
-        transition_quotients = [fast_coset_divide(tp, transition_zerofier, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
+        if on_device:
+            tz_dev = DevicePolynomial.from_polynomial(transition_zerofier, field)
+            transition_quotients = [coset_divide_device(tp, tz_dev, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
+        else:
+            transition_quotients = [fast_coset_divide(tp, transition_zerofier, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
 
         # randomizer polynomial
         max_degree = self.max_degree(transition_constraints)
         randomizer_polynomial = Polynomial([field.sample(os.urandom(17)) for i in range(max_degree + 1)])
-        randomizer_codeword = self._lde(randomizer_polynomial)
+        if on_device:
+            randomizer_polynomial = DevicePolynomial.from_polynomial(randomizer_polynomial, field)
+        randomizer_codeword = lde(randomizer_polynomial)
         proof_stream.push(Merkle.commit(randomizer_codeword))
 
         # Fiat-Shamir weights: 1 randomizer + 2 per transition quotient + 2 per boundary quotient
@@ -125,17 +156,22 @@ class FastStark:
         assert([tq.degree() for tq in transition_quotients] == tq_bounds), "transition quotient degrees do not match with expectation"
 
         # nonlinear combination: each quotient and its degree-shifted copy
-        x = Polynomial([field.zero(), field.one()])
         bq_bounds = self.boundary_quotient_degree_bounds(len(trace), boundary)
-        terms = [randomizer_polynomial]
+        shifted = [(randomizer_polynomial, None)]
         for i, tq in enumerate(transition_quotients):
-            terms += [tq, (x ^ (max_degree - tq_bounds[i])) * tq]
+            shifted.append((tq, max_degree - tq_bounds[i]))
         for i in registers:
-            terms += [boundary_quotients[i], (x ^ (max_degree - bq_bounds[i])) * boundary_quotients[i]]
-        combination = reduce(lambda a, b: a + b, [Polynomial([weights[i]]) * terms[i] for i in range(len(terms))], Polynomial([]))
+            shifted.append((boundary_quotients[i], max_degree - bq_bounds[i]))
+        if on_device:
+            combined_codeword = self._combine_on_device(shifted, weights, max_degree)
+        else:
+            terms = []
+            for poly, shift in shifted:
+                terms += [poly] if shift is None else [poly, (x ^ shift) * poly]
+            combination = reduce(lambda a, b: a + b, [Polynomial([weights[i]]) * terms[i] for i in range(len(terms))], Polynomial([]))
+            combined_codeword = self._lde(combination)
 
         # low-degree test of the combination
-        combined_codeword = self._lde(combination)
         indices = self.fri.prove(combined_codeword, proof_stream)
 
         # open the queried positions (and their expansion_factor / half-domain companions)
@@ -148,12 +184,27 @@ class FastStark:
 
         return proof_stream.serialize()
 
+    def _combine_on_device(self, shifted, weights, max_degree):
+        """sum_i weights[i] * terms[i] (fast_stark.py:130-145) as axpys over coefficient vectors in HBM, then the LDE straight from
+        the accumulator: `Polynomial([w]) * t` scales t, `(x ^ k) * t` shifts it by k places.  The combination never visits the host."""
+        width = max(max_degree + 1, max(len(p) + (k or 0) for p, k in shifted))
+        acc = DeviceVector.zeros(width)
+        w = iter(weights)
+        for poly, shift in shifted:
+            for k in ([0] if shift is None else [0, shift]):
+                weight = next(w)
+                if len(poly):
+                    acc.axpy_shift(_View(poly.vec, len(poly)), k, weight.value)
+        return DevicePolynomial(acc, self.field, width).coset_evaluate(self.generator, self.omega, self.fri_domain_length)
+
     def _open_all(self, codeword, indices, proof_stream):
         """leaf, path, leaf, path, ... for one codeword -- one resident tree, one batched gather of all paths."""
-        tree = Merkle._tree(codeword)
-        paths = tree.open_batch(indices)
-        for i, path in zip(indices, paths):
-            proof_stream.push(codeword[i])
+        if isinstance(codeword, DeviceCodeword):
+            entries, paths = codeword.query(indices)          # entries and paths in one device round trip
+        else:
+            entries, paths = [codeword[i] for i in indices], Merkle._tree(codeword).open_batch(indices)
+        for entry, path in zip(entries, paths):
+            proof_stream.push(entry)
             proof_stream.push(path)
 
     # -- verifier (fast_stark.py:180-286) -----------------------------------------------------------

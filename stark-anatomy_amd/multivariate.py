@@ -97,6 +97,12 @@ class MPolynomial:
         device = self._evaluate_symbolic_value_domain(point)
         if device is not None:
             return device
+        if any(hasattr(q, "vec") for q in point):
+            # device operands and nothing to compute pointwise: every term vanishes (a zero factor kills its term,
+            # univariate.py:139-140), so the sum is the zero polynomial
+            from ntt import DevicePolynomial
+            import starkcore as _sc
+            return DevicePolynomial(_sc.DeviceVector(1), next(q.field for q in point if hasattr(q, "vec")), 0)
         # Same sums of products as multivariate.py:83-90.  The reference recomputes point[i] ^ e for every term; the powers
         # are the same polynomials each time, so they are computed once per call, and a factor that is the constant 1
         # (e = 0) is not multiplied out: `term * Polynomial([1])` has the same coefficient list as `term`.
@@ -122,8 +128,12 @@ class MPolynomial:
         by the transition zerofier, which trims by degree).  Returns None when the point is too small to be worth it."""
         if not self.dictionary or not point:
             return None
+        on_device = [hasattr(q, "vec") for q in point]        # DevicePolynomial operands: coefficients already in HBM
         field = None
-        for q in point:
+        for q, dev in zip(point, on_device):
+            if dev:
+                field = q.field
+                break
             if q.coefficients:
                 field = q.coefficients[0].field
                 break
@@ -145,7 +155,7 @@ class MPolynomial:
                 continue
             terms.append((tuple(k) + (0,) * (nvars - len(k)), v.value))
             bound = max(bound, d)
-        if bound < MPolynomial.VALUE_DOMAIN_MIN_DEGREE or nvars > 255:
+        if (bound < MPolynomial.VALUE_DOMAIN_MIN_DEGREE and not any(on_device)) or nvars > 255 or bound < 0:
             return None
         import ctypes
         import starkcore as _sc
@@ -162,7 +172,10 @@ class MPolynomial:
             if not used[j]:
                 continue
             m = degs[j] + 1
-            src = _sc.DeviceVector.from_bytes(b"".join(c.value.to_bytes(16, "little") for c in q.coefficients[:m])) if m else _sc.DeviceVector(1)
+            if on_device[j]:
+                src = q.vec
+            else:
+                src = _sc.DeviceVector.from_bytes(b"".join(c.value.to_bytes(16, "little") for c in q.coefficients[:m])) if m else _sc.DeviceVector(1)
             keep.append(src)
             _sc._check(lib.sc_coset_evaluate_dev(src.ptr, m, one, _sc.fe_bytes(root.value), n, vals.ptr + 16 * j * n, None))
         exps = bytes(e for k, _ in terms for e in k)
@@ -171,6 +184,9 @@ class MPolynomial:
         _sc._check(lib.sc_mpoly_eval_dev(vals.ptr, nvars, n, exps, coefs, len(terms), out.ptr, None))
         coeffs = _sc.DeviceVector(n)
         _sc._check(lib.sc_ntt_dev(out.ptr, coeffs.ptr, n, _sc.fe_bytes(root.value), 1, None))
+        if any(on_device):
+            from ntt import DevicePolynomial
+            return DevicePolynomial(coeffs, field, bound + 1)     # stays in HBM for callers that work there
         raw = coeffs.to_bytes(0, bound + 1)
         frm = int.from_bytes
         return Polynomial([FieldElement(frm(raw[16 * i:16 * i + 16], "little"), field) for i in range(bound + 1)])

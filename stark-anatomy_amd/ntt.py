@@ -220,6 +220,101 @@ class DeviceDomain:
         return self.tree.k
 
 
+class DevicePolynomial:
+    """A coefficient list resident in HBM: what `Polynomial` is to the host path.  `len(p)` is the reference's LIST length
+    (trailing zeros count, like `polynomial.coefficients`); `degree()` is Polynomial.degree (code/univariate.py:7-17), computed
+    on the device once and cached.  Used by the callers that keep their polynomials on the device (fast_stark.py)."""
+
+    def __init__(self, vec, field, length=None):
+        self.vec, self.field = vec, field
+        self.n = vec.n if length is None else int(length)
+        self._degree = None
+
+    @classmethod
+    def from_polynomial(cls, polynomial, field=None):
+        coeffs = polynomial.coefficients
+        field = field if field is not None else coeffs[0].field
+        _require_main_field(field)
+        return cls(DeviceVector.from_bytes(_pack(coeffs)) if coeffs else DeviceVector(1), field, len(coeffs))
+
+    @classmethod
+    def from_codeword(cls, codeword):
+        return cls(codeword.vec, codeword.field)
+
+    def __len__(self):
+        return self.n
+
+    def to_polynomial(self):
+        return Polynomial(_unpack(self.vec.to_bytes(0, self.n), self.n, self.field))
+
+    def degree(self):
+        if self._degree is None:
+            deg = ctypes.c_int64(-1)
+            _sc._check(_sc.lib().sc_vec_degree_dev(self.vec.ptr, self.n, ctypes.byref(deg), None))
+            self._degree = int(deg.value)
+        return self._degree
+
+    def is_zero(self):
+        return self.degree() == -1
+
+    def copy(self, length=None):
+        length = self.n if length is None else length
+        out = DeviceVector.zeros(max(length, 1))
+        if min(length, self.n):
+            out.axpy_shift(_View(self.vec, min(length, self.n)), 0, 1)
+        return DevicePolynomial(out, self.field, length)
+
+    def minus(self, polynomial):
+        """self - polynomial for a (short) host Polynomial: list length max(len, len), like Polynomial.__sub__"""
+        coeffs = polynomial.coefficients
+        out = self.copy(max(self.n, len(coeffs)))
+        if coeffs:
+            out.vec.axpy_shift(DeviceVector.from_bytes(_pack(coeffs)), 0, self.field.p - 1)
+        return out
+
+    def scale(self, factor):
+        """Polynomial.scale (code/univariate.py:153-154): coefficient i times factor^i"""
+        out = DeviceVector(max(self.n, 1))
+        if self.n:
+            _sc._check(_sc.lib().sc_scale_dev(self.vec.ptr, out.ptr, self.n, _sc.fe_bytes(factor.value), None))
+        return DevicePolynomial(out, self.field, self.n)
+
+    def coset_evaluate(self, offset, generator, order):
+        """fast_coset_evaluate (code/ntt.py:132-135) -> DeviceCodeword"""
+        out = DeviceVector(order)
+        _sc._check(_sc.lib().sc_coset_evaluate_dev(self.vec.ptr, self.n, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out.ptr, None))
+        _sc.synchronize()
+        return DeviceCodeword(out, self.field)
+
+
+class _View:
+    """the first n elements of a DeviceVector (for axpy_shift sources)"""
+
+    def __init__(self, vec, n):
+        self.ptr, self.n = vec.ptr, n
+
+
+def coset_divide_device(lhs, rhs, offset, primitive_root, root_order, exact=False):
+    """fast_coset_divide (code/ntt.py:137-176) on DevicePolynomials: lhs.degree() - rhs.degree() + 1 coefficients, in HBM.
+    exact=True additionally asserts what Polynomial.__truediv__ asserts (a zero remainder), decided on the device."""
+    _check_root(primitive_root, root_order)
+    assert(not rhs.is_zero()), "cannot divide by zero polynomial"
+    field = lhs.field
+    if lhs.is_zero():
+        return DevicePolynomial(DeviceVector(1), field, 0)
+    dl, dr = lhs.degree(), rhs.degree()
+    assert(dr <= dl), "cannot divide by polynomial of larger degree"
+    root, order = _shrink_order(primitive_root, root_order, max(dl, dr))
+    n_out = dl - dr + 1
+    out = DeviceVector(n_out)
+    flag = ctypes.c_int(0)
+    _sc._check(_sc.lib().sc_coset_divide_dev(lhs.vec.ptr, dl + 1, rhs.vec.ptr, dr + 1, _sc.fe_bytes(offset.value), _sc.fe_bytes(root.value), order,
+                                             out.ptr, n_out, ctypes.byref(flag) if exact else None, None))
+    if exact:
+        assert(flag.value == 1), "cannot perform polynomial division because remainder is not zero"
+    return DevicePolynomial(out, field, n_out)
+
+
 def fast_zerofier_device(domain):
     """fast_zerofier (ntt.py:66-80) of a DeviceDomain -> DeviceCodeword of len(domain) + 1 coefficients"""
     return DeviceCodeword(domain.tree.zerofier(), domain.field)

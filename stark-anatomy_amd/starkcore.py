@@ -33,6 +33,7 @@ SIGNATURES = {
     "sc_vec_free": (_int, [_vp]),
     "sc_vec_len": (_u64, [_vp]),
     "sc_vec_ptr": (_vp, [_vp]),
+    "sc_vec_zero": (_int, [_vp]),
     "sc_vec_upload": (_int, [_vp, _u64, _vp, _u64]),
     "sc_vec_download": (_int, [_vp, _u64, _vp, _u64]),
     "sc_vec_gather": (_int, [_vp, _vp, _u64, _vp]),
@@ -46,9 +47,12 @@ SIGNATURES = {
     "sc_coset_evaluate_dev": (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "sc_poly_mul": (_int, [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64]),
     "sc_coset_divide": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64]),
+    "sc_coset_divide_dev": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_int), _vp]),
+    "sc_vec_degree_dev": (_int, [_vp, _u64, ctypes.POINTER(ctypes.c_int64), _vp]),
     "sc_pointwise_mul_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "sc_pointwise_div_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "sc_scale_dev": (_int, [_vp, _vp, _u64, _vp, _vp]),
+    "sc_axpy_shift_dev": (_int, [_vp, _u64, _vp, _u64, _u64, _vp, _vp]),
     "sc_scale_slab_dev": (_int, [_vp, _vp, _u64, _u64, _u64, _u64, _vp, _vp]),
     "sc_fri_fold": (_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
     "sc_fri_fold_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp]),
@@ -163,6 +167,16 @@ class DeviceVector:
     @classmethod
     def from_ints(cls, values):
         return cls.from_bytes(pack(values))
+
+    @classmethod
+    def zeros(cls, n):
+        v = cls(n)
+        _check(lib().sc_vec_zero(v._h))
+        return v
+
+    def axpy_shift(self, src, shift, weight):
+        """self[shift + j] += weight * src[j]  (one term of the nonlinear combination, code/fast_stark.py:130-145)"""
+        _check(lib().sc_axpy_shift_dev(self.ptr, self.n, src.ptr, src.n, int(shift), fe_bytes(weight), None))
 
     @property
     def ptr(self):

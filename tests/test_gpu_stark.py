@@ -31,7 +31,12 @@ def _seed_urandom(seed):
     return rng
 
 
-def test_fast_stark_seeded_golden_proofs():
+@pytest.mark.parametrize("device_min", [32, 10 ** 9])
+def test_fast_stark_seeded_golden_proofs(device_min, monkeypatch):
+    """device_min = 32: every polynomial of the prover lives in HBM (DevicePolynomial pipeline: interpolation, exact boundary
+    quotients, value-domain AIR substitution, transition quotients, LDEs, device combination); 10^9: the reference's host-list
+    data flow with the GPU behind each fast_* call.  Both must reproduce the reference's proofs byte for byte."""
+    monkeypatch.setattr(FastStark, "DEVICE_MIN", device_min)
     g = load_golden("fast_stark.json")
     field = Field.main()
     rp = RescuePrime()
@@ -57,7 +62,9 @@ def test_fast_stark_seeded_golden_proofs():
         assert stark.verify(proof, air, rp.boundary_constraints(output_element + field.one()), transition_zerofier_root) == rec["false_claim_verifies"] == False
 
 
-def test_fast_stark():                             # code/test_fast_stark.py:9-65, 3 trials, seeded
+@pytest.mark.parametrize("device_min", [32, 10 ** 9])
+def test_fast_stark(device_min, monkeypatch):      # code/test_fast_stark.py:9-65, 3 trials, seeded
+    monkeypatch.setattr(FastStark, "DEVICE_MIN", device_min)
     field = Field.main()
     rng = _seed_urandom(2024)
     expansion_factor, num_colinearity_checks, security_level = 4, 2, 2
