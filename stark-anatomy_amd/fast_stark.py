@@ -39,14 +39,22 @@ class FastStark:
         self.generator = self.field.generator()
         self.omega = self.field.primitive_nth_root(self.fri_domain_length)
         self.omicron = self.field.primitive_nth_root(self.omicron_domain_length)
-        self.omicron_domain = [self.omicron ^ i for i in range(self.omicron_domain_length)]
+        # omicron^i for i < omicron_domain_length (fast_stark.py:33), by running product instead of one exponentiation per entry
+        self.omicron_domain, acc = [], self.field.one()
+        for _ in range(self.omicron_domain_length):
+            self.omicron_domain.append(acc)
+            acc = acc * self.omicron
 
         self.fri = Fri(self.generator, self.omega, self.fri_domain_length, self.expansion_factor, self.num_colinearity_checks)
 
     # -- preprocessing (fast_stark.py:36-40) ------------------------------------------------------
     def preprocess(self):
         transition_zerofier = fast_zerofier(self.omicron_domain[:(self.original_trace_length - 1)], self.omicron, len(self.omicron_domain))
-        transition_zerofier_codeword = self._lde(transition_zerofier)
+        if self.randomized_trace_length >= FastStark.DEVICE_MIN and self.field.p == Field.P_MAIN:
+            # long traces: the codeword is committed here and opened in prove() where it lies, in HBM (a DeviceCodeword is list-like)
+            transition_zerofier_codeword = fast_coset_evaluate_device(transition_zerofier, self.generator, self.omega, self.fri_domain_length)
+        else:
+            transition_zerofier_codeword = self._lde(transition_zerofier)
         transition_zerofier_root = Merkle.commit(transition_zerofier_codeword)
         return transition_zerofier, transition_zerofier_codeword, transition_zerofier_root
 
