@@ -47,3 +47,56 @@ for log2n, world in [(22, 2), (23, 4), (24, 8), (24, 1), (21, 1)]:
     rt = sc.fe_bytes(nth_root(1 << lg))
     res["single_gpu_ntt_same_size_us"] = round(timeit(lambda: sc._check(sc.lib().sc_ntt_dev(xs.ptr, ys.ptr, 1 << lg, rt, 0, sp))), 1)
     print(json.dumps(res), flush=True)
+
+# ---- overlap of the corner turn with the row stage (ShardedNtt._transform_overlapped), SIMULATED on one GPU: there is no xGMI on a
+# 1-GPU box, so the exchange of row block q is stood in for by device-to-device copies of `slow` x its bytes on a side stream
+# (slow = 1: as fast as HBM allows; slow = 8: a link ~8x slower than an HBM copy, the order of 7 xGMI links vs HBM); what is
+# measured is the pipeline: K async "exchanges" back to back on the side stream, the row transforms of block q on the compute
+# stream as soon as block q has landed (event wait), against the blocking form (whole exchange, then the whole row stage).
+side = torch.cuda.Stream(device=dev)
+for log2n, world, K in [(24, 8, 4), (24, 8, 8), (23, 4, 4)]:
+    n = 1 << log2n
+    eng = ShardedNtt(log2n, nth_root(n), 0, world, dev)
+    for (R, C, tag) in ((eng.n1, eng.n2, "forward"), (eng.n2, eng.n1, "inverse")):
+        rw, cw = R // world, C // world
+        if rw % K:
+            continue
+        rk = rw // K
+        root_rows = pow(eng.root, R, P)
+        a = torch.randint(0, 1 << 62, (R, cw, 2), dtype=torch.int64, device=dev)
+        recv = torch.empty((K, world, rk, cw, 2), dtype=torch.int64, device=dev)
+        recv1 = recv.view(world * K, rk, cw, 2)
+        y = torch.empty((C, rw, 2), dtype=torch.int64, device=dev)
+        for slow in (1, 8):
+            def exch_block(q):
+                for _ in range(slow):
+                    recv[q].copy_(a.view(world, K, rk, cw, 2)[:, q], non_blocking=True)
+            def blocking():
+                side.wait_stream(stream)
+                with torch.cuda.stream(side):
+                    for q in range(K): exch_block(q)
+                stream.wait_stream(side)
+                for q in range(K):
+                    assert eng.engine.rows_ntt_t_block(recv[q], y, q * rk, C, rk, world, root_rows, rw)
+            def overlapped():
+                side.wait_stream(stream)
+                evs = []
+                with torch.cuda.stream(side):
+                    for q in range(K):
+                        exch_block(q)
+                        ev = torch.cuda.Event(); ev.record(side); evs.append(ev)
+                for q in range(K):
+                    stream.wait_event(evs[q])
+                    assert eng.engine.rows_ntt_t_block(recv[q], y, q * rk, C, rk, world, root_rows, rw)
+            def only_exchange():
+                side.wait_stream(stream)
+                with torch.cuda.stream(side):
+                    for q in range(K): exch_block(q)
+                stream.wait_stream(side)
+            def only_rows():
+                for q in range(K):
+                    assert eng.engine.rows_ntt_t_block(recv[q], y, q * rk, C, rk, world, root_rows, rw)
+            t_x, t_r, t_b, t_o = timeit(only_exchange, 10), timeit(only_rows, 10), timeit(blocking, 10), timeit(overlapped, 10)
+            hidden = (t_b - t_o) / t_x if t_x > 0 else 0.0
+            print(json.dumps(dict(overlap_sim=tag, log2n=log2n, world=world, blocks=K, exchange_slowdown=slow, exchange_us=round(t_x, 1), rows_us=round(t_r, 1),
+                                  blocking_us=round(t_b, 1), overlapped_us=round(t_o, 1), exchange_hidden_frac=round(hidden, 2))), flush=True)
