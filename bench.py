@@ -232,18 +232,41 @@ def main():
                 from sharded import ShardedNtt
                 log2n = args.log2n or (20 + (world.bit_length() - 1) + 1)     # 2^21 per GPU: 8 GPUs -> 2^24
                 n = 1 << log2n
-                eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True)
-                x = eng.synthetic_input(seed=1)
-                y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
-                z = torch.empty_like(x)
+                corner_turn = None
+                for chunks in (4, 1):
+                    # the overlapped corner turn (4 asynchronous row blocks) first; if it cannot be set up, or its result is not
+                    # the blocking form's, the single blocking all_to_all_single -- and the JSON line says which one ran
+                    try:
+                        eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True, overlap_chunks=chunks)
+                        x = eng.synthetic_input(seed=1)
+                        y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
+                        z = torch.empty_like(x)
 
-                def step():
-                    eng.forward(x, y)
-                    eng.inverse(y, z)
+                        def step():
+                            eng.forward(x, y)
+                            eng.inverse(y, z)
 
-                step()
-                dist.barrier()
-                torch.cuda.synchronize()
+                        step()
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        same = torch.equal(z, x)
+                        if chunks > 1:            # the overlapped forward transform against the blocking one, element for element
+                            ref_eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True, overlap_chunks=1)
+                            y_ref = torch.empty_like(y)
+                            ref_eng.forward(x, y_ref)
+                            torch.cuda.synchronize()
+                            same = same and torch.equal(y_ref, y)
+                            del ref_eng, y_ref
+                        good = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+                        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+                        if int(good.item()) != 1:
+                            raise RuntimeError("round trip mismatch with %d corner-turn blocks" % chunks)
+                        corner_turn = "%d asynchronous row blocks overlapped with the row stage" % chunks if chunks > 1 else "one blocking all_to_all_single"
+                        break
+                    except Exception as e1:       # noqa: BLE001
+                        if chunks == 1:
+                            raise
+                        sys.stderr.write("bench.py: overlapped corner turn unavailable (%r); using the blocking form\n" % (e1,))
                 launches_per_step = 2      # N > 1: roofline is reported per whole transform (local passes + all-to-all)
                 workload = "ntt_fwd_inv_2^%d_fourstep_%dgpu" % (log2n, world)
                 total_n = n
@@ -341,6 +364,7 @@ def main():
         if sharded:
             out["config"]["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
             out["config"]["world_size"] = world
+            out["config"]["corner_turn"] = corner_turn
             out["config"]["all_to_all_bytes_sent_per_rank_per_step"] = 2 * (total_n // world) * 16 * (world - 1) // world
         if census is not None:
             out.setdefault("extras", {})["stark_census_sharded"] = census
