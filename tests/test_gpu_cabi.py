@@ -502,3 +502,66 @@ def test_query_multi_and_mpoly_eval(sc):
             acc = (acc + t) % P
         want.append(acc)
     assert synth.unpack_ints(out.to_bytes()) == want
+
+
+def test_round2_device_entry_points(sc):
+    """Direct parity of the entries added in round 2: slab scaling, axpy with shift, degree, exact coset division on device
+    operands, and one row block of the overlapped corner turn -- each against the oracle / plain integer arithmetic."""
+    import numpy as np
+    lib = sc.lib()
+    # sc_scale_slab_dev: out[r][c] = in[r][c] * f^(r*row_len + col_base + c)
+    rows, cols, row_len, col_base, f = 12, 8, 32, 16, po.GENERATOR
+    vals = synth.synth_ints(5100, rows * cols)
+    v = sc.DeviceVector.from_ints(vals)
+    out = sc.DeviceVector(rows * cols)
+    sc._check(lib.sc_scale_slab_dev(v.ptr, out.ptr, rows, cols, row_len, col_base, sc.fe_bytes(f), None))
+    want = [vals[r * cols + c] * pow(f, r * row_len + col_base + c, P) % P for r in range(rows) for c in range(cols)]
+    assert synth.unpack_ints(out.to_bytes()) == want
+    # sc_vec_zero / sc_axpy_shift_dev / sc_vec_degree_dev
+    acc = sc.DeviceVector.zeros(300)
+    assert acc.to_bytes() == bytes(16 * 300)
+    src = synth.synth_ints(5101, 100)
+    w = synth.synth_ints(5102, 2)
+    sv = sc.DeviceVector.from_ints(src)
+    acc.axpy_shift(sv, 0, w[0])
+    acc.axpy_shift(sv, 57, w[1])
+    model = [0] * 300
+    for j, x in enumerate(src):
+        model[j] = (model[j] + w[0] * x) % P
+        model[57 + j] = (model[57 + j] + w[1] * x) % P
+    assert synth.unpack_ints(acc.to_bytes()) == model
+    deg = ctypes.c_int64(0)
+    sc._check(lib.sc_vec_degree_dev(acc.ptr, 300, ctypes.byref(deg), None))
+    assert deg.value == po.degree(model) == 156
+    sc._check(lib.sc_vec_degree_dev(sc.DeviceVector.zeros(64).ptr, 64, ctypes.byref(deg), None))
+    assert deg.value == -1
+    with pytest.raises(sc.StarkCoreError):
+        acc.axpy_shift(sv, 201, 1)                                        # does not fit
+    # sc_coset_divide_dev: exact quotient, exactness flag, inexact numerator
+    a, b = synth.synth_ints(5103, 300), synth.synth_ints(5104, 41)
+    prod = po.schoolbook_mul(a, b)
+    order = 512
+    root = po.primitive_nth_root(order)
+    dp, db = sc.DeviceVector.from_ints(prod), sc.DeviceVector.from_ints(b)
+    q = sc.DeviceVector(len(a))
+    flag = ctypes.c_int(-1)
+    sc._check(lib.sc_coset_divide_dev(dp.ptr, len(prod), db.ptr, len(b), sc.fe_bytes(po.GENERATOR), sc.fe_bytes(root), order, q.ptr, len(a), ctypes.byref(flag), None))
+    assert flag.value == 1 and synth.unpack_ints(q.to_bytes()) == a
+    assert synth.unpack_ints(q.to_bytes()) == po.fast_coset_divide(prod, b, po.GENERATOR, root, order)
+    bad = list(prod); bad[3] = (bad[3] + 1) % P                             # remainder != 0
+    sc._check(lib.sc_coset_divide_dev(sc.DeviceVector.from_ints(bad).ptr, len(bad), db.ptr, len(b), sc.fe_bytes(po.GENERATOR), sc.fe_bytes(root), order, q.ptr, len(a),
+                                      ctypes.byref(flag), None))
+    assert flag.value == 0
+    # sc_ntt_rows_t_ld_dev: two row blocks of 8 rows each, chunked input, written into one [len][16] output
+    ln, bt, ch = 1 << 9, 16, 4
+    host = synth.synth_packed(5105, ln * bt)
+    rt = po.primitive_nth_root(ln)
+    m = host.reshape(bt, ln, 2)
+    exp = np.stack([np.frombuffer(C.ntt(rt, m[r].tobytes(), ln), dtype=np.uint64).reshape(ln, 2) for r in range(bt)], axis=1)
+    wide = sc.DeviceVector(ln * bt)
+    for blk in range(2):
+        part = np.ascontiguousarray(m[blk * 8:(blk + 1) * 8].reshape(8, ch, ln // ch, 2).transpose(1, 0, 2, 3))
+        pv = sc.DeviceVector.from_bytes(part.tobytes())
+        sc._check(lib.sc_ntt_rows_t_ld_dev(pv.ptr, wide.ptr + 16 * blk * 8, ln, 8, sc.fe_bytes(rt), ch, bt, None))
+        sc.synchronize()
+    assert wide.to_bytes() == exp.tobytes()
