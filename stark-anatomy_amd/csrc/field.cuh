@@ -174,6 +174,27 @@ SC_HD Fe mont_mul(Fe a, Fe b) {
     return mont_mul_c(a, b);
 #endif
 }
+// two independent products at once (device: hand-interleaved, see field_asm.cuh; elsewhere: one after the other)
+#ifndef SC_MUL2
+#define SC_MUL2 1
+#endif
+SC_HD void mont_mul2(Fe a0, Fe b0, Fe a1, Fe b1, Fe& r0, Fe& r1) {
+#if defined(__HIP_DEVICE_COMPILE__) && SC_ASM_MUL && SC_MUL2
+    mont_mul2_asm(a0, b0, a1, b1, r0, r1);
+#else
+    r0 = mont_mul(a0, b0);
+    r1 = mont_mul(a1, b1);
+#endif
+}
+// sums and differences of two butterflies at once (device: four interleaved carry chains, see field_asm.cuh)
+SC_HD void fe_addsub2(Fe u0, Fe v0, Fe u1, Fe v1, Fe& s0, Fe& d0, Fe& s1, Fe& d1) {
+#if defined(__HIP_DEVICE_COMPILE__) && SC_ASM_ADDSUB && SC_MUL2
+    fe_addsub2_asm(u0, v0, u1, v1, s0, d0, s1, d1);
+#else
+    s0 = fe_add(u0, v0); d0 = fe_sub(u0, v0);
+    s1 = fe_add(u1, v1); d1 = fe_sub(u1, v1);
+#endif
+}
 SC_HD Fe fe_add(Fe a, Fe b) {
 #if defined(__HIP_DEVICE_COMPILE__) && SC_ASM_ADDSUB
     return fe_add_asm(a, b);

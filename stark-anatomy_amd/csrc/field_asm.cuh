@@ -167,6 +167,142 @@ __device__ __forceinline__ Fe mont_mul_asm(Fe a, Fe b) {
     return Fe{((uint64_t)o1 << 32) | o0, ((uint64_t)o3 << 32) | o2};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two independent Montgomery products, hand-interleaved (A, B, A, B, ...) so that every carry / borrow consumer sits at least two
+// VALU instructions behind its producer: the 2 wait states of the SGPR hazard are filled with the other product's work instead of
+// `s_nop`s (one product alone spends ~25 `s_nop 1` plus what hipcc adds between the asm statements; a pair needs 10 `s_nop 0`).
+// The statements are `asm volatile`, which pins their relative order -- the compiler may put other instructions between them
+// (that only adds wait states), never fewer.  Same arithmetic as mont_mul_asm, instruction for instruction.
+#define SC_V_MAD(d, cy, x, y, c)   asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(x), "v"(y), "v"(c))
+#define SC_V_INC(d, x, ci, co)     asm volatile("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(d), "=s"(co) : "v"(x), "s"(ci))
+#define SC_V_ADDCO(d, co, x, y)    asm volatile("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(d), "=s"(co) : "v"(x), "v"(y))
+#define SC_V_ADDC(d, co, x, y, ci) asm volatile("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(x), "v"(y), "s"(ci))
+#define SC_V_SUBCO(d, bo, x, y)    asm volatile("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(d), "=s"(bo) : "v"(x), "v"(y))
+#define SC_V_SUBB(d, bo, x, y, bi) asm volatile("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=s"(bo) : "v"(x), "v"(y), "s"(bi))
+#define SC_V_CND(d, x, y, m)       asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "s"(m))
+#define SC_V_NOP0()                asm volatile("s_nop 0")
+
+struct MulState {       // registers of one product in flight
+    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+    uint64_t E0, O0, E1, O1, E2, O2, E3, s0, s1, s2, s3;
+    uint32_t nO0, nE1, nO1, nE2, nO2, t1, t2, t3, t4, t5, t6, t7, m3, r0, r1, r2, r3, ph, o0, o1, o2, o3;
+    smask_t c1, c2, c3, c4, c5, c6, c7, c8, c9, ct, bw, cx;
+};
+
+__device__ __forceinline__ void mont_mul2_asm(Fe xa, Fe wa, Fe xb, Fe wb, Fe& ra, Fe& rb) {
+    MulState A, B;
+    A.a0 = lo32(xa.lo); A.a1 = hi32(xa.lo); A.a2 = lo32(xa.hi); A.a3 = hi32(xa.hi);
+    A.b0 = lo32(wa.lo); A.b1 = hi32(wa.lo); A.b2 = lo32(wa.hi); A.b3 = hi32(wa.hi);
+    B.a0 = lo32(xb.lo); B.a1 = hi32(xb.lo); B.a2 = lo32(xb.hi); B.a3 = hi32(xb.hi);
+    B.b0 = lo32(wb.lo); B.b1 = hi32(wb.lo); B.b2 = lo32(wb.hi); B.b3 = hi32(wb.hi);
+    const uint64_t zero64 = 0;
+    const uint32_t zero32 = 0, PHc = PH3;
+    smask_t dump;
+#define SC_BOTH(STEP) { MulState& M = A; STEP } { MulState& M = B; STEP }
+    // ---- product (the schedule of one product already keeps every counter >= 2 instructions behind its v_mad)
+    SC_BOTH(SC_V_MAD(M.E0, dump, M.a0, M.b0, zero64);)
+    SC_BOTH(SC_V_MAD(M.O0, dump, M.a0, M.b1, zero64);)
+    SC_BOTH(SC_V_MAD(M.E1, dump, M.a0, M.b2, zero64);)
+    SC_BOTH(SC_V_MAD(M.O0, M.c1, M.a1, M.b0, M.O0);)
+    SC_BOTH(SC_V_MAD(M.E1, M.c2, M.a1, M.b1, M.E1);)
+    SC_BOTH(SC_V_INC(M.nO0, zero32, M.c1, dump);)
+    SC_BOTH(SC_V_INC(M.nE1, zero32, M.c2, dump);)
+    SC_BOTH(SC_V_MAD(M.E1, M.c3, M.a2, M.b0, M.E1);)
+    SC_BOTH(SC_V_MAD(M.O1, dump, M.a0, M.b3, (uint64_t)M.nO0);)
+    SC_BOTH(SC_V_MAD(M.O1, M.c4, M.a1, M.b2, M.O1);)
+    SC_BOTH(SC_V_INC(M.nE1, M.nE1, M.c3, dump);)
+    SC_BOTH(SC_V_MAD(M.O1, M.c5, M.a2, M.b1, M.O1);)
+    SC_BOTH(SC_V_INC(M.nO1, zero32, M.c4, dump);)
+    SC_BOTH(SC_V_MAD(M.O1, M.c6, M.a3, M.b0, M.O1);)
+    SC_BOTH(SC_V_MAD(M.E2, dump, M.a1, M.b3, (uint64_t)M.nE1);)
+    SC_BOTH(SC_V_INC(M.nO1, M.nO1, M.c5, dump);)
+    SC_BOTH(SC_V_MAD(M.E2, M.c7, M.a2, M.b2, M.E2);)
+    SC_BOTH(SC_V_INC(M.nO1, M.nO1, M.c6, dump);)
+    SC_BOTH(SC_V_MAD(M.E2, M.c8, M.a3, M.b1, M.E2);)
+    SC_BOTH(SC_V_INC(M.nE2, zero32, M.c7, dump);)
+    SC_BOTH(SC_V_MAD(M.O2, dump, M.a2, M.b3, (uint64_t)M.nO1);)
+    SC_BOTH(SC_V_MAD(M.O2, M.c9, M.a3, M.b2, M.O2);)
+    SC_BOTH(SC_V_INC(M.nE2, M.nE2, M.c8, dump);)
+    SC_BOTH(SC_V_MAD(M.E3, dump, M.a3, M.b3, (uint64_t)M.nE2);)
+    SC_BOTH(SC_V_INC(M.nO2, zero32, M.c9, dump);)
+    // ---- merge T = E + (O << 32), interleaved with the reduction chain s0..s3 (t0 = lo32(E0))
+    SC_BOTH(SC_V_ADDCO(M.t1, M.ct, hi32(M.E0), lo32(M.O0));)
+    SC_BOTH(SC_V_MAD(M.s0, dump, lo32(M.E0), PHc, zero64);)
+    SC_BOTH(SC_V_ADDC(M.t2, M.ct, lo32(M.E1), hi32(M.O0), M.ct);)
+    SC_BOTH(SC_V_MAD(M.s1, dump, M.t1, PHc, (uint64_t)hi32(M.s0));)
+    SC_BOTH(SC_V_ADDC(M.t3, M.ct, hi32(M.E1), lo32(M.O1), M.ct);)
+    SC_BOTH(SC_V_MAD(M.s2, dump, M.t2, PHc, (uint64_t)hi32(M.s1));)
+    SC_BOTH(SC_V_SUBCO(M.m3, M.bw, M.t3, lo32(M.s0));)
+    SC_BOTH(SC_V_ADDC(M.t4, M.ct, lo32(M.E2), hi32(M.O1), M.ct);)
+    SC_BOTH(SC_V_MAD(M.s3, dump, M.m3, PHc, (uint64_t)hi32(M.s2));)
+    SC_BOTH(SC_V_ADDC(M.t5, M.ct, hi32(M.E2), lo32(M.O2), M.ct);)
+    SC_BOTH(SC_V_SUBB(M.r0, M.bw, M.t4, lo32(M.s1), M.bw);)
+    SC_BOTH(SC_V_ADDC(M.t6, M.ct, lo32(M.E3), hi32(M.O2), M.ct);)
+    SC_BOTH(SC_V_SUBB(M.r1, M.bw, M.t5, lo32(M.s2), M.bw);)
+    SC_BOTH(SC_V_ADDC(M.t7, M.cx, hi32(M.E3), M.nO2, M.ct);)
+    SC_BOTH(SC_V_SUBB(M.r2, M.bw, M.t6, lo32(M.s3), M.bw);)
+    SC_V_NOP0();
+    SC_BOTH(SC_V_SUBB(M.r3, M.bw, M.t7, hi32(M.s3), M.bw);)
+    SC_V_NOP0();
+    // ---- negative -> add p back
+    SC_BOTH(SC_V_CND(M.ph, zero32, PHc, M.bw);)
+    SC_BOTH(SC_V_ADDC(M.o0, M.cx, M.r0, zero32, M.bw);)
+    SC_V_NOP0();
+    SC_BOTH(SC_V_ADDC(M.o1, M.cx, M.r1, zero32, M.cx);)
+    SC_V_NOP0();
+    SC_BOTH(SC_V_ADDC(M.o2, M.cx, M.r2, zero32, M.cx);)
+    SC_V_NOP0();
+    SC_BOTH(SC_V_ADDC(M.o3, dump, M.r3, M.ph, M.cx);)
+#undef SC_BOTH
+    ra = Fe{((uint64_t)A.o1 << 32) | A.o0, ((uint64_t)A.o3 << 32) | A.o2};
+    rb = Fe{((uint64_t)B.o1 << 32) | B.o0, ((uint64_t)B.o3 << 32) | B.o2};
+    (void)dump;
+}
+
+// The sums and differences of TWO butterflies (u0 +- v0, u1 +- v1): four independent carry chains issued round-robin, so every
+// carry consumer is three instructions behind its producer and no `s_nop` is needed at all (fe_add_asm + fe_sub_asm spend 18 per
+// butterfly).  Same arithmetic as fe_add_asm / fe_sub_asm.
+struct AddSubState {
+    uint32_t u0, u1, u2, u3, v0, v1, v2, v3;
+    uint32_t r0, r1, r2, r3, t0, t1, t2, t3, d0, d1, d2, d3, ph, e0, e1, e2, e3, s0, s1, s2, s3;
+    smask_t ca, cb, bd, ce, sel;
+};
+
+__device__ __forceinline__ void fe_addsub2_asm(Fe ua, Fe va, Fe ub, Fe vb, Fe& sa, Fe& da, Fe& sb, Fe& db) {
+    AddSubState A, B;
+    A.u0 = lo32(ua.lo); A.u1 = hi32(ua.lo); A.u2 = lo32(ua.hi); A.u3 = hi32(ua.hi);
+    A.v0 = lo32(va.lo); A.v1 = hi32(va.lo); A.v2 = lo32(va.hi); A.v3 = hi32(va.hi);
+    B.u0 = lo32(ub.lo); B.u1 = hi32(ub.lo); B.u2 = lo32(ub.hi); B.u3 = hi32(ub.hi);
+    B.v0 = lo32(vb.lo); B.v1 = hi32(vb.lo); B.v2 = lo32(vb.hi); B.v3 = hi32(vb.hi);
+    const uint32_t zero32 = 0, one32 = 1, PHc = PH3;
+    smask_t dump;
+#define SC_BOTH(STEP) { AddSubState& M = A; STEP } { AddSubState& M = B; STEP }
+    // sum chain (r, carry ca) and difference chain (d, borrow bd), limb by limb
+    SC_BOTH(SC_V_ADDCO(M.r0, M.ca, M.u0, M.v0); SC_V_SUBCO(M.d0, M.bd, M.u0, M.v0);)
+    SC_BOTH(SC_V_ADDC(M.r1, M.ca, M.u1, M.v1, M.ca); SC_V_SUBB(M.d1, M.bd, M.u1, M.v1, M.bd);)
+    SC_BOTH(SC_V_ADDC(M.r2, M.ca, M.u2, M.v2, M.ca); SC_V_SUBB(M.d2, M.bd, M.u2, M.v2, M.bd);)
+    SC_BOTH(SC_V_ADDC(M.r3, M.ca, M.u3, M.v3, M.ca); SC_V_SUBB(M.d3, M.bd, M.u3, M.v3, M.bd);)
+    // sum - p (borrow cb)  |  difference + p where it borrowed (carry ce)
+    SC_BOTH(SC_V_SUBCO(M.t0, M.cb, M.r0, one32); SC_V_CND(M.ph, zero32, PHc, M.bd);)
+    SC_BOTH(SC_V_SUBB(M.t1, M.cb, M.r1, zero32, M.cb); SC_V_ADDC(M.e0, M.ce, M.d0, zero32, M.bd);)
+    SC_BOTH(SC_V_SUBB(M.t2, M.cb, M.r2, zero32, M.cb); SC_V_ADDC(M.e1, M.ce, M.d1, zero32, M.ce);)
+    SC_BOTH(SC_V_SUBB(M.t3, M.cb, M.r3, PHc, M.cb); SC_V_ADDC(M.e2, M.ce, M.d2, zero32, M.ce);)
+    // take sum - p where the sum carried out of bit 127 or did not borrow against p (the last step of the difference chain rides
+    // along so that it, too, stays three instructions behind its carry)
+    A.sel = A.ca | ~A.cb;
+    B.sel = B.ca | ~B.cb;
+    SC_BOTH(SC_V_CND(M.s0, M.r0, M.t0, M.sel); SC_V_ADDC(M.e3, dump, M.d3, M.ph, M.ce);)
+    SC_BOTH(SC_V_CND(M.s1, M.r1, M.t1, M.sel);)
+    SC_BOTH(SC_V_CND(M.s2, M.r2, M.t2, M.sel);)
+    SC_BOTH(SC_V_CND(M.s3, M.r3, M.t3, M.sel);)
+#undef SC_BOTH
+    sa = Fe{((uint64_t)A.s1 << 32) | A.s0, ((uint64_t)A.s3 << 32) | A.s2};
+    da = Fe{((uint64_t)A.e1 << 32) | A.e0, ((uint64_t)A.e3 << 32) | A.e2};
+    sb = Fe{((uint64_t)B.s1 << 32) | B.s0, ((uint64_t)B.s3 << 32) | B.s2};
+    db = Fe{((uint64_t)B.e1 << 32) | B.e0, ((uint64_t)B.e3 << 32) | B.e2};
+    (void)dump;
+}
+
 __device__ __forceinline__ Fe fe_add_asm(Fe a, Fe b) {
     smask_t c;
     uint32_t r0 = a_add_co(lo32(a.lo), lo32(b.lo), c);

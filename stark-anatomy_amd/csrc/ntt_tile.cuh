@@ -222,24 +222,51 @@ struct Round {
                 }
                 continue;
             }
+            // the E/2 butterflies of this stage: sums and differences first, then the twiddle multiplications two at a time
+            // (mont_mul2: two independent products interleaved so that their carry hazards cover each other).  All register
+            // indices stay compile-time constants: butterfly number bf <-> (i0, i1) is a fixed enumeration.
+            Fe dd[E / 2];
+            uint32_t ee[E / 2];
+            bool triv[E / 2];
 #pragma unroll
-            for (int i0 = 0; i0 < E; ++i0) {
-                if (i0 & (1 << bit)) continue;
+            for (int bf = 0; bf < E / 2; bf += 2) {
+                const int i0 = ((bf >> bit) << (bit + 1)) | (bf & ((1 << bit) - 1));     // bf with a 0 inserted at position `bit`
                 const int i1 = i0 | (1 << bit);
+                if (bf + 1 < E / 2) {
+                    const int j0 = (((bf + 1) >> bit) << (bit + 1)) | ((bf + 1) & ((1 << bit) - 1));
+                    const int j1 = j0 | (1 << bit);
+                    fe_addsub2(x[i0], x[i1], x[j0], x[j1], x[i0], dd[bf], x[j0], dd[bf + 1]);
+                } else {
+                    Fe u = x[i0], v = x[i1];
+                    x[i0] = fe_add(u, v);
+                    dd[bf] = fe_sub(u, v);
+                }
+            }
+#pragma unroll
+            for (int bf = 0; bf < E / 2; ++bf) {
+                const int i0 = ((bf >> bit) << (bit + 1)) | (bf & ((1 << bit) - 1));
                 const int g = i0 >> S;
                 const uint32_t fi_low = (uint32_t)(i0 & (F - 1)) & ((1u << bit) - 1u);
-                Fe u = x[i0], v = x[i1];
-                x[i0] = fe_add(u, v);
-                Fe d = fe_sub(u, v);
-                if (last && (bit == 0 || fi_low == 0)) {
-                    x[i1] = d;                  // twiddle is w^0 = 1 (row bit 0, or no low field bits in the last round)
+                triv[bf] = last && (bit == 0 || fi_low == 0);       // twiddle is w^0 = 1 (row bit 0, or no low field bits in the last round)
+                const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
+                ee[bf] = ((fi_low << sh) | row_lo) << tau;            // < R/2
+                if (q == 0 && bf == 0) set_prio(prio, 2);
+                if (q == S - 1 && bf == 0) set_prio(prio, 1);
+            }
+#pragma unroll
+            for (int bf = 0; bf < E / 2; bf += 2) {
+                const int ia = (((bf >> bit) << (bit + 1)) | (bf & ((1 << bit) - 1))) | (1 << bit);
+                if (bf + 1 < E / 2) {
+                    const int ib = ((((bf + 1) >> bit) << (bit + 1)) | ((bf + 1) & ((1 << bit) - 1))) | (1 << bit);
+                    if (!triv[bf] && !triv[bf + 1]) {
+                        mont_mul2(dd[bf], tw[(uint64_t)ee[bf] << tw_shift], dd[bf + 1], tw[(uint64_t)ee[bf + 1] << tw_shift], x[ia], x[ib]);
+                    } else {
+                        x[ia] = triv[bf] ? dd[bf] : mont_mul(dd[bf], tw[(uint64_t)ee[bf] << tw_shift]);
+                        x[ib] = triv[bf + 1] ? dd[bf + 1] : mont_mul(dd[bf + 1], tw[(uint64_t)ee[bf + 1] << tw_shift]);
+                    }
                 } else {
-                    const uint32_t row_lo = rr[g] & ((1u << sh) - 1u);
-                    const uint32_t e = ((fi_low << sh) | row_lo) << tau;     // < R/2
-                    x[i1] = mont_mul(d, tw[(uint64_t)e << tw_shift]);
+                    x[ia] = triv[bf] ? dd[bf] : mont_mul(dd[bf], tw[(uint64_t)ee[bf] << tw_shift]);
                 }
-                if (q == 0 && i0 == 0) set_prio(prio, 2);
-                if (q == S - 1 && i0 == 0) set_prio(prio, 1);
             }
             if (q == S - 1) set_prio(prio, 0);
         }
