@@ -180,7 +180,8 @@ struct Round {
         }
         if (P.twd_in) {
 #pragma unroll
-            for (int i = 0; i < E; ++i) x[i] = mont_mul(x[i], tin[i]);
+            for (int i = 0; i + 1 < E; i += 2) mont_mul2(x[i], tin[i], x[i + 1], tin[i + 1], x[i], x[i + 1]);
+            if (E & 1) x[E - 1] = mont_mul(x[E - 1], tin[E - 1]);
         }
     }
     SC_HD void gather_lds(int sh, Fe* x, const Fe* lds) const {
@@ -289,23 +290,47 @@ struct Round {
     }
     // last round (sh == 0): four-step twiddle (unless the next pass applies it on load), final scale, store
     SC_HD void scatter_global(const PassParams& P, const Fe* x) const {
+        Fe v[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[i] = x[i];
+        if (P.tw_enable) {
+            // the four-step twiddles of this thread's E elements first (table loads, or two-level lookups multiplied out in
+            // pairs), then the E products in pairs
+            Fe t[E];
+            if (P.twd) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const uint32_t k = bitrev32(row(i, 0), logR);
+                    const uint64_t colidx = ((((uint64_t)t_lo << logC) | cc[i >> S]) >> P.tw_col_shift) + P.tw_col_base;
+                    t[i] = P.twd[(uint64_t)k * P.twd_stride + colidx];
+                }
+            } else {
+                Fe a[E], b[E];
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const uint32_t k = bitrev32(row(i, 0), logR);
+                    const uint64_t colidx = ((((uint64_t)t_lo << logC) | cc[i >> S]) >> P.tw_col_shift) + P.tw_col_base;
+                    const uint64_t e = colidx * ((uint64_t)k * P.tw_row_k + (uint64_t)t_mid * P.tw_row_mid) * P.tw_scale;
+                    a[i] = P.tl[e & 4095u];
+                    b[i] = P.th[e >> 12];
+                }
+#pragma unroll
+                for (int i = 0; i + 1 < E; i += 2) mont_mul2(a[i], b[i], a[i + 1], b[i + 1], t[i], t[i + 1]);
+                if (E & 1) t[E - 1] = mont_mul(a[E - 1], b[E - 1]);
+            }
+#pragma unroll
+            for (int i = 0; i + 1 < E; i += 2) mont_mul2(v[i], t[i], v[i + 1], t[i + 1], v[i], v[i + 1]);
+            if (E & 1) v[E - 1] = mont_mul(v[E - 1], t[E - 1]);
+        }
+        if (P.scale_enable) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) v[i] = mont_mul(v[i], P.scale);
+        }
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const uint32_t r = row(i, 0), c = cc[i >> S];
-            const uint32_t k = bitrev32(r, logR);
-            Fe v = x[i];
-            if (P.tw_enable) {
-                const uint64_t colidx = ((((uint64_t)t_lo << logC) | c) >> P.tw_col_shift) + P.tw_col_base;
-                if (P.twd) {
-                    v = mont_mul(v, P.twd[(uint64_t)k * P.twd_stride + colidx]);
-                } else {
-                    const uint64_t e = colidx * ((uint64_t)k * P.tw_row_k + (uint64_t)t_mid * P.tw_row_mid) * P.tw_scale;
-                    v = mont_mul(v, pow2level(P.tl, P.th, e));
-                }
-            }
-            if (P.scale_enable) v = mont_mul(v, P.scale);
+            const uint32_t k = bitrev32(row(i, 0), logR), c = cc[i >> S];
             uint64_t j = (uint64_t)t_hi * P.out_hi + (uint64_t)t_mid * P.out_mid + (uint64_t)t_lo * P.out_lo + (uint64_t)k * P.out_rs + (uint64_t)c * P.out_cs;
-            P.out[j] = v;
+            P.out[j] = v[i];
         }
     }
 };
