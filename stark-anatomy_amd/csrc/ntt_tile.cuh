@@ -289,7 +289,21 @@ struct Round {
         for (int i = 0; i < E; ++i) lds[lds_index(row(i, sh), cc[i >> S], logC)] = x[i];
     }
     // last round (sh == 0): four-step twiddle (unless the next pass applies it on load), final scale, store
+    // the direct four-step twiddles of this thread's E output elements (PassParams::twd): issued early by the fixed-shape kernel,
+    // at the top of the last round, so that their latency hides behind that round's butterflies
+    SC_HD void load_twd(const PassParams& P, Fe* t) const {
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t k = bitrev32(row(i, 0), logR);
+            const uint64_t colidx = ((((uint64_t)t_lo << logC) | cc[i >> S]) >> P.tw_col_shift) + P.tw_col_base;
+            t[i] = P.twd[(uint64_t)k * P.twd_stride + colidx];
+        }
+    }
     SC_HD void scatter_global(const PassParams& P, const Fe* x) const {
+        Fe none[E];
+        scatter_global(P, x, none, false);
+    }
+    SC_HD void scatter_global(const PassParams& P, const Fe* x, const Fe (&twd_prefetched)[E], bool have_prefetched) const {
         Fe v[E];
 #pragma unroll
         for (int i = 0; i < E; ++i) v[i] = x[i];
@@ -298,11 +312,11 @@ struct Round {
             // pairs), then the E products in pairs
             Fe t[E];
             if (P.twd) {
+                if (have_prefetched) {
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const uint32_t k = bitrev32(row(i, 0), logR);
-                    const uint64_t colidx = ((((uint64_t)t_lo << logC) | cc[i >> S]) >> P.tw_col_shift) + P.tw_col_base;
-                    t[i] = P.twd[(uint64_t)k * P.twd_stride + colidx];
+                    for (int i = 0; i < E; ++i) t[i] = twd_prefetched[i];
+                } else {
+                    load_twd(P, t);
                 }
             } else {
                 Fe a[E], b[E];
@@ -411,6 +425,14 @@ struct FixedRounds {
         } else {
             R.gather_lds(SH, x, lds);
         }
+        Fe tpre[E];
+        bool prefetched = false;
+        if constexpr (ROUND + 1 == NR && NR > 1) {
+            if (P.tw_enable && P.twd) {
+                R.load_twd(P, tpre);            // in flight during this round's arithmetic
+                prefetched = true;
+            }
+        }
         // the degenerate stages of a zero-padded input lie in the first two rounds (the planner caps prune_log accordingly)
         const int prune = (ROUND <= 1) ? P.prune_log : 0;
         R.butterflies(SH, x, tw, 0, prune, ROUND + 1 == NR ? 1 : 0, P.prio_balance);
@@ -421,7 +443,7 @@ struct FixedRounds {
             stamp(4 + 2 * ROUND);
             FixedRounds<LOGE, GLR, GLC, ROUND + 1>::run(P, tile, tid, lds, tw, sync, wsync, stamp, wave_local);
         } else {
-            R.scatter_global(P, x);
+            R.scatter_global(P, x, tpre, prefetched);
             stamp(4 + 2 * ROUND);
         }
     }
