@@ -16,10 +16,11 @@ struct NttTuning {
     int single_pass_max_log = 11;
     int max_digit_log = -1;  // passes = ceil(logn / max_digit_log)
     int direct_tw_max_log = 22;  // direct four-step twiddle tables up to 2^this entries per pass (bigger ones cost more HBM than they save)
-    // a pass whose predecessor has a direct table applies that table on LOAD (PassParams::twd_in).  Measured (profiles/r02/
-    // ab_redc_waveLocal_twOnLoad.txt): +1-2 % from 2^22 up, where other workgroups hide the longer load phase; -5 % at 2^20,
-    // where the grid is a single wave of workgroups and the doubled load burst (table + data) is exposed.  -1 = by size.
-    int tw_on_load = -1;
+    // 1: a pass whose predecessor has a direct table applies that table on LOAD (PassParams::twd_in) instead of the predecessor
+    // applying it at its store.  Round-2 history (profiles/r02): on-load won +1-2 % from 2^22 up while the at-store variant waited
+    // for its table between the last butterfly and the store; since the fixed-shape kernels PREFETCH the table at the top of their
+    // last round, at-store wins everywhere (2^22 +3 %, LDE 2^18 -> 2^21 71 -> 63.5 us, 2^20 +8 %).  Kept as an option.
+    int tw_on_load = 0;
     int prune = 1;               // skip the degenerate top stages of a zero-padded first pass (PassParams::prune_log)
 };
 
@@ -29,7 +30,7 @@ inline NttTuning resolve_tuning(const NttTuning& in, int logn) {
     if (t.max_digit_log < 0) t.max_digit_log = small ? 10 : 8;
     if (t.max_tile_log < 0) t.max_tile_log = small ? 12 : 11;
     if (t.max_col_log < 0) t.max_col_log = small ? 4 : 6;
-    if (t.tw_on_load < 0) t.tw_on_load = small ? 0 : 1;
+    if (t.tw_on_load < 0) t.tw_on_load = 0;
     return t;
 }
 

@@ -21,7 +21,7 @@ def sc():
     assert starkcore.device_count() > 0, "no GPU visible: the HIP path is mandatory for these tests"
     starkcore.init()
     yield starkcore
-    for k, v in (("max_tile_log", -1), ("loge", 2), ("max_col_log", -1), ("min_tiles_log", 8), ("single_pass_max_log", 11), ("max_digit_log", -1), ("xcd_remap", 1), ("direct_tw_max_log", 22), ("fixed_shapes", 1), ("wave_local", 1), ("tw_on_load", -1)):
+    for k, v in (("max_tile_log", -1), ("loge", 2), ("max_col_log", -1), ("min_tiles_log", 8), ("single_pass_max_log", 11), ("max_digit_log", -1), ("xcd_remap", 1), ("direct_tw_max_log", 22), ("fixed_shapes", 1), ("wave_local", 1), ("tw_on_load", 0)):
         starkcore.set_tuning(k, v)
 
 
@@ -82,7 +82,7 @@ TUNINGS = [dict(max_tile_log=12, loge=3, max_digit_log=8), dict(max_tile_log=11,
 @pytest.mark.parametrize("tune", TUNINGS)
 def test_ntt_tunings_agree_with_oracle(sc, tune):
     defaults = dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1,
-                    wave_local=1, tw_on_load=-1)
+                    wave_local=1, tw_on_load=0)
     defaults.update(tune)
     for k, v in defaults.items():
         sc.set_tuning(k, v)
@@ -95,7 +95,7 @@ def test_ntt_tunings_agree_with_oracle(sc, tune):
             assert gpu_ntt(sc, data, n, root, 1) == C.intt(root, data, n), (tune, logn)
     finally:
         for k, v in dict(max_tile_log=-1, loge=2, max_col_log=-1, min_tiles_log=8, single_pass_max_log=11, max_digit_log=-1, xcd_remap=1, direct_tw_max_log=22, fixed_shapes=1,
-                         wave_local=1, tw_on_load=-1).items():
+                         wave_local=1, tw_on_load=0).items():
             sc.set_tuning(k, v)
 
 
