@@ -239,6 +239,9 @@ struct BatchExtras {
     const Fe* outer_tl = nullptr;
     const Fe* outer_th = nullptr;
     uint64_t outer_col_base = 0;
+    // the same outer twiddles as a direct table [len][batch] of THIS rank's slab (entry (r, c) = w_n^(r * (outer_col_base + c))
+    // [* scale]): one prefetched load + one modmul per element instead of two loads + two modmuls
+    const Fe* outer_twd = nullptr;
     int chunks_log = 0;
     // direct table of the inter-pass twiddles of a two-pass plan: [k < 2^digits[0]][b < len >> digits[0]] = w_len^(b*k)
     // (one coalesced load + one modmul per element instead of the two-level lookup's two loads + two modmuls)
@@ -318,6 +321,11 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
                 p.tw_row_mid = (m == 2) ? 1 : 0;
                 p.tl = ex.outer_tl;
                 p.th = ex.outer_th;
+                if (ex.outer_twd) {
+                    p.twd = ex.outer_twd;           // indexed by (natural row, LOCAL column)
+                    p.twd_stride = batch;
+                    p.tw_col_base = 0;
+                }
             }
             pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
         } else if (!lastp) {

@@ -296,7 +296,9 @@ struct Round {
         for (int i = 0; i < E; ++i) {
             const uint32_t k = bitrev32(row(i, 0), logR);
             const uint64_t colidx = ((((uint64_t)t_lo << logC) | cc[i >> S]) >> P.tw_col_shift) + P.tw_col_base;
-            t[i] = P.twd[(uint64_t)k * P.twd_stride + colidx];
+            // natural output row of element i: k for a column pass of the plain plans (tw_row_k = 1, tw_row_mid = 0), and
+            // t_mid + N_1 * k for the last pass of a batched two-pass column transform with a fused outer twiddle table
+            t[i] = P.twd[((uint64_t)k * P.tw_row_k + (uint64_t)t_mid * P.tw_row_mid) * P.twd_stride + colidx];
         }
     }
     SC_HD void scatter_global(const PassParams& P, const Fe* x) const {

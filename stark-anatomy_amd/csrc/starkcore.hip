@@ -92,6 +92,14 @@ __global__ void __launch_bounds__(256) twiddle_table_kernel(Fe* out, int logB, u
     out[i] = pow2level(tl, th, b * k * scale_exp);
 }
 
+// direct table of one rank's outer four-step twiddles: out[r * cols + c] = w^(r * (col_base + c)) [* n^-1 via th]
+__global__ void __launch_bounds__(256) outer_table_kernel(Fe* out, uint64_t count, int logcols, uint64_t col_base, const Fe* __restrict__ tl, const Fe* __restrict__ th) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t r = i >> logcols, c = i & ((1ull << logcols) - 1);
+    out[i] = pow2level(tl, th, r * (col_base + c));
+}
+
 // out = a * b (canonical in, canonical out)
 __global__ void __launch_bounds__(256) pointwise_mul_kernel(const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -280,6 +288,15 @@ struct PlanTables {      // power tables of one root of order n = 2^logn
     int twd_b_digit0 = 0;
     uint64_t last_use = 0;   // lookup tick (eviction order; see evict_tables)
 };
+struct OuterKey {        // direct outer-twiddle table of one rank's slab (multi-GPU column stage)
+    uint64_t lo, hi, order, len, batch, col_base;
+    int ninv;
+    bool operator<(const OuterKey& o) const { return std::tie(lo, hi, order, len, batch, col_base, ninv) < std::tie(o.lo, o.hi, o.order, o.len, o.batch, o.col_base, o.ninv); }
+};
+struct OuterTable {
+    Fe* d = nullptr;
+    uint64_t last_use = 0;
+};
 struct PowKey {
     uint64_t lo, hi, hi_count;
     bool operator<(const PowKey& o) const { return std::tie(lo, hi, hi_count) < std::tie(o.lo, o.hi, o.hi_count); }
@@ -298,6 +315,7 @@ struct Ctx {
     NttTuning tuning;
     std::map<PlanKey, PlanTables> plans;
     std::map<PowKey, PowTables> pows;
+    std::map<OuterKey, OuterTable> outers;
     uint64_t tick = 0;       // bumped by every table lookup
     bool foreign_streams = false;   // a caller-owned stream has been used (see pick_stream)
     DevBuf scratch[8];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging, 6: uploaded operands, 7: degree / exactness flag
@@ -447,6 +465,8 @@ void free_plans() {
     g.plans.clear();
     for (auto& kv : g.pows) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     g.pows.clear();
+    for (auto& kv : g.outers) hipFree(kv.second.d);
+    g.outers.clear();
 }
 
 // Cache eviction, least recently used first and NEVER an entry looked up recently: one API call makes at most a handful of
@@ -1228,6 +1248,25 @@ static int batch_ex_impl(const void* d_in, void* d_out, uint64_t len, uint64_t b
         ex.outer_tl = po->tl;
         ex.outer_th = outer_scale_ninv ? po->th_ninv : po->th;
         ex.outer_col_base = outer_col_base;
+        if (g.tuning.direct_tw_max_log > 0 && len * batch <= (1ull << g.tuning.direct_tw_max_log)) {
+            // a rank transforms the same slab shape over and over: keep its outer twiddles as a direct table (prefetched by the
+            // kernel at the top of its last round) instead of two table loads and an extra modmul per element
+            OuterKey ok{ort.lo, ort.hi, outer_order, len, batch, outer_col_base, outer_scale_ninv ? 1 : 0};
+            ++g.tick;
+            auto it = g.outers.find(ok);
+            if (it == g.outers.end()) {
+                SCCHK(evict_tables(g.outers, (size_t)16, [](OuterTable& t) { hipFree(t.d); }));
+                OuterTable t;
+                const uint64_t count = len * batch;
+                HIPCHK(hipMalloc((void**)&t.d, count * sizeof(Fe)));
+                hipLaunchKernelGGL(outer_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t.d, count, logbatch, outer_col_base, ex.outer_tl, ex.outer_th);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(st));
+                it = g.outers.emplace(ok, t).first;
+            }
+            it->second.last_use = g.tick;
+            ex.outer_twd = it->second.d;
+        }
         // get_plan may have rehashed the map: re-fetch the inner tables
         SCCHK(get_plan(rt, loglen, false, st, &pt));
         tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;

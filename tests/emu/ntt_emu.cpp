@@ -140,7 +140,7 @@ static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int log
     BatchExtras ex;
     ex.chunks_log = chunks_log;
     ex.out_ld = out_ld;
-    std::vector<Fe> otl, oth;
+    std::vector<Fe> otl, oth, otw;
     if (outer_root) {
         Fe o_m = to_mont(Fe{outer_root[0], outer_root[1]});
         const uint64_t on = 1ull << outer_logorder;
@@ -148,11 +148,17 @@ static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int log
         fill_table(otl, on < 4096 ? on : 4096, o_m, 1, fe_mont_one());
         fill_table(oth, on > 4096 ? on >> 12 : 1, o_m, 4096, sc_m);
         ex.outer_tl = otl.data(); ex.outer_th = oth.data(); ex.outer_col_base = outer_col_base;
+        if (inner_direct & 2) {
+            // the library's direct outer table (outer_table_kernel): [r][c] = w^(r * (col_base + c)) [* order^-1]
+            otw.resize(len * batch);
+            for (uint64_t i = 0; i < len * batch; ++i) otw[i] = pow2level(ex.outer_tl, ex.outer_th, (i >> logbatch) * (outer_col_base + (i & (batch - 1))));
+            ex.outer_twd = otw.data();
+        }
     }
     NttPlanDesc d;
     if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu, ex)) return -1;
     std::vector<Fe> itw;
-    if (inner_direct && d.npasses == 2) {
+    if ((inner_direct & 1) && d.npasses == 2) {
         // the library's direct inter-pass table (twiddle_table_kernel): [k][b] = w^(b*k), B = len >> digits[0]
         const int logB = loglen - d.digits[0];
         itw.resize(len);

@@ -180,13 +180,14 @@ def test_emu_batched(emu, cfg):
         ologn = loglen + logbatch + 2
         w = po.primitive_nth_root(1 << ologn)
         for col_base, ninv in ((0, 0), (bt * 3, 1)):
-            rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit,
-                                     w.to_bytes(16, "little"), ologn, col_base, ninv, 0, col_base & 1 or ninv)
-            assert rc > 0
             ints = synth.unpack_ints(expect)
             sc_ = pow(1 << ologn, P - 2, P) if ninv else 1
             want = [ints[r * bt + c] * pow(w, r * (col_base + c), P) * sc_ % P for r in range(ln) for c in range(bt)]
-            assert synth.unpack_ints(out.raw) == want, (cfg, col_base)
+            for tables in (col_base & 1 or ninv, 2, 3):          # bit 0: direct inter-pass table, bit 1: direct outer-twiddle table
+                rc = emu.emu_ntt_batched(data, out, kind, loglen, logbatch, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit,
+                                         w.to_bytes(16, "little"), ologn, col_base, ninv, 0, tables)
+                assert rc > 0
+                assert synth.unpack_ints(out.raw) == want, (cfg, col_base, tables)
     else:
         # chunked input [chunks][batch][len/chunks]
         for chunks_log in (1, 2):

@@ -1,3 +1,4 @@
-O=gpurun_out/r2n; mkdir -p $O
-(timeout 400 python tools/ab3.py '{"max_tile_log":10}' '{"max_tile_log":10,"max_col_log":2}' '{"max_tile_log":12}' '{"max_tile_log":12,"max_digit_log":9}' 2>&1 | grep -v amdgpu.ids) > $O/ab3_tiles.txt
-cat $O/ab3_tiles.txt
+O=gpurun_out/r2o; mkdir -p $O
+(timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -5) > $O/gpu_tests.txt
+(timeout 300 python tools/sharded_stage_timing.py 2>&1 | grep -v amdgpu.ids | head -5) > $O/sharded_stage_timing.txt
+tail -2 $O/gpu_tests.txt; cut -c1-520 $O/sharded_stage_timing.txt
