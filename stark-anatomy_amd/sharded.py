@@ -166,10 +166,13 @@ class ShardedNtt:
         return (R, C // self.world, 2)
 
     def _buf(self, key, shape):
-        b = self._bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
+        """persistent work buffers, one per (purpose, shape): forward and inverse alternate between two shapes per purpose and
+        neither should go back to the allocator in between"""
+        k = (key, tuple(shape))
+        b = self._bufs.get(k)
+        if b is None:
             b = torch.empty(shape, dtype=torch.int64, device=self.device)
-            self._bufs[key] = b
+            self._bufs[k] = b
         return b
 
     def synthetic_input(self, seed=1):
