@@ -359,7 +359,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(log2n) if not sharded else None, "kernel": "ntt_pass_kernel" if not sharded else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
-                         "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from profiles/ (PMC passes); kernel is VALU-bound (128-bit modmul), see DESIGN.md"},
+                         "valu_insts_per_launch": measured_valu(log2n) if not sharded else None,
+                         "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 and valu_insts (SQ_INSTS_VALU, wave-level) per launch from profiles/ (PMC passes); "
+                                 "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor (13 of 18.8 us at 2^20), see DESIGN.md 3.1"},
         }
         if sharded:
             out["config"]["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
@@ -606,6 +608,24 @@ def stark_census(sc, lib, field, log_fri):
     return {"ms": total * 1e3, "lde_and_commit_ms": t_lde_commit * 1e3, "coset_divide_ms": t_div * 1e3, "fri_prove_ms": t_fri * 1e3,
             "openings_ms": t_open * 1e3, "fri_rounds": fr.num_rounds(), "proof_objects": len(ps.objects),
             "proof_sha256_16": hashlib.sha256(ps.serialize()).hexdigest()[:16], "roots": [o.hex()[:16] for o in ps.objects[:3]]}
+
+
+def measured_valu(log2n):
+    """wave-level VALU instructions per ntt_pass_kernel launch from the committed PMC runs (profiles/*/pmc_summary.json), or None"""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+            for run, kernels in d.items():
+                if not run.endswith("_%d" % log2n):
+                    continue
+                for name, ctrs in kernels.items():
+                    if "ntt_pass" in name and "SQ_INSTS_VALU" in ctrs:
+                        best = ctrs["SQ_INSTS_VALU"]["avg_per_dispatch"]
+        except Exception:
+            pass
+    return best
 
 
 def measured_traffic(log2n):
