@@ -53,12 +53,46 @@ def main():
         if not ok:
             print("rank", rank, "MISMATCH at log2n", log2n, flush=True)
             break
+        if log2n <= 17:
+            ok &= poly_check(eng, rank, world, n, dev)
+            if not ok:
+                print("rank", rank, "POLY MISMATCH at log2n", log2n, flush=True)
+                break
     ok &= fri_check(rank, world, dev)
     dist.barrier()
     dist.destroy_process_group()
     if not ok:
         sys.exit(3)
     print("rank", rank, "ok")
+
+
+def poly_check(eng, rank, world, n, dev):
+    """SURVEY 8(e)-5 with the HIP engine on every rank: fast_multiply / fast_coset_divide cores on slabs (sc_scale_slab_dev,
+    sc_pointwise_mul_dev / _div_dev between the sharded transforms) against the oracle's products."""
+    from sharded import gather_natural
+    as_t = lambda vals: torch.from_numpy(np.frombuffer(synth.pack_ints(vals), dtype=np.int64).reshape(len(vals), 2).copy()).to(dev)
+    la, lb = n // 2 - 3, n // 2 + 1
+    a, b = synth.synth_ints(21, la), synth.synth_ints(22, lb)
+    root = po.primitive_nth_root(n)                           # product through the C oracle (ntt, Hadamard, intt: code/ntt.py:58-64)
+    pad = lambda v: synth.pack_ints(v) + bytes(16 * (n - len(v)))
+    prod = po.C.intt(root, po.C.pointwise_mul(po.C.ntt(root, pad(a), n), po.C.ntt(root, pad(b), n), n), n)
+    want = synth.unpack_ints(prod)[:la + lb - 1]
+    out = torch.empty(eng.local_shape(True), dtype=torch.int64, device=dev)
+    eng.multiply(eng.slab_of(as_t(a), "ta").clone(), eng.slab_of(as_t(b), "tb").clone(), out)
+    torch.cuda.synchronize()
+    got = synth.unpack_ints(gather_natural(out.cpu(), eng.n1, eng.n2, world).numpy().tobytes())
+    ok = got[:len(want)] == want and not any(got[len(want):])
+    q = torch.empty(eng.local_shape(True), dtype=torch.int64, device=dev)
+    eng.coset_divide(eng.slab_of(as_t(want), "ta").clone(), eng.slab_of(as_t(b), "tb").clone(), po.GENERATOR, q)
+    torch.cuda.synchronize()
+    gq = synth.unpack_ints(gather_natural(q.cpu(), eng.n1, eng.n2, world).numpy().tobytes())
+    ok = ok and gq[:la] == a and not any(gq[la:])
+    try:                                                     # a divisor with a zero on the coset: every rank raises together
+        eng.coset_divide(eng.slab_of(as_t(want), "ta").clone(), eng.slab_of(as_t([(-po.GENERATOR) % po.P, 1]), "tb").clone(), po.GENERATOR, q)
+        ok = False
+    except AssertionError as e:
+        ok = ok and "divide by zero" in str(e)
+    return bool(ok)
 
 
 def fri_check(rank, world, dev):
