@@ -168,6 +168,14 @@ int sc_fri_fold_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const
 int sc_merkle_commit(const void* elems, uint64_t N, uint8_t root_out[64]);                 /* Merkle.commit, merkle.py:13-14 */
 int sc_merkle_build(const void* elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree);
 int sc_merkle_build_dev(const void* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree, void* stream); /* sync (returns root) */
+/* The commit loop of Fri.commit (fri.py:66-94) without idle time on either side: the build is only ENQUEUED (the caller prepares
+ * the next round meanwhile); sc_merkle_root waits for it (once) and returns the root -- it works on every tree.
+ * sc_fri_fold_commit_dev = one round in one call: the fold of fri.py:85 into d_out (N/2 elements), then the asynchronous
+ * build of the tree over d_out. */
+int sc_merkle_build_async_dev(const void* d_elems, uint64_t N, sc_merkle_t** tree, void* stream);
+int sc_merkle_root(sc_merkle_t* tree, uint8_t root_out[64]);
+int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* d_out,
+                           sc_merkle_t** tree, void* stream);
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */
 int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out /* k*64*log2 N */);
 /* opened elements AND their paths in one call: elems_out[i] = d_elems[indices[i]] (d_elems = the device vector the tree was built from) */

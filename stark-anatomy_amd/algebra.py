@@ -121,7 +121,11 @@ class Field:
             assert(False), "Unknown field, can't return root of unity."
 
     def sample(self, byte_array):
-        acc = 0
-        for b in byte_array:
-            acc = (acc << 8) ^ int(b)
+        # algebra.py:123-127 folds the bytes in with acc = (acc << 8) ^ b: for byte values that is the big-endian integer
+        try:
+            acc = int.from_bytes(bytes(byte_array), "big")
+        except (TypeError, ValueError):
+            acc = 0
+            for b in byte_array:
+                acc = (acc << 8) ^ int(b)
         return FieldElement(acc % self.p, self)

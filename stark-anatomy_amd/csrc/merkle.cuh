@@ -428,6 +428,48 @@ __global__ void __launch_bounds__(256) merkle_open_kernel(const uint64_t* __rest
     o[quarter] = s[quarter];
 }
 
+// the same for up to QUERY_MAX_TREES (tree, vector) pairs in ONE launch (Fri.prove's query phase: 15-17 trees, ~30 launches
+// of a few microseconds each otherwise).  Per opened index: 4 * logN threads copy the path (as above), one more copies the
+// opened element.  thread_off / idx_off / path_off are exclusive prefix sums over the pairs.
+constexpr int QUERY_MAX_TREES = 32;
+struct QueryTree {
+    const uint64_t* levels;
+    const Fe* elems;
+    uint64_t N;
+    uint32_t logN;
+    uint32_t per_query;      // 4 * logN + 1 threads per opened index
+    uint64_t thread_off;     // first thread of this pair
+    uint64_t idx_off;        // first index / first output element of this pair
+    uint64_t path_off;       // first output digest of this pair
+};
+struct QueryTrees {
+    QueryTree t[QUERY_MAX_TREES];
+    uint64_t total_threads;
+    int count;
+};
+__global__ void __launch_bounds__(256) merkle_query_multi_kernel(QueryTrees Q, const uint64_t* __restrict__ indices, Fe* __restrict__ elems_out,
+                                                                 uint64_t* __restrict__ paths_out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Q.total_threads) return;
+    int w = 0;
+    for (int i = 1; i < Q.count; ++i) if (t >= Q.t[i].thread_off) w = i;
+    const QueryTree& T = Q.t[w];
+    const uint64_t local = t - T.thread_off;
+    const uint64_t q = local / T.per_query;
+    const uint32_t r = (uint32_t)(local % T.per_query);
+    const uint64_t idx = indices[T.idx_off + q];
+    if (r == T.per_query - 1) {
+        elems_out[T.idx_off + q] = T.elems[idx];
+        return;
+    }
+    const uint32_t quarter = r & 3, l = r >> 2;
+    const uint64_t off = (l == 0) ? 0 : (2 * T.N - (T.N >> (l - 1)));
+    const uint64_t node = (idx >> l) ^ 1ull;
+    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(T.levels + 8 * (off + node));
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(paths_out + 8 * (T.path_off + q * T.logN + l));
+    o[quarter] = s[quarter];
+}
+
 #endif  // __HIPCC__
 
 }  // namespace sc

@@ -259,6 +259,12 @@ struct sc_merkle {
     uint64_t* d_levels;   // (2N-1) digests of 8 x u64
     uint64_t N;
     int logN;
+    // asynchronous builds (sc_merkle_build_async_dev, sc_fri_fold_commit_dev): the root is on its way to a pinned host slot;
+    // sc_merkle_root waits for `st` once and moves it to `root`
+    int slot = -1;
+    hipStream_t st = nullptr;
+    bool have_root = false;
+    uint8_t root[64] = {};
 };
 
 namespace {
@@ -326,7 +332,11 @@ struct Ctx {
     int wave_local = 1;      // wave-level fences instead of workgroup barriers once a tile's exchanges stay inside one wave
     unsigned long long* trace = nullptr;   // diagnostics: phase stamps of the next fixed-shape pass launches (sc_debug_trace)
     int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)
+    uint8_t* root_slots = nullptr;        // pinned host memory: roots of asynchronously built Merkle trees in flight
+    std::vector<int> free_root_slots;
 };
+constexpr int ROOT_SLOTS = 256;
+constexpr int SPIN_QUERIES = 4000;
 
 Ctx g;
 std::mutex g_mu;
@@ -731,8 +741,25 @@ int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
 // finish a tree whose level 0 (the `width` digests at `levels`) is already in place
 int merkle_finish(uint64_t* levels, uint64_t width, hipStream_t st) { return merkle_climb(levels, width, 0, st); }
 
-int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st) {
+// pinned host slots the roots of asynchronously built trees are copied to (64 bytes each)
+int root_slot_get() {
+    if (!g.root_slots) {
+        if (hipHostMalloc((void**)&g.root_slots, 64 * ROOT_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.root_slots = nullptr; return -1; }
+        for (int i = ROOT_SLOTS - 1; i >= 0; --i) g.free_root_slots.push_back(i);
+    }
+    if (g.free_root_slots.empty()) return -1;
+    const int s = g.free_root_slots.back();
+    g.free_root_slots.pop_back();
+    return s;
+}
+
+// async: nothing is waited for; the root travels to a pinned slot behind the build (tree required).  Without a free slot the
+// call degrades to the synchronous form.
+int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st, bool async = false) {
     if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
+    const int slot = (async && tree) ? root_slot_get() : -1;
+    uint8_t root_tmp[64];
+    if (!root_out) root_out = root_tmp;
     uint64_t* levels = nullptr;
     const size_t tree_bytes = (2 * N - 1) * 64;
     HIPCHK(pool_alloc((void**)&levels, tree_bytes));
@@ -751,16 +778,44 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
         (void)merkle_climb(levels, N, 0, st);
     }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) { if (slot >= 0) g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    if (slot >= 0) {
+        e = hipMemcpyAsync(g.root_slots + 64 * slot, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) { g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+        sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
+        t->slot = slot;
+        t->st = st;
+        *tree = t;
+        return SC_OK;
+    }
     e = hipMemcpyAsync(root_out, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
     if (tree) {
         sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
+        memcpy(t->root, root_out, 64);
+        t->have_root = true;
         *tree = t;
     } else {
         pool_free(levels, tree_bytes);
     }
+    return SC_OK;
+}
+
+// the root of a tree, waiting for an asynchronous build if that is what made it
+int merkle_root_wait(sc_merkle* t) {
+    if (t->have_root) return SC_OK;
+    if (t->slot < 0) return fail(SC_ERR_BAD_ARG, "tree has no root");
+    // the prover's serial chain waits here once per round: poll (a blocking wait that has gone to sleep costs tens of
+    // microseconds to wake up), fall back to the blocking form after a few milliseconds
+    hipError_t e = hipErrorNotReady;
+    for (int spin = 0; spin < SPIN_QUERIES && e == hipErrorNotReady; ++spin) e = hipStreamQuery(t->st);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); e = hipStreamSynchronize(t->st); }
+    memcpy(t->root, g.root_slots + 64 * t->slot, 64);
+    g.free_root_slots.push_back(t->slot);
+    t->slot = -1;
+    if (e != hipSuccess) return fail(SC_ERR_HIP, hipGetErrorString(e));
+    t->have_root = true;
     return SC_OK;
 }
 
@@ -1565,6 +1620,31 @@ int sc_merkle_build_dev(const void* d_elems, uint64_t N, uint8_t root_out[64], s
     SCCHK(ensure_init());
     return merkle_build_device((const Fe*)d_elems, N, root_out, tree, pick_stream(stream));
 }
+// the build is enqueued and the call returns; sc_merkle_root waits.  (The host prepares the next round while the device hashes.)
+int sc_merkle_build_async_dev(const void* d_elems, uint64_t N, sc_merkle_t** tree, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_elems) return fail(SC_ERR_BAD_ARG, "null argument");
+    return merkle_build_device((const Fe*)d_elems, N, nullptr, tree, pick_stream(stream), true);
+}
+int sc_merkle_root(sc_merkle_t* tree, uint8_t root_out[64]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!tree || !root_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    SCCHK(merkle_root_wait(tree));
+    memcpy(root_out, tree->root, 64);
+    return SC_OK;
+}
+// one round of Fri.commit in one call (fri.py:73-88): split-and-fold with alpha, then the Merkle tree of the folded codeword;
+// nothing is waited for (sc_merkle_root fetches the root)
+int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* d_out,
+                           sc_merkle_t** tree, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_in || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    hipStream_t st = pick_stream(stream);
+    SCCHK(fold_device((const Fe*)d_in, N, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)d_out, st));
+    return merkle_build_device((const Fe*)d_out, N / 2, nullptr, tree, st, true);
+}
 int sc_merkle_build(const void* elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
@@ -1647,18 +1727,30 @@ int sc_merkle_query_multi_dev(uint64_t n, const sc_merkle_t* const* trees, const
     Fe* d_el = (Fe*)((char*)buf + idx_bytes);
     uint64_t* d_paths = (uint64_t*)((char*)buf + idx_bytes + el_bytes);
     SCCHK(upload(d_idx, indices, total * 8, g.stream));
+    // one launch per QUERY_MAX_TREES pairs (Fri.prove: one launch)
     uint64_t off = 0, poff = 0;
-    for (uint64_t t = 0; t < n; ++t) {
-        const uint64_t k = counts[t];
-        if (!k) continue;
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, g.stream, (const Fe*)d_elems[t], d_idx + off, k, d_el + off);
-        if (trees[t]->logN > 0) {
-            const uint64_t threads = k * (uint64_t)trees[t]->logN * 4;
-            hipLaunchKernelGGL(merkle_open_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g.stream, trees[t]->d_levels, trees[t]->N, trees[t]->logN,
-                               d_idx + off, k, d_paths + poff);
+    for (uint64_t t0 = 0; t0 < n; t0 += QUERY_MAX_TREES) {
+        QueryTrees Q;
+        Q.count = 0;
+        Q.total_threads = 0;
+        for (uint64_t t = t0; t < n && t < t0 + QUERY_MAX_TREES; ++t) {
+            const uint64_t k = counts[t];
+            if (!k) continue;
+            QueryTree& T = Q.t[Q.count++];
+            T.levels = trees[t]->d_levels;
+            T.elems = (const Fe*)d_elems[t];
+            T.N = trees[t]->N;
+            T.logN = (uint32_t)trees[t]->logN;
+            T.per_query = 4 * T.logN + 1;
+            T.thread_off = Q.total_threads;
+            T.idx_off = off;
+            T.path_off = poff;
+            Q.total_threads += k * T.per_query;
+            off += k;
+            poff += k * (uint64_t)trees[t]->logN;
         }
-        off += k;
-        poff += k * 8 * (uint64_t)trees[t]->logN;
+        if (!Q.count) continue;
+        hipLaunchKernelGGL(merkle_query_multi_kernel, dim3((unsigned)((Q.total_threads + 255) / 256)), dim3(256), 0, g.stream, Q, d_idx, d_el, d_paths);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(elems_out, d_el, total * sizeof(Fe), hipMemcpyDeviceToHost, g.stream));
@@ -1694,6 +1786,8 @@ int sc_merkle_from_digests_dev(const void* d_digests, uint64_t count, uint8_t ro
     }
     if (rc != SC_OK) { pool_free(levels, tree_bytes); return rc; }
     *tree = new sc_merkle{levels, count, ilog2(count)};
+    memcpy((*tree)->root, root_out, 64);
+    (*tree)->have_root = true;
     return SC_OK;
 }
 
@@ -1722,6 +1816,7 @@ uint64_t sc_merkle_leaves(const sc_merkle_t* tree) { return tree ? tree->N : 0; 
 int sc_merkle_free(sc_merkle_t* tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree) return SC_OK;
+    if (tree->slot >= 0) (void)merkle_root_wait(tree);        // a root still in flight: let it land, return the slot
     sync_before_free();
     pool_free(tree->d_levels, (2 * tree->N - 1) * 64);
     delete tree;

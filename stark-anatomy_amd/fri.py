@@ -37,10 +37,14 @@ class Fri:
         return rounds
 
     def sample_index(byte_array, size):
-        acc = 0
-        for b in byte_array:
-            acc = (acc << 8) ^ int(b)
-        return acc % size
+        # fri.py:30-34 folds the bytes in with acc = (acc << 8) ^ b: the big-endian integer of the array
+        try:
+            return int.from_bytes(bytes(byte_array), "big") % size
+        except (TypeError, ValueError):
+            acc = 0
+            for b in byte_array:
+                acc = (acc << 8) ^ int(b)
+            return acc % size
 
     def sample_indices(self, seed, size, reduced_size, number):
         assert(number <= reduced_size), f"cannot sample more indices than available in last codeword; requested: {number}, available: {reduced_size}"
@@ -64,6 +68,10 @@ class Fri:
         return DeviceCodeword.from_list(codeword, self.field)
 
     def commit(self, codeword, proof_stream, round_index=0):
+        """fri.py:66-94.  The chain root -> alpha -> fold -> next root is strictly serial, so the loop keeps both sides busy:
+        a round's fold and tree are ENQUEUED in one library call (sc_fri_fold_commit_dev) and everything the host can do without
+        the root (the order check of the next omega, the next output vector) happens while the device hashes; only the
+        Fiat-Shamir step sits between a root arriving and the next launch."""
         omega, offset = self.omega, self.offset
         codeword = self._on_device(codeword)
         codewords = []
@@ -71,16 +79,16 @@ class Fri:
         for r in range(rounds):
             N = len(codeword)
             assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
-            # Merkle root of this round's codeword; the tree stays in HBM for the query phase
+            if r == 0:
+                codeword.start_tree()
+            folded = DeviceVector(N // 2) if r < rounds - 1 else None
+            # Merkle root of this round's codeword (waits for the device); the tree stays in HBM for the query phase
             proof_stream.push(codeword.tree().root)
             if r == rounds - 1:
                 break
             alpha = self.field.sample(proof_stream.prover_fiat_shamir())
             codewords.append(codeword)
-            folded = DeviceVector(N // 2)
-            _sc._check(_sc.lib().sc_fri_fold_dev(codeword.vec.ptr, N, _sc.fe_bytes(alpha.value), _sc.fe_bytes(offset.value),
-                                                 _sc.fe_bytes(omega.value), folded.ptr, None))
-            codeword = DeviceCodeword(folded, self.field)
+            codeword = codeword.fold_commit(alpha, offset, omega, folded)
             omega = omega ^ 2
             offset = offset ^ 2
         # the last codeword goes out in the clear, as a plain list (it is pickled into the transcript)

@@ -3,7 +3,9 @@
 This is the ONLY path from the host modules (ntt.py, fri.py, merkle.py) to the GPU.  There is no CPU
 fallback: if the shared library is missing or no MI355X is visible, calls raise RuntimeError.
 """
+import array
 import ctypes
+import itertools
 import os
 from collections.abc import Sequence
 
@@ -59,6 +61,9 @@ SIGNATURES = {
     "sc_merkle_commit": (_int, [_vp, _u64, _vp]),
     "sc_merkle_build": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp)]),
     "sc_merkle_build_dev": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp), _vp]),
+    "sc_merkle_build_async_dev": (_int, [_vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "sc_merkle_root": (_int, [_vp, _vp]),
+    "sc_fri_fold_commit_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
     "sc_merkle_open_batch": (_int, [_vp, _vp, _u64, _vp]),
     "sc_merkle_query_dev": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
@@ -215,7 +220,10 @@ def query_codewords(codewords, requests):
     returns [(entries, paths)] in the same order (entries identity-preserving, paths fresh objects)."""
     n = len(codewords)
     trees = [cw.tree() for cw in codewords]
-    flat = [int(i) for req in requests for i in req]
+    try:
+        flat = array.array("Q", itertools.chain.from_iterable(requests))  # (the upper bound is checked by the library)
+    except OverflowError:
+        raise AssertionError("cannot open invalid index")
     total = len(flat)
     if total == 0:
         return [([], []) for _ in codewords]
@@ -224,15 +232,15 @@ def query_codewords(codewords, requests):
     elems = ctypes.create_string_buffer(16 * total)
     paths = ctypes.create_string_buffer(path_bytes if path_bytes else 64)
     _check(lib().sc_merkle_query_multi_dev(n, (_vp * n)(*[t._h for t in trees]), (_vp * n)(*[cw.vec.ptr for cw in codewords]),
-                                           (ctypes.c_uint64 * total)(*flat), (ctypes.c_uint64 * n)(*[len(req) for req in requests]), elems, paths))
+                                           (ctypes.c_uint64 * total).from_buffer(flat), (ctypes.c_uint64 * n)(*[len(req) for req in requests]), elems, paths))
     values = unpack(elems.raw, total)
-    digests = _digest_struct(path_bytes // 64).unpack_from(paths) if path_bytes else ()
+    view = memoryview(paths)
     out, vo, po = [], 0, 0
     for cw, req, d in zip(codewords, requests, depths):
         k = len(req)
-        out.append((cw._entries(req, values[vo:vo + k]), [list(digests[po + q * d:po + (q + 1) * d]) for q in range(k)]))
+        out.append((cw._entries(req, values[vo:vo + k]), _path_lists(view, po, d, k)))
         vo += k
-        po += k * d
+        po += 64 * k * d
     return out
 
 
@@ -290,14 +298,31 @@ def _digest_struct(count):
     return st
 
 
+def _path_lists(view, offset, depth, k):
+    """k authentication paths of `depth` 64-byte digests each, packed back to back in `view` from byte `offset`, as the
+    reference's lists of fresh bytes objects (merkle.py:16-27).  One C-level pass per tree: the ~25 000 digest objects of a
+    2^22 Fri.prove are the largest host cost of its query phase."""
+    if depth == 0:
+        return [[] for _ in range(k)]
+    return list(map(list, _digest_struct(depth).iter_unpack(view[offset:offset + 64 * k * depth])))
+
+
 class MerkleTree:
     """Owner of an sc_merkle_t: all levels resident in HBM, so `open` is a gather (code/merkle.py:16-27)."""
 
     def __init__(self, handle, root, n):
         self._h = handle
-        self.root = root
+        self._root = root        # None: built asynchronously, fetched (and waited for) on first use
         self.n = n
         self.depth = n.bit_length() - 1
+
+    @property
+    def root(self):
+        if self._root is None:
+            out = ctypes.create_string_buffer(64)
+            _check(lib().sc_merkle_root(self._h, out))
+            self._root = out.raw
+        return self._root
 
     @classmethod
     def from_device(cls, vec):
@@ -305,6 +330,13 @@ class MerkleTree:
         h = _vp()
         _check(lib().sc_merkle_build_dev(vec.ptr, vec.n, root, ctypes.byref(h), None))
         return cls(h, root.raw, vec.n)
+
+    @classmethod
+    def from_device_async(cls, vec):
+        """the build is enqueued, not waited for: `.root` waits (the caller prepares its next step meanwhile)"""
+        h = _vp()
+        _check(lib().sc_merkle_build_async_dev(vec.ptr, vec.n, ctypes.byref(h), None))
+        return cls(h, None, vec.n)
 
     @classmethod
     def from_bytes(cls, data):
@@ -345,9 +377,7 @@ class MerkleTree:
         out = ctypes.create_string_buffer(64 * self.depth * k)
         _check(lib().sc_merkle_open_batch(self._h, idx, k, out))
         # one C-level pass creates all the 64-byte digest objects (they end up, one by one, in the transcript)
-        d = self.depth
-        digests = _digest_struct(d * k).unpack_from(out)
-        return [list(digests[q * d:(q + 1) * d]) for q in range(k)]
+        return _path_lists(memoryview(out), 0, self.depth, k)
 
     def open(self, index):
         return self.open_batch([index])[0]
@@ -443,6 +473,22 @@ class DeviceCodeword(Sequence):
             self._tree = MerkleTree.from_device(self.vec)
         return self._tree
 
+    def start_tree(self):
+        """enqueue the build of the tree and return at once (`tree().root` waits for it)"""
+        if self._tree is None:
+            self._tree = MerkleTree.from_device_async(self.vec)
+        return self._tree
+
+    def fold_commit(self, alpha, offset, omega, out_vec):
+        """One round of Fri.commit in one library call (fri.py:85 then the tree of the folded codeword, both only enqueued):
+        the folded DeviceCodeword, whose tree().root waits for the device."""
+        h = _vp()
+        _check(lib().sc_fri_fold_commit_dev(self.vec.ptr, self.vec.n, fe_bytes(alpha.value), fe_bytes(offset.value), fe_bytes(omega.value),
+                                            out_vec.ptr, ctypes.byref(h), None))
+        folded = DeviceCodeword(out_vec, self.field)
+        folded._tree = MerkleTree(h, None, out_vec.n)
+        return folded
+
     def query(self, indices):
         """One device round trip: the entries at `indices` (identity-preserving, like gather) and one freshly created
         authentication path per requested index (paths are new objects every time, as in the reference, which
@@ -456,8 +502,7 @@ class DeviceCodeword(Sequence):
         elems = ctypes.create_string_buffer(16 * k)
         paths = ctypes.create_string_buffer(64 * d * k if d else 64)
         _check(lib().sc_merkle_query_dev(tree._h, self.vec.ptr, idx, k, elems, paths))
-        digests = _digest_struct(d * k).unpack_from(paths) if d else ()
-        return self._entries(indices, unpack(elems.raw, k)), [list(digests[q * d:(q + 1) * d]) for q in range(k)]
+        return self._entries(indices, unpack(elems.raw, k)), _path_lists(memoryview(paths), 0, d, k)
 
     def _entries(self, indices, values):
         """FieldElement objects for freshly fetched residues, created once per index (see __init__)"""

@@ -565,3 +565,65 @@ def test_round2_device_entry_points(sc):
         sc._check(lib.sc_ntt_rows_t_ld_dev(pv.ptr, wide.ptr + 16 * blk * 8, ln, 8, sc.fe_bytes(rt), ch, bt, None))
         sc.synchronize()
     assert wide.to_bytes() == exp.tobytes()
+
+
+def test_async_commit_round_and_wide_query(sc):
+    """sc_merkle_build_async_dev / sc_merkle_root / sc_fri_fold_commit_dev against the synchronous entries and the oracle, and
+    sc_merkle_query_multi_dev over more (tree, vector) pairs than one launch takes (chunks of 32), a one-leaf tree among them."""
+    lib = sc.lib()
+    N = 1 << 11
+    data = packed(1500, N)
+    v = sc.DeviceVector.from_bytes(data)
+    t_async = sc.MerkleTree.from_device_async(v)
+    t_sync = sc.MerkleTree.from_device(v)
+    assert t_async.root == t_sync.root == C.merkle_commit(data, N)
+    assert t_async.root is t_async.root                       # fetched once
+    assert t_async.open_batch([0, 5, N - 1]) == t_sync.open_batch([0, 5, N - 1])
+    # many builds in flight (more than there are pinned root slots): every root still arrives
+    vs = [sc.DeviceVector.from_bytes(packed(1600 + i, 256)) for i in range(8)]
+    many = [sc.MerkleTree.from_device_async(vs[i % 8]) for i in range(300)]
+    for i, t in enumerate(many):
+        assert t.root == C.merkle_commit(packed(1600 + i % 8, 256), 256)
+    del many
+    unfetched = sc.MerkleTree.from_device_async(vs[0])         # freed with its root still in flight
+    del unfetched
+    # one commit round in one call
+    from algebra import Field
+    field = Field.main()
+    cw = sc.DeviceCodeword(v, field)
+    alpha, offset, omega = field.sample(b"a"), field.generator(), field.primitive_nth_root(N)
+    folded = cw.fold_commit(alpha, offset, omega, sc.DeviceVector(N // 2))
+    want = C.fold(data, N, alpha.value, offset.value, omega.value)
+    assert folded.tree().root == C.merkle_commit(want, N // 2)
+    assert folded.vec.to_bytes() == want
+    h = ctypes.c_void_p()
+    assert lib.sc_fri_fold_commit_dev(v.ptr, 12, sc.fe_bytes(1), sc.fe_bytes(1), sc.fe_bytes(1), v.ptr, ctypes.byref(h), None) == sc.SC_ERR_NOT_POW2
+    assert lib.sc_merkle_root(None, ctypes.create_string_buffer(64)) == -6          # SC_ERR_BAD_ARG
+    # 40 pairs in one query call
+    sizes = [1 << (1 + i % 9) for i in range(39)] + [1]
+    datas = [packed(1700 + i, n) for i, n in enumerate(sizes)]
+    vecs = [sc.DeviceVector.from_bytes(d) for d in datas]
+    trees = [sc.MerkleTree.from_device_async(x) for x in vecs]
+    reqs = [[(7 * i + j) % n for j in range(i % 4)] for i, n in enumerate(sizes)]
+    reqs[-1] = [0, 0]
+    n = len(sizes)
+    flat = [i for r in reqs for i in r]
+    el = ctypes.create_string_buffer(16 * len(flat))
+    pbytes = sum(64 * (m.bit_length() - 1) * len(r) for m, r in zip(sizes, reqs))
+    pa = ctypes.create_string_buffer(pbytes)
+    sc._check(lib.sc_merkle_query_multi_dev(n, (ctypes.c_void_p * n)(*[t._h for t in trees]), (ctypes.c_void_p * n)(*[x.ptr for x in vecs]),
+                                            (ctypes.c_uint64 * len(flat))(*flat), (ctypes.c_uint64 * n)(*[len(r) for r in reqs]), el, pa))
+    eo = po_ = 0
+    for d_, m, r in zip(datas, sizes, reqs):
+        d = m.bit_length() - 1
+        for i in r:
+            assert el.raw[eo:eo + 16] == d_[16 * i:16 * i + 16]
+            if d:
+                assert pa.raw[po_:po_ + 64 * d] == b"".join(C.merkle_open(d_, m, i))
+            eo += 16
+            po_ += 64 * d
+    assert eo == 16 * len(flat) and po_ == pbytes
+    fetched = sc.query_codewords([sc.DeviceCodeword(x, field) for x in vecs[:3]], [[0, 1], [], [3]])
+    assert [len(e) for e, _ in fetched] == [2, 0, 1] and fetched[2][1] == [C.merkle_open(datas[2], sizes[2], 3)]
+    with pytest.raises(AssertionError):
+        sc.query_codewords([sc.DeviceCodeword(vecs[0], field)], [[-1]])
