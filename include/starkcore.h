@@ -171,7 +171,7 @@ int sc_merkle_build_dev(const void* d_elems, uint64_t N, uint8_t root_out[64], s
 /* The commit loop of Fri.commit (fri.py:66-94) without idle time on either side: the build is only ENQUEUED (the caller prepares
  * the next round meanwhile); sc_merkle_root waits for it (once) and returns the root -- it works on every tree.
  * sc_fri_fold_commit_dev = one round in one call: the fold of fri.py:85 into d_out (N/2 elements), then the asynchronous
- * build of the tree over d_out. */
+ * build of the tree over d_out.  Fetch the root (or free the tree) before destroying a caller-owned stream the build ran on. */
 int sc_merkle_build_async_dev(const void* d_elems, uint64_t N, sc_merkle_t** tree, void* stream);
 int sc_merkle_root(sc_merkle_t* tree, uint8_t root_out[64]);
 int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* d_out,
