@@ -13,6 +13,7 @@ N > 1: four-step NTT sharded over the ranks with one RCCL all-to-all (see stark-
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -25,6 +26,7 @@ for p in (PKG, REPO):
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_ELEMENT_PER_TRANSFORM = 32   # read once + write once, 16-byte elements
+CLOCK_RAMP_MS = 150.0      # untimed load between the after-idle window and the reported one (see main)
 
 
 def cpu_baseline(sample_log2n):
@@ -306,22 +308,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def timed_window():
+        """the contract's measurement: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides;
+        (seconds on the host clock, max over ranks; milliseconds between HIP events on the launch stream)"""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(args.steps):
+            step()
+        e1.record(stream)
+        barrier()
+        dt = time.perf_counter() - t0
+        if sharded:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, e0.elapsed_time(e1)
+
+    # The board idles at a low clock and needs tens of milliseconds of load to reach its sustained one (profiles/r02/ramp_probe.txt:
+    # 79-82 us per 2^20 pair for the first ~5 ms after idle, 69 us from then on), so a short window straight after start-up
+    # measures the clock ramp as much as the transform.  `value` is the contract's window, run first, straight after start-up;
+    # then CLOCK_RAMP_MS of the same untimed steps and the same window once more, reported beside it as
+    # "clock_ramp.steady_state" (information only).  With the default 200 + 2000 steps the two agree to ~1 %.
+    elapsed, ev_ms = timed_window()
+    ramp_steps = max(1, min(20000, int(math.ceil(CLOCK_RAMP_MS * 1e-3 / (elapsed / args.steps)))))
+    for _ in range(ramp_steps):
         step()
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    for _ in range(args.steps):
-        step()
-    e1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
-    if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    steady_elapsed, steady_ev_ms = timed_window()
 
     # correctness guard inside the bench: the round trip must reproduce the input bit for bit
     ok = bool(torch.equal(z, x))
@@ -356,6 +372,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u128", "data": "synthetic",
             "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
                        "passes_per_transform": passes, "roundtrip_bit_exact": ok},
+            "clock_ramp": {"untimed_steps_between_windows": ramp_steps, "target_ms": CLOCK_RAMP_MS,
+                           "steady_state": {"value": 2.0 * total_n * args.steps / steady_elapsed, "ms_per_step": 1e3 * steady_elapsed / args.steps,
+                                            "avg_launch_us": steady_ev_ms * 1e3 / (args.steps * launches_per_step),
+                                            "roofline_frac": alg_bytes_per_launch / ((steady_ev_ms * 1e-3) / (args.steps * launches_per_step)) / 1e9 / HBM_PEAK_GBS},
+                           "note": "information only: the same W + K window repeated after the board has clocked up (`value` is the first window, straight after start-up)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(log2n) if not sharded else None, "kernel": "ntt_pass_kernel" if not sharded else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
@@ -504,18 +525,19 @@ def extras(sc, lib, stream=None):
     sc._check(lib.sc_coset_evaluate_dev(coeffs.ptr, N // 4, sc.fe_bytes(GEN), sc.fe_bytes(om.value), N, cwv.ptr, None))
     sc.synchronize()
     fr = Fri(field.generator(), om, N, 4, 40)
-    best = None
-    for _ in range(3):
-        cw = sc.DeviceCodeword(cwv, field)
+    best, runs = None, []
+    for _ in range(8):                   # every run is listed: the first pays allocations and tables, an occasional one a full
+        cw = sc.DeviceCodeword(cwv, field)   # collection of this process's heap (torch, numpy) by CPython's collector
         ps = ProofStream()
         t0 = time.perf_counter()
         fr.prove(cw, ps)
         dt = time.perf_counter() - t0
+        runs.append(round(dt * 1e3, 3))
         best = dt if best is None or dt < best else best
     t0 = time.perf_counter()
     verified = fr.verify(ps, [])        # outside the timed loop: the proof that was timed is a proof the verifier accepts
     res["fri_prove_2p22_ef4_s40"] = {"ms": best * 1e3, "rounds": fr.num_rounds(), "proof_objects": len(ps.objects), "verify_accepts": bool(verified),
-                                     "verify_s": time.perf_counter() - t0}
+                                     "verify_s": time.perf_counter() - t0, "runs_ms": runs}
     del cw, cwv, coeffs
     # configs[4] on ONE GPU: the polynomial-core call census of FastStark.prove replayed at
     # fri_domain_length 2^24, omicron_domain_length 2^22, 2 registers: 4 LDEs to 2^24, 2 coset divisions at 2^22,

@@ -324,6 +324,7 @@ struct Ctx {
     std::map<OuterKey, OuterTable> outers;
     uint64_t tick = 0;       // bumped by every table lookup
     bool foreign_streams = false;   // a caller-owned stream has been used (see pick_stream)
+    std::vector<hipStream_t> seen_streams;   // those streams, most recent last (at most SEEN_STREAMS; more: device-wide waits)
     DevBuf scratch[8];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging, 6: uploaded operands, 7: degree / exactness flag
     int num_cus = 256;
     int xcd_remap = 1;
@@ -430,13 +431,37 @@ int scratch(int slot, size_t bytes, void** out) {
 
 // A caller stream (the *_dev entries take one; sharded.py passes torch's) may still be reading a pooled buffer when it is
 // freed: once any foreign stream has been seen, frees wait for the whole device instead of the library stream only.
+constexpr size_t SEEN_STREAMS = 8;
 inline hipStream_t pick_stream(void* s) {
-    if (s && (hipStream_t)s != g.stream) g.foreign_streams = true;
+    if (s && (hipStream_t)s != g.stream) {
+        g.foreign_streams = true;
+        hipStream_t st = (hipStream_t)s;
+        if (g.seen_streams.size() <= SEEN_STREAMS && std::find(g.seen_streams.begin(), g.seen_streams.end(), st) == g.seen_streams.end())
+            g.seen_streams.push_back(st);
+    }
     return s ? (hipStream_t)s : g.stream;
 }
+// Before a buffer goes back to the pool nothing may still be using it.  Frees come in bursts when the streams are already
+// idle (a prover dropping its codewords and trees): ask each stream that has been used (a microsecond each) and wait only
+// for a busy one.  A stream that no longer answers (destroyed by its owner), or more streams than are tracked: wait for the
+// whole device.
 inline void sync_before_free() {
-    if (g.foreign_streams) (void)hipDeviceSynchronize();
-    else (void)hipStreamSynchronize(g.stream);
+    if (!g.foreign_streams) { (void)hipStreamSynchronize(g.stream); return; }
+    bool device_wide = g.seen_streams.size() > SEEN_STREAMS;
+    if (!device_wide) {
+        if (hipStreamQuery(g.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(g.stream); }
+        for (hipStream_t st : g.seen_streams) {
+            hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess) continue;
+            (void)hipGetLastError();
+            if (e == hipErrorNotReady && hipStreamSynchronize(st) == hipSuccess) continue;
+            (void)hipGetLastError();
+            device_wide = true;
+            g.seen_streams.clear();                   // stale handles: forget them, start over
+            break;
+        }
+    }
+    if (device_wide) (void)hipDeviceSynchronize();
 }
 inline Fe fe_from(const uint64_t v[2]) { return Fe{v[0], v[1]}; }
 inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }

@@ -3,6 +3,9 @@
 import os, sys, time, json
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd"))
+if "torch" in sys.argv[1:]:
+    import torch
+    torch.zeros(4, device="cuda").sum().item()
 import starkcore as sc, synth
 from algebra import Field
 from fri import Fri
