@@ -1160,7 +1160,9 @@ int sc_shutdown(void) {
     for (auto& b : g.scratch) { if (b.p) hipFree(b.p); b = DevBuf{}; }
     if (g.stream) hipStreamDestroy(g.stream);
     g.stream = nullptr;
-    g.init = false;
+    g.seen_streams.clear();
+    g.foreign_streams = false;
+    g.init = false;        // (the pinned root slots stay: a tree built asynchronously may still be freed after this)
     return SC_OK;
 }
 
