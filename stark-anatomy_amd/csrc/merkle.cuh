@@ -428,6 +428,13 @@ __global__ void __launch_bounds__(256) merkle_open_kernel(const uint64_t* __rest
     o[quarter] = s[quarter];
 }
 
+// root of a finished tree -> a pinned, host-coherent slot: 8 words, then (ordered behind them) the sequence number the host polls
+__global__ void __launch_bounds__(64) root_publish_kernel(const uint64_t* __restrict__ root, volatile uint64_t* host, uint64_t seq) {
+    if (threadIdx.x < 8) host[threadIdx.x] = root[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) host[8] = seq;
+}
+
 // the same for up to QUERY_MAX_TREES (tree, vector) pairs in ONE launch (Fri.prove's query phase: 15-17 trees, ~30 launches
 // of a few microseconds each otherwise).  Per opened index: 4 * logN threads copy the path (as above), one more copies the
 // opened element.  thread_off / idx_off / path_off are exclusive prefix sums over the pairs.

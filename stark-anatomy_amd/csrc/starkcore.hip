@@ -262,6 +262,7 @@ struct sc_merkle {
     // asynchronous builds (sc_merkle_build_async_dev, sc_fri_fold_commit_dev): the root is on its way to a pinned host slot;
     // sc_merkle_root waits for `st` once and moves it to `root`
     int slot = -1;
+    uint64_t seq = 0;
     hipStream_t st = nullptr;
     bool have_root = false;
     uint8_t root[64] = {};
@@ -334,10 +335,12 @@ struct Ctx {
     unsigned long long* trace = nullptr;   // diagnostics: phase stamps of the next fixed-shape pass launches (sc_debug_trace)
     int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)
     uint8_t* root_slots = nullptr;        // pinned host memory: roots of asynchronously built Merkle trees in flight
+    uint64_t root_seq = 0;
     std::vector<int> free_root_slots;
 };
 constexpr int ROOT_SLOTS = 256;
-constexpr int SPIN_QUERIES = 4000;
+constexpr size_t ROOT_SLOT_BYTES = 128;   // 64-byte root, then the 8-byte sequence number that says it has landed
+constexpr long SPIN_POLLS = 40000000;     // ~ tens of milliseconds of polling before the blocking wait
 
 Ctx g;
 std::mutex g_mu;
@@ -769,7 +772,8 @@ int merkle_finish(uint64_t* levels, uint64_t width, hipStream_t st) { return mer
 // pinned host slots the roots of asynchronously built trees are copied to (64 bytes each)
 int root_slot_get() {
     if (!g.root_slots) {
-        if (hipHostMalloc((void**)&g.root_slots, 64 * ROOT_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.root_slots = nullptr; return -1; }
+        if (hipHostMalloc((void**)&g.root_slots, ROOT_SLOT_BYTES * ROOT_SLOTS, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); g.root_slots = nullptr; return -1; }
+        memset(g.root_slots, 0, ROOT_SLOT_BYTES * ROOT_SLOTS);
         for (int i = ROOT_SLOTS - 1; i >= 0; --i) g.free_root_slots.push_back(i);
     }
     if (g.free_root_slots.empty()) return -1;
@@ -805,10 +809,16 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (slot >= 0) g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
     if (slot >= 0) {
-        e = hipMemcpyAsync(g.root_slots + 64 * slot, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
+        // the root is WRITTEN to the host slot by a one-wave kernel behind the build (then its sequence number): the waiting
+        // host sees it a microsecond later, without a copy engine, a completion signal or a runtime call in between
+        const uint64_t seq = ++g.root_seq;
+        hipLaunchKernelGGL(root_publish_kernel, dim3(1), dim3(64), 0, st, (const uint64_t*)(levels + 8 * (2 * N - 2)),
+                           (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * slot), seq);
+        e = hipGetLastError();
         if (e != hipSuccess) { g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
         sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
         t->slot = slot;
+        t->seq = seq;
         t->st = st;
         *tree = t;
         return SC_OK;
@@ -831,12 +841,28 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
 int merkle_root_wait(sc_merkle* t) {
     if (t->have_root) return SC_OK;
     if (t->slot < 0) return fail(SC_ERR_BAD_ARG, "tree has no root");
-    // the prover's serial chain waits here once per round: poll (a blocking wait that has gone to sleep costs tens of
-    // microseconds to wake up), fall back to the blocking form after a few milliseconds
-    hipError_t e = hipErrorNotReady;
-    for (int spin = 0; spin < SPIN_QUERIES && e == hipErrorNotReady; ++spin) e = hipStreamQuery(t->st);
-    if (e == hipErrorNotReady) { (void)hipGetLastError(); e = hipStreamSynchronize(t->st); }
-    memcpy(t->root, g.root_slots + 64 * t->slot, 64);
+    // the prover's serial chain waits here once per round: poll the slot's sequence number (a blocking wait that has gone to
+    // sleep costs tens of microseconds to wake up); every so often ask the stream, so that a failed launch cannot hang the
+    // caller, and after a few milliseconds block
+    volatile uint64_t* slot = (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * t->slot);
+    hipError_t e = hipSuccess;
+    bool landed = false;
+    for (long spin = 0; spin < SPIN_POLLS; ++spin) {
+        if (__atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == t->seq) { landed = true; break; }
+        if ((spin & 4095) == 4095) {
+            e = hipStreamQuery(t->st);
+            if (e != hipErrorNotReady) break;              // finished (the number is there now) or failed
+            (void)hipGetLastError();
+            e = hipSuccess;
+        }
+    }
+    if (!landed) {
+        if (e == hipSuccess || e == hipErrorNotReady) { (void)hipGetLastError(); e = hipStreamSynchronize(t->st); }
+        landed = (e == hipSuccess) && __atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == t->seq;
+        if (e == hipSuccess && !landed) e = hipErrorUnknown;
+    }
+    memcpy(t->root, (const void*)slot, 64);
+    if (e != hipSuccess) (void)hipStreamSynchronize(t->st);      // nothing may still write to the slot when it is reused
     g.free_root_slots.push_back(t->slot);
     t->slot = -1;
     if (e != hipSuccess) return fail(SC_ERR_HIP, hipGetErrorString(e));
@@ -847,12 +873,31 @@ int merkle_root_wait(sc_merkle* t) {
 int fold_device(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st) {
     if (N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
     if (fe_is_zero(offset) || fe_is_zero(omega)) return fail(SC_ERR_DIV_ZERO, "divide by zero");
-    // omega^-1 power tables; c = alpha / (2 * offset)
-    Fe winv = from_mont(mont_inv(to_mont(omega)));
+    // omega^-1 power tables; c = alpha / (2 * offset).  Consecutive rounds of Fri.commit square omega and offset (fri.py:86-87):
+    // then 1/omega' = (1/omega)^2 and 1/(2 offset') = 2 (1/(2 offset))^2 -- three products instead of two ~250-product inversions
+    // on the hand-over between rounds; the products are checked, anything else takes the inversions.
+    static Fe prev_omega_m = Fe{0, 0}, prev_offset_m = Fe{0, 0}, prev_winv_m = Fe{0, 0}, prev_i2o_m = Fe{0, 0};
+    static bool have_prev = false;
+    const Fe omega_m = to_mont(omega), offset_m = to_mont(offset);
+    const Fe two_off_m = fe_add(offset_m, offset_m);
+    Fe winv_m, i2o_m;
+    bool derived = false;
+    if (have_prev && fe_eq(omega_m, mont_mul(prev_omega_m, prev_omega_m)) && fe_eq(offset_m, mont_mul(prev_offset_m, prev_offset_m))) {
+        winv_m = mont_mul(prev_winv_m, prev_winv_m);
+        Fe sq = mont_mul(prev_i2o_m, prev_i2o_m);
+        i2o_m = fe_add(sq, sq);
+        derived = fe_eq(mont_mul(winv_m, omega_m), fe_mont_one()) && fe_eq(mont_mul(i2o_m, two_off_m), fe_mont_one());
+    }
+    if (!derived) {
+        winv_m = mont_inv(omega_m);
+        i2o_m = mont_inv(two_off_m);
+    }
+    prev_omega_m = omega_m; prev_offset_m = offset_m; prev_winv_m = winv_m; prev_i2o_m = i2o_m;
+    have_prev = true;
+    Fe winv = from_mont(winv_m);
     PowTables* pw;
     SCCHK(get_pow(winv, N / 2, st, &pw));
-    Fe two_off = fe_add(offset, offset);
-    Fe c_m = mont_mul(to_mont(alpha), mont_inv(to_mont(two_off)));     // alpha~ * (2 offset)^-1~ / R = c~
+    Fe c_m = mont_mul(to_mont(alpha), i2o_m);     // alpha~ * (2 offset)^-1~ / R = c~
     uint64_t half = N / 2;
     hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, d_in, d_out, half, pw->lo, pw->hi, c_m);
     HIPCHK(hipGetLastError());
