@@ -182,6 +182,26 @@ __device__ __forceinline__ Fe mont_mul_asm(Fe a, Fe b) {
 #define SC_V_CND(d, x, y, m)       asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "s"(m))
 #define SC_V_NOP0()                asm volatile("s_nop 0")
 
+// Carry-outs nobody reads.  hipcc cannot look inside an asm statement, so on gfx950 it assumes the worst whenever an asm statement
+// touches a register the PREVIOUS asm statement defined (the dst-forwarding hazard) and puts an `s_nop 0` between them -- with one
+// shared dump register that is after every v_mad_u64_u32.  Chain A dumps into vcc, chain B into s[100:101] (named in the text and
+// declared as clobbers), so that neighbouring statements of the interleave never share a register.
+template <int W> __device__ __forceinline__ void v_mad_dump(uint64_t& d, uint32_t x, uint32_t y, uint64_t c) {
+    if constexpr (W == 0) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(c) : "vcc");
+    else asm volatile("v_mad_u64_u32 %0, s[100:101], %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(c) : "s100", "s101");
+}
+template <int W> __device__ __forceinline__ void v_inc_dump(uint32_t& d, uint32_t x, smask_t ci) {
+    if constexpr (W == 0) asm volatile("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(d) : "v"(x), "s"(ci) : "vcc");
+    else asm volatile("v_addc_co_u32_e64 %0, s[100:101], %1, 0, %2" : "=v"(d) : "v"(x), "s"(ci) : "s100", "s101");
+}
+template <int W> __device__ __forceinline__ void v_addc_dump(uint32_t& d, uint32_t x, uint32_t y, smask_t ci) {
+    if constexpr (W == 0) asm volatile("v_addc_co_u32_e64 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "s"(ci) : "vcc");
+    else asm volatile("v_addc_co_u32_e64 %0, s[100:101], %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "s"(ci) : "s100", "s101");
+}
+#define SC_V_MADD(d, x, y, c)      v_mad_dump<W>(d, x, y, c)
+#define SC_V_INCD(d, x, ci)        v_inc_dump<W>(d, x, ci)
+#define SC_V_ADDCD(d, x, y, ci)    v_addc_dump<W>(d, x, y, ci)
+
 struct MulState {       // registers of one product in flight
     uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
     uint64_t E0, O0, E1, O1, E2, O2, E3, s0, s1, s2, s3;
@@ -197,44 +217,43 @@ __device__ __forceinline__ void mont_mul2_asm(Fe xa, Fe wa, Fe xb, Fe wb, Fe& ra
     B.b0 = lo32(wb.lo); B.b1 = hi32(wb.lo); B.b2 = lo32(wb.hi); B.b3 = hi32(wb.hi);
     const uint64_t zero64 = 0;
     const uint32_t zero32 = 0, PHc = PH3;
-    smask_t dump;
-#define SC_BOTH(STEP) { MulState& M = A; STEP } { MulState& M = B; STEP }
+#define SC_BOTH(STEP) { MulState& M = A; constexpr int W = 0; STEP } { MulState& M = B; constexpr int W = 1; STEP }
     // ---- product (the schedule of one product already keeps every counter >= 2 instructions behind its v_mad)
-    SC_BOTH(SC_V_MAD(M.E0, dump, M.a0, M.b0, zero64);)
-    SC_BOTH(SC_V_MAD(M.O0, dump, M.a0, M.b1, zero64);)
-    SC_BOTH(SC_V_MAD(M.E1, dump, M.a0, M.b2, zero64);)
+    SC_BOTH(SC_V_MADD(M.E0, M.a0, M.b0, zero64);)
+    SC_BOTH(SC_V_MADD(M.O0, M.a0, M.b1, zero64);)
+    SC_BOTH(SC_V_MADD(M.E1, M.a0, M.b2, zero64);)
     SC_BOTH(SC_V_MAD(M.O0, M.c1, M.a1, M.b0, M.O0);)
     SC_BOTH(SC_V_MAD(M.E1, M.c2, M.a1, M.b1, M.E1);)
-    SC_BOTH(SC_V_INC(M.nO0, zero32, M.c1, dump);)
-    SC_BOTH(SC_V_INC(M.nE1, zero32, M.c2, dump);)
+    SC_BOTH(SC_V_INCD(M.nO0, zero32, M.c1);)
+    SC_BOTH(SC_V_INCD(M.nE1, zero32, M.c2);)
     SC_BOTH(SC_V_MAD(M.E1, M.c3, M.a2, M.b0, M.E1);)
-    SC_BOTH(SC_V_MAD(M.O1, dump, M.a0, M.b3, (uint64_t)M.nO0);)
+    SC_BOTH(SC_V_MADD(M.O1, M.a0, M.b3, (uint64_t)M.nO0);)
     SC_BOTH(SC_V_MAD(M.O1, M.c4, M.a1, M.b2, M.O1);)
-    SC_BOTH(SC_V_INC(M.nE1, M.nE1, M.c3, dump);)
+    SC_BOTH(SC_V_INCD(M.nE1, M.nE1, M.c3);)
     SC_BOTH(SC_V_MAD(M.O1, M.c5, M.a2, M.b1, M.O1);)
-    SC_BOTH(SC_V_INC(M.nO1, zero32, M.c4, dump);)
+    SC_BOTH(SC_V_INCD(M.nO1, zero32, M.c4);)
     SC_BOTH(SC_V_MAD(M.O1, M.c6, M.a3, M.b0, M.O1);)
-    SC_BOTH(SC_V_MAD(M.E2, dump, M.a1, M.b3, (uint64_t)M.nE1);)
-    SC_BOTH(SC_V_INC(M.nO1, M.nO1, M.c5, dump);)
+    SC_BOTH(SC_V_MADD(M.E2, M.a1, M.b3, (uint64_t)M.nE1);)
+    SC_BOTH(SC_V_INCD(M.nO1, M.nO1, M.c5);)
     SC_BOTH(SC_V_MAD(M.E2, M.c7, M.a2, M.b2, M.E2);)
-    SC_BOTH(SC_V_INC(M.nO1, M.nO1, M.c6, dump);)
+    SC_BOTH(SC_V_INCD(M.nO1, M.nO1, M.c6);)
     SC_BOTH(SC_V_MAD(M.E2, M.c8, M.a3, M.b1, M.E2);)
-    SC_BOTH(SC_V_INC(M.nE2, zero32, M.c7, dump);)
-    SC_BOTH(SC_V_MAD(M.O2, dump, M.a2, M.b3, (uint64_t)M.nO1);)
+    SC_BOTH(SC_V_INCD(M.nE2, zero32, M.c7);)
+    SC_BOTH(SC_V_MADD(M.O2, M.a2, M.b3, (uint64_t)M.nO1);)
     SC_BOTH(SC_V_MAD(M.O2, M.c9, M.a3, M.b2, M.O2);)
-    SC_BOTH(SC_V_INC(M.nE2, M.nE2, M.c8, dump);)
-    SC_BOTH(SC_V_MAD(M.E3, dump, M.a3, M.b3, (uint64_t)M.nE2);)
-    SC_BOTH(SC_V_INC(M.nO2, zero32, M.c9, dump);)
+    SC_BOTH(SC_V_INCD(M.nE2, M.nE2, M.c8);)
+    SC_BOTH(SC_V_MADD(M.E3, M.a3, M.b3, (uint64_t)M.nE2);)
+    SC_BOTH(SC_V_INCD(M.nO2, zero32, M.c9);)
     // ---- merge T = E + (O << 32), interleaved with the reduction chain s0..s3 (t0 = lo32(E0))
     SC_BOTH(SC_V_ADDCO(M.t1, M.ct, hi32(M.E0), lo32(M.O0));)
-    SC_BOTH(SC_V_MAD(M.s0, dump, lo32(M.E0), PHc, zero64);)
+    SC_BOTH(SC_V_MADD(M.s0, lo32(M.E0), PHc, zero64);)
     SC_BOTH(SC_V_ADDC(M.t2, M.ct, lo32(M.E1), hi32(M.O0), M.ct);)
-    SC_BOTH(SC_V_MAD(M.s1, dump, M.t1, PHc, (uint64_t)hi32(M.s0));)
+    SC_BOTH(SC_V_MADD(M.s1, M.t1, PHc, (uint64_t)hi32(M.s0));)
     SC_BOTH(SC_V_ADDC(M.t3, M.ct, hi32(M.E1), lo32(M.O1), M.ct);)
-    SC_BOTH(SC_V_MAD(M.s2, dump, M.t2, PHc, (uint64_t)hi32(M.s1));)
+    SC_BOTH(SC_V_MADD(M.s2, M.t2, PHc, (uint64_t)hi32(M.s1));)
     SC_BOTH(SC_V_SUBCO(M.m3, M.bw, M.t3, lo32(M.s0));)
     SC_BOTH(SC_V_ADDC(M.t4, M.ct, lo32(M.E2), hi32(M.O1), M.ct);)
-    SC_BOTH(SC_V_MAD(M.s3, dump, M.m3, PHc, (uint64_t)hi32(M.s2));)
+    SC_BOTH(SC_V_MADD(M.s3, M.m3, PHc, (uint64_t)hi32(M.s2));)
     SC_BOTH(SC_V_ADDC(M.t5, M.ct, hi32(M.E2), lo32(M.O2), M.ct);)
     SC_BOTH(SC_V_SUBB(M.r0, M.bw, M.t4, lo32(M.s1), M.bw);)
     SC_BOTH(SC_V_ADDC(M.t6, M.ct, lo32(M.E3), hi32(M.O2), M.ct);)
@@ -252,11 +271,10 @@ __device__ __forceinline__ void mont_mul2_asm(Fe xa, Fe wa, Fe xb, Fe wb, Fe& ra
     SC_V_NOP0();
     SC_BOTH(SC_V_ADDC(M.o2, M.cx, M.r2, zero32, M.cx);)
     SC_V_NOP0();
-    SC_BOTH(SC_V_ADDC(M.o3, dump, M.r3, M.ph, M.cx);)
+    SC_BOTH(SC_V_ADDCD(M.o3, M.r3, M.ph, M.cx);)
 #undef SC_BOTH
     ra = Fe{((uint64_t)A.o1 << 32) | A.o0, ((uint64_t)A.o3 << 32) | A.o2};
     rb = Fe{((uint64_t)B.o1 << 32) | B.o0, ((uint64_t)B.o3 << 32) | B.o2};
-    (void)dump;
 }
 
 // The sums and differences of TWO butterflies (u0 +- v0, u1 +- v1): four independent carry chains issued round-robin, so every
@@ -275,8 +293,7 @@ __device__ __forceinline__ void fe_addsub2_asm(Fe ua, Fe va, Fe ub, Fe vb, Fe& s
     B.u0 = lo32(ub.lo); B.u1 = hi32(ub.lo); B.u2 = lo32(ub.hi); B.u3 = hi32(ub.hi);
     B.v0 = lo32(vb.lo); B.v1 = hi32(vb.lo); B.v2 = lo32(vb.hi); B.v3 = hi32(vb.hi);
     const uint32_t zero32 = 0, one32 = 1, PHc = PH3;
-    smask_t dump;
-#define SC_BOTH(STEP) { AddSubState& M = A; STEP } { AddSubState& M = B; STEP }
+#define SC_BOTH(STEP) { AddSubState& M = A; constexpr int W = 0; STEP } { AddSubState& M = B; constexpr int W = 1; STEP }
     // sum chain (r, carry ca) and difference chain (d, borrow bd), limb by limb
     SC_BOTH(SC_V_ADDCO(M.r0, M.ca, M.u0, M.v0); SC_V_SUBCO(M.d0, M.bd, M.u0, M.v0);)
     SC_BOTH(SC_V_ADDC(M.r1, M.ca, M.u1, M.v1, M.ca); SC_V_SUBB(M.d1, M.bd, M.u1, M.v1, M.bd);)
@@ -291,7 +308,7 @@ __device__ __forceinline__ void fe_addsub2_asm(Fe ua, Fe va, Fe ub, Fe vb, Fe& s
     // along so that it, too, stays three instructions behind its carry)
     A.sel = A.ca | ~A.cb;
     B.sel = B.ca | ~B.cb;
-    SC_BOTH(SC_V_CND(M.s0, M.r0, M.t0, M.sel); SC_V_ADDC(M.e3, dump, M.d3, M.ph, M.ce);)
+    SC_BOTH(SC_V_CND(M.s0, M.r0, M.t0, M.sel); SC_V_ADDCD(M.e3, M.d3, M.ph, M.ce);)
     SC_BOTH(SC_V_CND(M.s1, M.r1, M.t1, M.sel);)
     SC_BOTH(SC_V_CND(M.s2, M.r2, M.t2, M.sel);)
     SC_BOTH(SC_V_CND(M.s3, M.r3, M.t3, M.sel);)
@@ -300,7 +317,6 @@ __device__ __forceinline__ void fe_addsub2_asm(Fe ua, Fe va, Fe ub, Fe vb, Fe& s
     da = Fe{((uint64_t)A.e1 << 32) | A.e0, ((uint64_t)A.e3 << 32) | A.e2};
     sb = Fe{((uint64_t)B.s1 << 32) | B.s0, ((uint64_t)B.s3 << 32) | B.s2};
     db = Fe{((uint64_t)B.e1 << 32) | B.e0, ((uint64_t)B.e3 << 32) | B.e2};
-    (void)dump;
 }
 
 __device__ __forceinline__ Fe fe_add_asm(Fe a, Fe b) {
