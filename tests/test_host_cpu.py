@@ -137,3 +137,28 @@ def test_other_fields_are_refused_not_misreduced():
         ntt(root, vals)
     with pytest.raises(AssertionError, match="p = 1 \\+ 407"):
         fast_coset_evaluate(Polynomial(vals[:2]), FieldElement(3, f97), root, 4)
+
+
+def test_byte_sampling_matches_the_shift_xor_loop():
+    """Field.sample (algebra.py:123-127) and Fri.sample_index (fri.py:30-34) fold bytes with acc = (acc << 8) ^ b; the host
+    modules take the big-endian integer instead -- same value for bytes, and the loop itself for anything else."""
+    import random
+    from fri import Fri
+    rng = random.Random(5)
+
+    def loop(byte_array, mod):
+        acc = 0
+        for b in byte_array:
+            acc = (acc << 8) ^ int(b)
+        return acc % mod
+    field = Field.main()
+    for length in (0, 1, 16, 17, 32, 64, 100):
+        for _ in range(20):
+            data = bytes(rng.randrange(256) for _ in range(length))
+            assert field.sample(data).value == loop(data, field.p)
+            assert field.sample(bytearray(data)).value == loop(data, field.p)
+            assert field.sample(list(data)).value == loop(data, field.p)
+            for size in (1, 2, 255, 256, 4096, (1 << 22) - 1):
+                assert Fri.sample_index(data, size) == loop(data, size)
+    assert Fri.sample_index([1, 2, 300], 1000) == loop([1, 2, 300], 1000)      # not byte values: the reference's loop verbatim
+    assert field.sample([7, 1000]).value == loop([7, 1000], field.p)
