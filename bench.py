@@ -382,7 +382,7 @@ def main():
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "valu_insts_per_launch": measured_valu(log2n) if not sharded else None,
                          "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 and valu_insts (SQ_INSTS_VALU, wave-level) per launch from profiles/ (PMC passes); "
-                                 "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor (13 of 18.8 us at 2^20), see DESIGN.md 3.1"},
+                                 "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor (13 of 17.5 us at 2^20), see DESIGN.md 3.1"},
         }
         if sharded:
             out["config"]["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
