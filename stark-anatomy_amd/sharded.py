@@ -638,6 +638,13 @@ class ShardedFri:
         last_layer["cache"] = dict(enumerate(last_list))
         proof_stream.push(last_list)
 
+        return self._query_all(layers, last_list, proof_stream)
+
+    def _query_all(self, layers, last_list, proof_stream):
+        """the query phase of fri.py:124-128 over the committed layers: indices from the transcript, ONE collective for every
+        opening of every round, pushes in the reference's order"""
+        fr = self.fri
+        N = fr.domain_length
         s = fr.num_colinearity_tests
         top_level_indices = fr.sample_indices(proof_stream.prover_fiat_shamir(), N // 2, len(last_list), s)
         nq = len(layers) - 1
@@ -665,6 +672,115 @@ class ShardedFri:
                 proof_stream.push(paths[s + t])
                 proof_stream.push(next_paths[c_at + t])
         return top_level_indices
+
+
+class ContiguousFri(ShardedFri):
+    """`Fri.prove` (reference code/fri.py:115-130) on a codeword in the NATURAL contiguous layout (SURVEY.md 8(e), row "FRI
+    fold"): rank g owns x[g*N/G : (g+1)*N/G] -- a single-GPU LDE cut into G pieces, or a host list scattered in order.
+      * split-and-fold pairs i with i + N/2, i.e. rank g with rank g + G/2: ONE neighbour exchange per fold.  The upper rank
+        ships its slab to its partner, which folds both; the folded codeword (half as long) lives contiguously on the lower
+        half of the ranks, and so on until one rank holds what is left;
+      * Merkle leaves are contiguous: a commit is the active ranks' local subtrees plus one all-gather of their sub-roots
+        (64 bytes per rank); the levels above are rebuilt, identically, on every rank;
+      * every rank -- also one that has run out of data -- follows the same transcript, so alphas and query indices agree without
+        a broadcast; an opening is answered by the rank that owns the leaf, all of them merged by one collective.
+    ShardedFri (column slabs: no element exchange at all) is the better layout for a codeword that comes out of ShardedNtt; this
+    class serves codewords that arrive in natural order without re-slabbing them (rows_to_column_slab is the other option)."""
+
+    def __init__(self, fri, rank, world, device, engine=None, group=None):
+        self.fri, self.rank, self.world, self.device, self.group = fri, rank, world, device, group
+        assert world & (world - 1) == 0 and fri.domain_length % world == 0 and fri.domain_length // world >= 1
+        self.engine = engine if engine is not None else HipFriEngine(device)
+        self.elements_shipped = 0
+
+    def _ship(self, t, src, dst, count):
+        """the neighbour exchange: `count` elements from rank src to rank dst (returns the received tensor on dst)"""
+        staged = t is not None and t.is_cuda and dist.get_backend(self.group) == "gloo"     # functional tests: host-staged
+        if self.rank == src:
+            dist.send(t.cpu() if staged else t.contiguous(), dst, group=self.group)
+            self.elements_shipped += count
+            return None
+        buf = torch.empty((count, 2), dtype=torch.int64, device="cpu" if (self.device.type == "cuda" and dist.get_backend(self.group) == "gloo") else self.device)
+        dist.recv(buf, src, group=self.group)
+        return buf.to(self.device)
+
+    def _commit_contiguous(self, cur, length, active):
+        eng = self.engine
+        seg = length // active
+        mine = self.rank < active
+        local = eng.tree(cur) if mine else None
+        sub = eng.level(local, seg.bit_length() - 1) if mine else torch.zeros((1, 8), dtype=torch.int64, device=self.device)
+        top = eng.tree_from_digests(self._all_gather(sub)[:active].reshape(active, 8))
+        return {"kind": "contiguous", "vec": cur, "local": local, "top": top, "root": top.root, "seg": seg, "active": active, "length": length, "cache": {}}
+
+    def commit(self, slab, length, active=None):
+        """Merkle.commit (code/merkle.py:13-14) of a codeword of `length` held contiguously by the first `active` ranks"""
+        return self._commit_contiguous(slab, length, self.world if active is None else active)
+
+    def _open_many_raw(self, requests):
+        eng, g = self.engine, self.rank
+        mine_all = []
+        for layer, indices in requests:
+            seg = layer["seg"]
+            mine = [(pos, i) for pos, i in enumerate(indices) if i // seg == g]
+            local_idx = [i % seg for _, i in mine]
+            vals = eng.read(layer["vec"], local_idx) if mine else []
+            bottoms = (layer["local"].open(local_idx) if seg > 1 else [[] for _ in mine]) if mine else []
+            mine_all.append([(pos, v, list(b)) for (pos, _), v, b in zip(mine, vals, bottoms)])
+        shared = self._all_gather_object(mine_all)
+        out = []
+        for q, (layer, indices) in enumerate(requests):
+            values, bottom = [None] * len(indices), [None] * len(indices)
+            for part in shared:
+                for pos, v, b in part[q]:
+                    values[pos], bottom[pos] = v, b
+            tops = layer["top"].open([i // layer["seg"] for i in indices]) if layer["active"] > 1 else [[] for _ in indices]
+            out.append((values, [list(b) + list(t) for b, t in zip(bottom, tops)]))
+        return out
+
+    def prove(self, slab, proof_stream):
+        from algebra import FieldElement
+        fr, eng, field, G = self.fri, self.engine, self.fri.field, self.world
+        N = fr.domain_length
+        assert tuple(slab.shape) == (N // G, 2), "slab must be this rank's N/G consecutive elements"
+        omega, offset, rounds = fr.omega, fr.offset, fr.num_rounds()
+        layers, cur, active = [], slab, G
+        for r in range(rounds):
+            Nr = N >> r
+            assert(omega ^ (Nr - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
+            layer = self._commit_contiguous(cur, Nr, active)
+            layers.append(layer)
+            proof_stream.push(layer["root"])
+            if r == rounds - 1:
+                break
+            alpha = field.sample(proof_stream.prover_fiat_shamir())
+            seg = Nr // active
+            if active == 1:
+                if self.rank == 0:
+                    cur = eng.fold_full(cur, Nr, alpha.value, offset.value, omega.value)
+            else:
+                half = active // 2
+                if self.rank < half:
+                    upper = self._ship(None, self.rank + half, self.rank, seg)
+                    pair = torch.cat([cur, upper], dim=0)
+                    # the rank's outputs are i in [rank*seg, (rank+1)*seg): a fold of length 2*seg whose domain starts at omega^(rank*seg)
+                    shifted = (offset * (omega ^ (self.rank * seg))).value
+                    cur = eng.fold_full(pair, 2 * seg, alpha.value, shifted, omega.value)
+                elif self.rank < active:
+                    self._ship(cur, self.rank, self.rank - half, seg)
+                    cur = None
+                active = half
+            omega = omega ^ 2
+            offset = offset ^ 2
+        # last codeword in the clear (fri.py:91): natural order, plain list; its objects are reused by the last query round
+        last_layer = layers[-1]
+        seg = last_layer["seg"]
+        part = cur if self.rank < active else torch.zeros((seg, 2), dtype=torch.int64, device=self.device)
+        last_vec = self._all_gather(part)[:active].reshape(last_layer["length"], 2)
+        last_list = [FieldElement(v, field) for v in eng.read(last_vec, range(last_layer["length"]))]
+        last_layer["cache"] = dict(enumerate(last_list))
+        proof_stream.push(last_list)
+        return self._query_all(layers, last_list, proof_stream)
 
 
 # =====================================================================================================================

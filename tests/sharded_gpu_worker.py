@@ -127,6 +127,18 @@ def fri_check(rank, world, dev):
             if not good:
                 print("rank", rank, "FRI MISMATCH logN", logN, "R", R, flush=True)
             ok &= good
+        # the NATURAL contiguous layout (SURVEY 8(e) "FRI fold": one neighbour exchange per fold), HIP engine on every rank
+        from sharded import ContiguousFri
+        seg = N // world
+        chunk = torch.from_numpy(cw[rank * seg:(rank + 1) * seg].copy()).to(dev)
+        fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+        ps = ProofStream()
+        top = ContiguousFri(fr, rank, world, dev).prove(chunk, ps)
+        ser = ps.serialize()
+        good = (top == rec["top_level_indices"] and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
+        if not good:
+            print("rank", rank, "CONTIGUOUS FRI MISMATCH logN", logN, flush=True)
+        ok &= good
     # independent columns, one register per rank (HIP LDE + Merkle commit), roots gathered in column order
     from sharded import ColumnReplicas
     order = 1 << 12

@@ -265,6 +265,26 @@ def fri_main():
             if not good:
                 print("rank", rank, "MISMATCH logN", logN, "R", R, top == rec["top_level_indices"], len(ser), rec["serialized_len"], flush=True)
             ok &= good
+        # SURVEY 8(e), row "FRI fold": the same proof from the NATURAL contiguous layout (one neighbour exchange per fold)
+        from sharded import ContiguousFri
+        if N // world >= 1:
+            seg = N // world
+            chunk = torch.from_numpy(cw[rank * seg:(rank + 1) * seg].copy())
+            fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+            ps = ProofStream()
+            cf = ContiguousFri(fr, rank, world, torch.device("cpu"), engine=OracleFriEngine())
+            top = cf.prove(chunk, ps)
+            ser = ps.serialize()
+            good = (top == rec["top_level_indices"] and [o.hex() for o in ps.objects[:rec["num_rounds"]]] == rec["roots"]
+                    and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
+            # what the upper halves shipped: N/2 + N/4 + ... while more than one rank holds data
+            shipped = sum((N >> r) // 2 for r in range(min(rec["num_rounds"] - 1, world.bit_length() - 1)))
+            total = torch.tensor([cf.elements_shipped], dtype=torch.int64)
+            dist.all_reduce(total)
+            good = good and int(total.item()) == shipped
+            if not good:
+                print("rank", rank, "CONTIGUOUS MISMATCH logN", logN, top == rec["top_level_indices"], len(ser), rec["serialized_len"], int(total.item()), shipped, flush=True)
+            ok &= good
     # independent columns: one register per rank, roots gathered in column order
     from sharded import ColumnReplicas
     order = 256
