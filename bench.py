@@ -235,16 +235,18 @@ def main():
                 log2n = args.log2n or (20 + (world.bit_length() - 1) + 1)     # 2^21 per GPU: 8 GPUs -> 2^24
                 n = 1 << log2n
                 corner_turn = None
+                candidates = {}
                 for chunks in (4, 1):
-                    # the overlapped corner turn (4 asynchronous row blocks) first; if it cannot be set up, or its result is not
-                    # the blocking form's, the single blocking all_to_all_single -- and the JSON line says which one ran
+                    # the overlapped corner turn (4 asynchronous row blocks) and the single blocking all_to_all_single: each is
+                    # checked (round trip; the overlapped forward transform against the blocking one, element for element), then
+                    # timed for a few steps; the faster one that is correct runs the measurement and the JSON line says which
                     try:
                         eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True, overlap_chunks=chunks)
                         x = eng.synthetic_input(seed=1)
                         y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
                         z = torch.empty_like(x)
 
-                        def step():
+                        def step(eng=eng, x=x, y=y, z=z):
                             eng.forward(x, y)
                             eng.inverse(y, z)
 
@@ -252,7 +254,7 @@ def main():
                         dist.barrier()
                         torch.cuda.synchronize()
                         same = torch.equal(z, x)
-                        if chunks > 1:            # the overlapped forward transform against the blocking one, element for element
+                        if chunks > 1:
                             ref_eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True, overlap_chunks=1)
                             y_ref = torch.empty_like(y)
                             ref_eng.forward(x, y_ref)
@@ -263,12 +265,27 @@ def main():
                         dist.all_reduce(good, op=dist.ReduceOp.MIN)
                         if int(good.item()) != 1:
                             raise RuntimeError("round trip mismatch with %d corner-turn blocks" % chunks)
-                        corner_turn = "%d asynchronous row blocks overlapped with the row stage" % chunks if chunks > 1 else "one blocking all_to_all_single"
-                        break
+                        for _ in range(2):
+                            step()
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(4):
+                            step()
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        candidates[chunks] = (float(t.item()) / 4, step, eng, x, y, z)
                     except Exception as e1:       # noqa: BLE001
-                        if chunks == 1:
-                            raise
-                        sys.stderr.write("bench.py: overlapped corner turn unavailable (%r); using the blocking form\n" % (e1,))
+                        sys.stderr.write("bench.py: corner turn with %d block(s) unavailable (%r)\n" % (chunks, e1))
+                if not candidates:
+                    raise RuntimeError("no working corner turn")
+                best = min(candidates, key=lambda c: candidates[c][0])         # the same choice on every rank (times are all-reduced)
+                _, step, eng, x, y, z = candidates[best]
+                corner_turn = ("%d asynchronous row blocks overlapped with the row stage" % best if best > 1 else "one blocking all_to_all_single") + \
+                    "; probe ms/step: " + ", ".join("%d block(s) %.3f" % (c, candidates[c][0] * 1e3) for c in sorted(candidates))
+                del candidates
                 launches_per_step = 2      # N > 1: roofline is reported per whole transform (local passes + all-to-all)
                 workload = "ntt_fwd_inv_2^%d_fourstep_%dgpu" % (log2n, world)
                 total_n = n
