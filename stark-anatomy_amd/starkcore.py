@@ -89,6 +89,23 @@ SIGNATURES = {
 _lib = None
 
 
+def _one_hip_runtime():
+    """torch wheels carry their own copy of the HIP runtime (same soname as /opt/rocm's).  Two copies in one process do not share
+    the device: if libstarkcore.so pulled in the system copy first, a later `import torch` would find "No HIP GPUs".  When torch is
+    installed it is therefore imported (not initialised) before the library is loaded, so that both bind to one runtime --
+    sharded.py and bench.py use torch for memory, streams and collectives in the same process.  STARKCORE_NO_TORCH=1 skips this
+    (a process that never touches torch)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("STARKCORE_NO_TORCH") == "1":
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:      # noqa: BLE001  a broken torch install must not take the library down with it
+        pass
+
+
 def lib():
     """The loaded library (loads on first use; raises if the HIP extension was not built)."""
     global _lib
@@ -96,6 +113,7 @@ def lib():
         if not os.path.exists(_LIB_PATH):
             raise RuntimeError("libstarkcore.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "or `make -C stark-anatomy_amd/csrc` (the HIP extension is mandatory, there is no CPU fallback)")
+        _one_hip_runtime()
         l = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)

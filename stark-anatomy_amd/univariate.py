@@ -209,6 +209,13 @@ class Polynomial:
 
 
 def test_colinearity(points):
+    if len(points) == 3:
+        (x0, y0), (x1, y1), (x2, y2) = points
+        if x0 != x1 and x0 != x2 and x1 != x2:
+            # univariate.py:159-163 interpolates and asks for degree == 1: three points with distinct abscissas lie on a line
+            # of non-zero slope (a constant interpolant has degree 0, a parabola 2).  The verifier runs this 3 s (rounds - 1)
+            # times (fri.py:207); the cross product is ~40x cheaper than the Lagrange interpolation.
+            return (y1 - y0) * (x2 - x0) == (y2 - y0) * (x1 - x0) and y1 != y0
     domain = [p[0] for p in points]
     values = [p[1] for p in points]
     polynomial = Polynomial.interpolate_domain(domain, values)

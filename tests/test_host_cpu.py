@@ -162,3 +162,32 @@ def test_byte_sampling_matches_the_shift_xor_loop():
                 assert Fri.sample_index(data, size) == loop(data, size)
     assert Fri.sample_index([1, 2, 300], 1000) == loop([1, 2, 300], 1000)      # not byte values: the reference's loop verbatim
     assert field.sample([7, 1000]).value == loop([7, 1000], field.p)
+
+
+def test_colinearity_shortcut_matches_interpolation():
+    """test_colinearity (univariate.py:159-163) by the cross product for three points with distinct abscissas must answer what the
+    reference's interpolate-and-take-the-degree answers: lines of non-zero slope only."""
+    import random
+    from univariate import test_colinearity as colinear
+    rng = random.Random(9)
+    fe = lambda v: FieldElement(v % field.p, field)
+
+    def by_interpolation(points):
+        return Polynomial.interpolate_domain([p[0] for p in points], [p[1] for p in points]).degree() == 1
+    cases = []
+    for _ in range(40):
+        xs = [fe(rng.randrange(field.p)) for _ in range(3)]
+        a, b = fe(rng.randrange(field.p)), fe(rng.randrange(field.p))
+        cases.append([(x, a * x + b) for x in xs])                                  # a line
+        cases.append([(x, b) for x in xs])                                          # constant: degree 0
+        cases.append([(x, fe(0)) for x in xs])                                      # zero: degree -1
+        cases.append([(x, fe(rng.randrange(field.p))) for x in xs])                 # generic: degree 2
+        cases.append([(xs[0], a * xs[0] + b), (xs[1], a * xs[1] + b), (xs[2], a * xs[2] + b + fe(1))])
+    cases.append([(fe(1), fe(2)), (fe(2), fe(4)), (fe(3), fe(6))])
+    cases.append([(fe(0), fe(0)), (fe(1), fe(0)), (fe(2), fe(1))])
+    for pts in cases:
+        assert colinear(pts) == by_interpolation(pts)
+    two = [(fe(1), fe(5)), (fe(2), fe(7))]                                          # other arities take the reference's route
+    assert colinear(two) == by_interpolation(two)
+    four = [(fe(i), fe(3 * i + 1)) for i in range(4)]
+    assert colinear(four) == by_interpolation(four) is True
