@@ -267,6 +267,7 @@ class FastStark:
         max_degree = self.max_degree(transition_constraints)
         tq_bounds = self.transition_quotient_degree_bounds(transition_constraints)
         bq_bounds = self.boundary_quotient_degree_bounds(randomized_trace_length, boundary)
+        constraint_at = [tc.evaluator() for tc in transition_constraints]      # term lists extracted once, not per queried point
         for position, current_index in enumerate(indices):
             next_index = (current_index + self.expansion_factor) % N
             x_current = self.generator * (self.omega ^ current_index)
@@ -275,7 +276,7 @@ class FastStark:
             current_trace = [leafs[s][current_index] * zerofiers[s].evaluate(x_current) + interpolants[s].evaluate(x_current) for s in range(self.num_registers)]
             next_trace = [leafs[s][next_index] * zerofiers[s].evaluate(x_next) + interpolants[s].evaluate(x_next) for s in range(self.num_registers)]
             point = [x_current] + current_trace + next_trace
-            constraint_values = [tc.evaluate(point) for tc in transition_constraints]
+            constraint_values = [at(point) for at in constraint_at]
 
             terms = [randomizer[current_index]]
             for s, tcv in enumerate(constraint_values):

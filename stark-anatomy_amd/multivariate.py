@@ -75,20 +75,27 @@ class MPolynomial:
     def evaluate(self, point):
         # multivariate.py:75-81 on residues: each power point[i]^e is computed once per call instead of once per term,
         # and factors with exponent 0 (the field's one) are not multiplied out -- same value
-        p = point[0].field.p
-        vals = [q.value for q in point]
-        powers = {}
-        acc = 0
-        for k, v in self.dictionary.items():
-            term = v.value
-            for i, e in enumerate(k):
-                if e:
-                    pw = powers.get((i, e))
-                    if pw is None:
-                        pw = powers[(i, e)] = pow(vals[i], e, p)
-                    term = term * pw % p
-            acc = (acc + term) % p
-        return FieldElement(acc, point[0].field)
+        return self.evaluator()(point)
+
+    def evaluator(self):
+        """point -> self.evaluate(point) for the polynomial AS IT IS NOW: the term list and the powers each call needs are
+        extracted once.  The verifier evaluates every constraint at every queried point (fast_stark.py:201-205)."""
+        terms = [(v.value, tuple((i, e) for i, e in enumerate(k) if e)) for k, v in self.dictionary.items()]
+        needed = sorted({ie for _, f in terms for ie in f})
+
+        def run(point):
+            field = point[0].field
+            p = field.p
+            vals = [q.value for q in point]
+            powers = {(i, e): pow(vals[i], e, p) for i, e in needed}
+            acc = 0
+            for coefficient, factors in terms:
+                term = coefficient
+                for ie in factors:
+                    term = term * powers[ie] % p
+                acc += term
+            return FieldElement(acc % p, field)
+        return run
 
     # degree bound of the result from which evaluate_symbolic goes through the value domain on the GPU
     VALUE_DOMAIN_MIN_DEGREE = 48

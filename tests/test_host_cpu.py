@@ -191,3 +191,28 @@ def test_colinearity_shortcut_matches_interpolation():
     assert colinear(two) == by_interpolation(two)
     four = [(fe(i), fe(3 * i + 1)) for i in range(4)]
     assert colinear(four) == by_interpolation(four) is True
+
+
+def test_mpolynomial_evaluate_against_term_by_term():
+    """MPolynomial.evaluate (multivariate.py:75-81) with its per-polynomial term list: same value as the sum of products
+    written out, also after the dictionary has changed."""
+    import random
+    from multivariate import MPolynomial
+    rng = random.Random(13)
+    fe = lambda v: FieldElement(v % field.p, field)
+    for _ in range(20):
+        nvars = rng.randrange(1, 5)
+        d = {}
+        for _ in range(rng.randrange(1, 12)):
+            d[tuple(rng.randrange(0, 4) for _ in range(nvars))] = fe(rng.randrange(field.p))
+        mp = MPolynomial(d)
+        for _ in range(3):
+            point = [fe(rng.randrange(field.p)) for _ in range(nvars)]
+            want = 0
+            for k, v in mp.dictionary.items():
+                t = v.value
+                for i, e in enumerate(k):
+                    t = t * pow(point[i].value, e, field.p) % field.p
+                want = (want + t) % field.p
+            assert mp.evaluate(point).value == want
+            mp.dictionary[tuple(rng.randrange(0, 4) for _ in range(nvars))] = fe(rng.randrange(field.p))   # mutate, evaluate again
