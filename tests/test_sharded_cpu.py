@@ -27,10 +27,11 @@ def test_sharded_fourstep_gloo(world):
     assert r.stdout.count("ok") == world
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_sharded_fri_gloo_matches_reference_proofs(world):
-    """ShardedFri (slab-local folds, sharded Merkle commits, collective openings) must reproduce the reference's
-    Fri.prove byte for byte (golden SHA-256 of the serialized proof stream) for several slab shapes."""
+    """ShardedFri (slab-local folds, sharded Merkle commits, collective openings) and ContiguousFri (natural layout, one
+    neighbour exchange per fold) must reproduce the reference's Fri.prove byte for byte (golden SHA-256 of the serialized
+    proof stream) for several slab shapes; world 8 = the node the sharding is designed for."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", env["MASTER_PORT"], os.path.join(REPO, "tests", "sharded_worker.py"), "fri"]
