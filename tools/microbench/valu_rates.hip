@@ -76,6 +76,26 @@ __global__ void __launch_bounds__(256) rate_kernel(uint64_t* out, unsigned long 
 #define INS(i) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b[i]));
             BODY8(INS)
 #undef INS
+        } else if constexpr (KIND == 14) {  // v_xor_b32 SDWA: word selects on both sources, one destination word written, the other preserved
+#define INS(i) asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(a[i]) : "v"(b[i]));
+            BODY8(INS)
+#undef INS
+        } else if constexpr (KIND == 15) {  // v_xor_b32 SDWA writing a whole dword (dst_sel:DWORD), sources by word
+#define INS(i) asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "+v"(a[i]) : "v"(b[i]));
+            BODY8(INS)
+#undef INS
+        } else if constexpr (KIND == 16) {  // v_cndmask_b32 e32 (mask in vcc)
+#define INS(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]));
+            BODY8(INS)
+#undef INS
+        } else if constexpr (KIND == 17) {  // v_cndmask_b32 e64 (mask in an SGPR pair)
+#define INS(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b[i]));
+            BODY8(INS)
+#undef INS
+        } else if constexpr (KIND == 18) {  // v_xor_b32 e64 (VOP3 encoding of a VOP2 operation)
+#define INS(i) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            BODY8(INS)
+#undef INS
         } else if constexpr (KIND == 13) {  // v_pk_add_u16 (packed math rate)
 #define INS(i) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
             BODY8(INS)
@@ -128,6 +148,11 @@ int main() {
         run<10>("v_mov_b32_dpp quad_perm", 8, w, d_out, d_ticks);
         run<11>("v_lshlrev_b64", 8, w, d_out, d_ticks);
         run<13>("v_pk_add_u16", 8, w, d_out, d_ticks);
+        run<16>("v_cndmask_b32_e32 (vcc)", 8, w, d_out, d_ticks);
+        run<17>("v_cndmask_b32_e64 (sgpr mask)", 8, w, d_out, d_ticks);
+        run<18>("v_xor_b32_e64", 8, w, d_out, d_ticks);
+        run<14>("v_xor_b32_sdwa (word -> word, preserve)", 8, w, d_out, d_ticks);
+        run<15>("v_xor_b32_sdwa (words -> dword)", 8, w, d_out, d_ticks);
     }
     return 0;
 }
