@@ -10,6 +10,13 @@ N > 1: four-step NTT sharded over the ranks with one RCCL all-to-all (see stark-
        `python bench.py --gpus N` re-launches itself under torch.distributed.run; the N > 1 line also carries the whole
        BASELINE configs[4] call census on the sharded layout (extras.stark_census_sharded); `--workload stark_census` makes that
        the timed step.  With fewer GPUs than ranks the ranks share devices and exchange through gloo (labelled functional run).
+       Both forms of the corner turn (one blocking collective / 4 asynchronous row blocks) are checked and timed for a few steps
+       first; the faster one is measured (`config.corner_turn`).
+
+Timing: W untimed steps, then exactly K steps between barrier + torch.cuda.synchronize(), max over ranks -> `value`,
+`ms_per_step`, `roofline` (launch duration by HIP events on the launch stream).  The same window is then repeated after
+CLOCK_RAMP_MS of untimed steps and reported beside it as `clock_ramp.steady_state` (information: a short window straight after
+start-up runs at the board's idle clock).  `cpu_baseline` and `extras` (Fri.prove, LDE, census, Merkle, ...) follow, rank 0, N = 1.
 """
 import argparse
 import json
@@ -26,7 +33,7 @@ for p in (PKG, REPO):
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_ELEMENT_PER_TRANSFORM = 32   # read once + write once, 16-byte elements
-CLOCK_RAMP_MS = 150.0      # untimed load between the after-idle window and the reported one (see main)
+CLOCK_RAMP_MS = 150.0      # untimed load between the contract's window (`value`) and its repetition (`clock_ramp.steady_state`)
 
 
 def cpu_baseline(sample_log2n):
