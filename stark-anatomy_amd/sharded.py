@@ -422,7 +422,11 @@ class HipFriEngine:
 
     class _Tree:
         def __init__(self, tree, keep):
-            self.tree, self.keep, self.root = tree, keep, tree.root
+            self.tree, self.keep = tree, keep
+
+        @property
+        def root(self):
+            return self.tree.root          # waits for an asynchronous build
 
         def open(self, indices):
             return self.tree.open_batch(list(indices))
@@ -441,10 +445,15 @@ class HipFriEngine:
         if sptr is None:
             self.sc.synchronize()
 
-    def tree(self, elems):
-        """Merkle tree over a contiguous tensor of field elements [..., 2]."""
+    def tree(self, elems, need_root=True):
+        """Merkle tree over a contiguous tensor of field elements [..., 2].  need_root=False: the build is only enqueued on the
+        current stream (a local subtree of a sharded commit: its sub-root level is copied out on the same stream, its own root
+        is never looked at)."""
         elems = elems.contiguous()
-        return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr(elems.data_ptr(), elems.numel() // 2, self._stream()), elems)
+        sptr = self._stream()
+        if need_root or sptr is None:
+            return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr(elems.data_ptr(), elems.numel() // 2, sptr), elems)
+        return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr_async(elems.data_ptr(), elems.numel() // 2, sptr), elems)
 
     def level(self, tree, level):
         count = tree.tree.n >> level
@@ -481,6 +490,37 @@ class HipFriEngine:
         self.sc._check(self.lib.sc_coset_evaluate_dev(src.ptr, m, _fe(offset), _fe(generator), order, out.data_ptr(), sptr))
         torch.cuda.current_stream(self.device).synchronize()      # `src` is freed on return: its reader must be done
         self._done(sptr)
+        return out
+
+    def query_many(self, requests):
+        """[(tree, elems tensor or None, indices)] -> [(values as ints or None, authentication paths)]: every opening of every
+        layer in ONE library call and one launch (sc_merkle_query_multi_dev), instead of a device round trip per tree."""
+        ct, sc = self.ctypes, self.sc
+        live = [(q, t, e, [int(i) for i in idx]) for q, (t, e, idx) in enumerate(requests) if len(idx)]
+        out = [(None if e is None else [], [[] for _ in idx]) for t, e, idx in requests]
+        if not live:
+            return out
+        torch.cuda.current_stream(self.device).synchronize()        # the library call runs on the library's stream
+        n = len(live)
+        flat = [i for _, _, _, idx in live for i in idx]
+        total = len(flat)
+        depths = [t.tree.depth for _, t, _, _ in live]
+        path_bytes = sum(64 * d * len(idx) for d, (_, _, _, idx) in zip(depths, live))
+        elems_out = ct.create_string_buffer(16 * total)
+        paths_out = ct.create_string_buffer(max(path_bytes, 64))
+        # a tree over digests has no element vector: any readable pointer will do, the value is not used
+        ptrs = [(e if e is not None else t.keep).data_ptr() for _, t, e, _ in live]
+        sc._check(self.lib.sc_merkle_query_multi_dev(n, (ct.c_void_p * n)(*[t.tree._h for _, t, _, _ in live]), (ct.c_void_p * n)(*ptrs),
+                                                     (ct.c_uint64 * total)(*flat), (ct.c_uint64 * n)(*[len(idx) for _, _, _, idx in live]),
+                                                     elems_out, paths_out))
+        values = sc.unpack(elems_out.raw, total)
+        view = memoryview(paths_out)
+        vo = po = 0
+        for (q, t, e, idx), d in zip(live, depths):
+            k = len(idx)
+            out[q] = (values[vo:vo + k] if e is not None else None, sc._path_lists(view, po, d, k))
+            vo += k
+            po += 64 * k * d
         return out
 
     def read(self, elems, flat_indices):
@@ -536,7 +576,7 @@ class ShardedFri:
     # -- layers -----------------------------------------------------------------------------------
     def _commit_sharded(self, slab, C):
         eng, G, Rw = self.engine, self.world, self.Rw
-        local = eng.tree(slab)
+        local = eng.tree(slab, need_root=False)
         sub_level = Rw.bit_length() - 1
         sub = eng.level(local, sub_level)                                   # [C][8]: one sub-root per row
         top_leaves = self._all_gather(sub).permute(1, 0, 2).contiguous()    # natural order: node (row, rank)
@@ -553,33 +593,42 @@ class ShardedFri:
         return self._all_gather(slab).permute(1, 0, 2, 3).reshape(C * self.R, 2).contiguous()
 
     def _open_many_raw(self, requests):
-        """[(values, paths)] for a list of (layer, global indices).  ONE collective for all of them: every rank answers the
-        entries whose columns it owns (value + the bottom of the path, from its local subtree); the tops of the paths come
-        from the replicated top tree."""
+        """[(values, paths)] for a list of (layer, global indices).  ONE library call for everything this rank can answer
+        (values + the bottoms of the paths of the columns it owns, from its local subtrees; the tops of all paths from the
+        replicated top trees) and ONE collective to merge the owners' answers."""
         eng = self.engine
         R, Rw, G, g = self.R, self.Rw, self.world, self.rank
         sub_level = Rw.bit_length() - 1
-        mine_all = []
-        for layer, indices in requests:
-            if layer["kind"] != "sharded":
-                mine_all.append(None)
-                continue
-            mine = [(pos, i) for pos, i in enumerate(indices) if (i % R) // Rw == g]
-            local_idx = [(i // R) * Rw + (i % R) % Rw for _, i in mine]
-            vals = eng.read(layer["slab"], local_idx)
-            bottoms = [p[:sub_level] for p in layer["local"].open(local_idx)] if mine else []
-            mine_all.append([(pos, v, b) for (pos, _), v, b in zip(mine, vals, bottoms)])
-        shared = self._all_gather_object(mine_all) if any(m is not None for m in mine_all) else [mine_all]
-        out = []
+        asks, where = [], []
         for q, (layer, indices) in enumerate(requests):
             if layer["kind"] == "local":
-                out.append((eng.read(layer["vec"], indices), layer["tree"].open(indices) if layer["length"] > 1 else [[] for _ in indices]))
+                where.append(("local", len(asks)))
+                asks.append((layer["tree"], layer["vec"], list(indices)))
+                continue
+            mine = [(pos, i) for pos, i in enumerate(indices) if (i % R) // Rw == g]
+            where.append(("sharded", len(asks), mine))
+            asks.append((layer["local"], layer["slab"], [(i // R) * Rw + (i % R) % Rw for _, i in mine]))
+            asks.append((layer["top"], None, [(i // R) * G + (i % R) // Rw for i in indices] if layer["C"] * G > 1 else []))
+        got = eng.query_many(asks)
+        mine_all = []
+        for (layer, indices), w in zip(requests, where):
+            if w[0] == "local":
+                mine_all.append(None)
+                continue
+            vals, bottoms = got[w[1]]
+            mine_all.append([(pos, v, b[:sub_level]) for (pos, _), v, b in zip(w[2], vals, bottoms)])
+        shared = self._all_gather_object(mine_all) if any(m is not None for m in mine_all) else [mine_all]
+        out = []
+        for q, ((layer, indices), w) in enumerate(zip(requests, where)):
+            if w[0] == "local":
+                vals, paths = got[w[1]]
+                out.append((vals, paths if layer["length"] > 1 else [[] for _ in indices]))
                 continue
             values, bottom = [None] * len(indices), [None] * len(indices)
             for part in shared:
                 for pos, v, b in part[q]:
                     values[pos], bottom[pos] = v, b
-            tops = layer["top"].open([(i // R) * G + (i % R) // Rw for i in indices]) if layer["C"] * G > 1 else [[] for _ in indices]
+            tops = got[w[1] + 1][1] if layer["C"] * G > 1 else [[] for _ in indices]
             out.append((values, [list(b) + list(t) for b, t in zip(bottom, tops)]))
         return out
 
@@ -708,7 +757,7 @@ class ContiguousFri(ShardedFri):
         eng = self.engine
         seg = length // active
         mine = self.rank < active
-        local = eng.tree(cur) if mine else None
+        local = eng.tree(cur, need_root=False) if mine else None
         sub = eng.level(local, seg.bit_length() - 1) if mine else torch.zeros((1, 8), dtype=torch.int64, device=self.device)
         top = eng.tree_from_digests(self._all_gather(sub)[:active].reshape(active, 8))
         return {"kind": "contiguous", "vec": cur, "local": local, "top": top, "root": top.root, "seg": seg, "active": active, "length": length, "cache": {}}
@@ -719,14 +768,18 @@ class ContiguousFri(ShardedFri):
 
     def _open_many_raw(self, requests):
         eng, g = self.engine, self.rank
-        mine_all = []
+        asks, owned = [], []
         for layer, indices in requests:
             seg = layer["seg"]
             mine = [(pos, i) for pos, i in enumerate(indices) if i // seg == g]
-            local_idx = [i % seg for _, i in mine]
-            vals = eng.read(layer["vec"], local_idx) if mine else []
-            bottoms = (layer["local"].open(local_idx) if seg > 1 else [[] for _ in mine]) if mine else []
-            mine_all.append([(pos, v, list(b)) for (pos, _), v, b in zip(mine, vals, bottoms)])
+            owned.append(mine)
+            asks.append((layer["local"], layer["vec"], [i % seg for _, i in mine]) if mine else (None, None, []))
+            asks.append((layer["top"], None, [i // seg for i in indices] if layer["active"] > 1 else []))
+        got = eng.query_many(asks)
+        mine_all = []
+        for q, mine in enumerate(owned):
+            vals, bottoms = got[2 * q]
+            mine_all.append([(pos, v, list(b)) for (pos, _), v, b in zip(mine, vals or [], bottoms)])
         shared = self._all_gather_object(mine_all)
         out = []
         for q, (layer, indices) in enumerate(requests):
@@ -734,7 +787,7 @@ class ContiguousFri(ShardedFri):
             for part in shared:
                 for pos, v, b in part[q]:
                     values[pos], bottom[pos] = v, b
-            tops = layer["top"].open([i // layer["seg"] for i in indices]) if layer["active"] > 1 else [[] for _ in indices]
+            tops = got[2 * q + 1][1] if layer["active"] > 1 else [[] for _ in indices]
             out.append((values, [list(b) + list(t) for b, t in zip(bottom, tops)]))
         return out
 

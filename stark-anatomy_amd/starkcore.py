@@ -374,6 +374,14 @@ class MerkleTree:
         return cls(h, root.raw, n)
 
     @classmethod
+    def from_device_ptr_async(cls, ptr, n, stream=None):
+        """as from_device_ptr, but only enqueued on `stream`: `.root` waits (a caller that needs a level of the tree, not its
+        root, never waits at all -- copy_level on the same stream is ordered behind the build)"""
+        h = _vp()
+        _check(lib().sc_merkle_build_async_dev(ptr, n, ctypes.byref(h), stream))
+        return cls(h, None, n)
+
+    @classmethod
     def from_digests_ptr(cls, ptr, count, stream=None):
         """tree whose level 0 is `count` given 64-byte digests at a raw device pointer"""
         root = ctypes.create_string_buffer(64)

@@ -182,7 +182,7 @@ class OracleFriEngine:
         def open(self, indices):
             return [[self._node(l, (i >> l) ^ 1) for l in range(self.depth)] for i in indices]
 
-    def tree(self, elems):
+    def tree(self, elems, need_root=True):
         data = elems.contiguous().numpy().tobytes()
         n = len(data) // 16
         return OracleFriEngine._Tree(po.C.merkle_tree(data, n), n)
@@ -206,6 +206,10 @@ class OracleFriEngine:
     def lde(self, coeffs, offset, generator, order):
         raw = po.C.coset_evaluate(coeffs, len(coeffs) // 16, offset, generator, order)
         return torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(order, 2).copy())
+
+    def query_many(self, requests):
+        """[(tree, elems or None, indices)] -> [(values or None, paths)] (the HIP engine answers all of them in one library call)"""
+        return [((self.read(e, idx) if e is not None else None), (t.open(idx) if t is not None else [])) for t, e, idx in requests]
 
     def read(self, elems, flat_indices):
         a = elems.contiguous().numpy().view(np.uint64).reshape(-1, 2)
