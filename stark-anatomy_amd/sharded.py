@@ -566,12 +566,52 @@ class ShardedFri:
         dist.all_gather(parts, t, group=self.group)
         return torch.stack(parts, dim=0)
 
-    def _all_gather_object(self, obj):
-        if self.world == 1:
-            return [obj]
-        out = [None] * self.world
-        dist.all_gather_object(out, obj, group=self.group)
-        return out
+    def _gather_answers(self, layout, mine):
+        """The owners' answers to the openings, merged with ONE fixed-shape tensor collective (no pickling, no object store).
+        layout[r] = [(q, positions, ndigests)]: the runs rank r answers (one per request it owns something of), in the order it
+        packs them -- every rank derives all of it from the public indices; `mine` = this rank's runs [(values, bottoms)] in that
+        order.  Returns {q: {pos: (value, [digests])}}.  Packing and unpacking are per run (numpy / struct), not per opening."""
+        import numpy as np
+        import starkcore as sc
+        G, g = self.world, self.rank
+        answers = {}
+        if G == 1:
+            for (q, positions, nd), (vals, bottoms) in zip(layout[0], mine):
+                answers.setdefault(q, {}).update({pos: (v, list(b[:nd])) for pos, v, b in zip(positions, vals, bottoms)})
+            return answers
+        words = [sum(len(positions) * (2 + 8 * nd) for _, positions, nd in layout[r]) for r in range(G)]
+        width = max(max(words), 1)
+        row = np.zeros(width, dtype=np.int64)
+        at = 0
+        for (q, positions, nd), (vals, bottoms) in zip(layout[g], mine):
+            k = len(positions)
+            block = np.empty((k, 2 + 8 * nd), dtype=np.int64)
+            block[:, :2] = np.frombuffer(b"".join(int(v).to_bytes(16, "little") for v in vals), dtype=np.int64).reshape(k, 2)
+            if nd:
+                block[:, 2:] = np.frombuffer(b"".join(d for b in bottoms for d in b[:nd]), dtype=np.int64).reshape(k, 8 * nd)
+            row[at:at + block.size] = block.reshape(-1)
+            at += block.size
+        assert at == words[g]
+        on_device = self.device.type == "cuda" and dist.get_backend(self.group) != "gloo"
+        t = torch.from_numpy(row).to(self.device) if on_device else torch.from_numpy(row)
+        if on_device:
+            out = torch.empty((G, width), dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+        else:
+            parts = [torch.empty_like(t) for _ in range(G)]
+            dist.all_gather(parts, t, group=self.group)
+            out = torch.stack(parts, dim=0)
+        rows = out.cpu().numpy()
+        for r in range(G):
+            at = 0
+            for q, positions, nd in layout[r]:
+                k = len(positions)
+                block = rows[r, at:at + k * (2 + 8 * nd)].reshape(k, 2 + 8 * nd)
+                at += block.size
+                vals = sc.unpack(np.ascontiguousarray(block[:, :2]).tobytes(), k)
+                bottoms = sc._path_lists(memoryview(np.ascontiguousarray(block[:, 2:]).tobytes()), 0, nd, k)
+                answers.setdefault(q, {}).update({pos: (v, b) for pos, v, b in zip(positions, vals, bottoms)})
+        return answers
 
     # -- layers -----------------------------------------------------------------------------------
     def _commit_sharded(self, slab, C):
@@ -610,26 +650,28 @@ class ShardedFri:
             asks.append((layer["local"], layer["slab"], [(i // R) * Rw + (i % R) % Rw for _, i in mine]))
             asks.append((layer["top"], None, [(i // R) * G + (i % R) // Rw for i in indices] if layer["C"] * G > 1 else []))
         got = eng.query_many(asks)
-        mine_all = []
-        for (layer, indices), w in zip(requests, where):
+        layout, mine = [[] for _ in range(G)], []
+        for q, ((layer, indices), w) in enumerate(zip(requests, where)):
             if w[0] == "local":
-                mine_all.append(None)
                 continue
-            vals, bottoms = got[w[1]]
-            mine_all.append([(pos, v, b[:sub_level]) for (pos, _), v, b in zip(w[2], vals, bottoms)])
-        shared = self._all_gather_object(mine_all) if any(m is not None for m in mine_all) else [mine_all]
+            owners = [[] for _ in range(G)]
+            for pos, i in enumerate(indices):
+                owners[(i % R) // Rw].append(pos)
+            for r in range(G):
+                if owners[r]:
+                    layout[r].append((q, owners[r], sub_level))
+            if owners[g]:
+                mine.append(got[w[1]])
+        answers = self._gather_answers(layout, mine) if any(layout) else {}
         out = []
         for q, ((layer, indices), w) in enumerate(zip(requests, where)):
             if w[0] == "local":
                 vals, paths = got[w[1]]
                 out.append((vals, paths if layer["length"] > 1 else [[] for _ in indices]))
                 continue
-            values, bottom = [None] * len(indices), [None] * len(indices)
-            for part in shared:
-                for pos, v, b in part[q]:
-                    values[pos], bottom[pos] = v, b
             tops = got[w[1] + 1][1] if layer["C"] * G > 1 else [[] for _ in indices]
-            out.append((values, [list(b) + list(t) for b, t in zip(bottom, tops)]))
+            have = answers.get(q, {})
+            out.append(([have[pos][0] for pos in range(len(indices))], [have[pos][1] + list(t) for pos, t in zip(range(len(indices)), tops)]))
         return out
 
     def _open_many(self, requests):
@@ -776,19 +818,23 @@ class ContiguousFri(ShardedFri):
             asks.append((layer["local"], layer["vec"], [i % seg for _, i in mine]) if mine else (None, None, []))
             asks.append((layer["top"], None, [i // seg for i in indices] if layer["active"] > 1 else []))
         got = eng.query_many(asks)
-        mine_all = []
-        for q, mine in enumerate(owned):
-            vals, bottoms = got[2 * q]
-            mine_all.append([(pos, v, list(b)) for (pos, _), v, b in zip(mine, vals or [], bottoms)])
-        shared = self._all_gather_object(mine_all)
+        layout, mine = [[] for _ in range(self.world)], []
+        for q, (layer, indices) in enumerate(requests):
+            seg = layer["seg"]
+            owners = [[] for _ in range(self.world)]
+            for pos, i in enumerate(indices):
+                owners[i // seg].append(pos)
+            for r in range(self.world):
+                if owners[r]:
+                    layout[r].append((q, owners[r], seg.bit_length() - 1))
+            if owners[g]:
+                mine.append(got[2 * q])
+        answers = self._gather_answers(layout, mine)
         out = []
         for q, (layer, indices) in enumerate(requests):
-            values, bottom = [None] * len(indices), [None] * len(indices)
-            for part in shared:
-                for pos, v, b in part[q]:
-                    values[pos], bottom[pos] = v, b
             tops = got[2 * q + 1][1] if layer["active"] > 1 else [[] for _ in indices]
-            out.append((values, [list(b) + list(t) for b, t in zip(bottom, tops)]))
+            have = answers.get(q, {})
+            out.append(([have[pos][0] for pos in range(len(indices))], [have[pos][1] + list(t) for pos, t in zip(range(len(indices)), tops)]))
         return out
 
     def prove(self, slab, proof_stream):
