@@ -562,6 +562,10 @@ class ShardedFri:
             parts = [torch.empty_like(host) for _ in range(self.world)]
             dist.all_gather(parts, host, group=self.group)
             return torch.stack(parts, dim=0).to(t.device)
+        if t.is_cuda:                                                   # RCCL: one output tensor, no per-rank pieces to stack
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+            return out
         parts = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(parts, t, group=self.group)
         return torch.stack(parts, dim=0)
