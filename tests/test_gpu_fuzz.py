@@ -117,3 +117,50 @@ def test_fuzz_subproduct_tree(sc):
         assert synth.unpack_ints(out.raw)[:k] == [po.evaluate(f, x) for x in pts], (k, m)
         sc._check(lib.sc_interpolate(synth.pack_ints(pts), synth.pack_ints(vals), k, out))
         assert synth.unpack_ints(out.raw)[:k] == po.fast_interpolate(pts, vals, root, order), k
+
+
+def test_fuzz_commit_rounds_and_wide_queries(sc):
+    """Round 2 entries: one commit round in one call (sc_fri_fold_commit_dev: fold, then the tree of the folded codeword, root
+    fetched later) and all openings of several trees in one launch (sc_merkle_query_multi_dev), random shapes vs the oracle."""
+    from algebra import Field, FieldElement
+    field = Field.main()
+    rng = random.Random(303)
+    lib = sc.lib()
+    for _ in range(40):
+        logn = rng.randrange(1, 13)
+        N = 1 << logn
+        vals = rand_vals(rng, N)
+        data = synth.pack_ints(vals)
+        v = sc.DeviceVector.from_bytes(data)
+        alpha, offset = rng.randrange(P), rng.randrange(1, P)
+        omega = rand_root(rng, N)
+        cw = sc.DeviceCodeword(v, field)
+        folded = cw.fold_commit(FieldElement(alpha, field), FieldElement(offset, field), FieldElement(omega, field), sc.DeviceVector(N // 2))
+        want = C.fold(data, N, alpha, offset, omega)
+        assert folded.vec.to_bytes() == want
+        assert folded.tree().root == C.merkle_commit(want, N // 2)
+        assert cw.start_tree().root == C.merkle_commit(data, N)
+    for _ in range(6):
+        ntrees = rng.randrange(1, 45)
+        sizes = [1 << rng.randrange(0, 11) for _ in range(ntrees)]
+        datas = [synth.pack_ints(rand_vals(rng, m)) for m in sizes]
+        vecs = [sc.DeviceVector.from_bytes(d) for d in datas]
+        trees = [sc.MerkleTree.from_device_async(x) if rng.random() < 0.5 else sc.MerkleTree.from_device(x) for x in vecs]
+        reqs = [[rng.randrange(m) for _ in range(rng.randrange(0, 6))] for m in sizes]
+        flat = [i for r in reqs for i in r]
+        if not flat:
+            continue
+        el = ctypes.create_string_buffer(16 * len(flat))
+        pbytes = sum(64 * (m.bit_length() - 1) * len(r) for m, r in zip(sizes, reqs))
+        pa = ctypes.create_string_buffer(max(pbytes, 64))
+        sc._check(lib.sc_merkle_query_multi_dev(ntrees, (ctypes.c_void_p * ntrees)(*[t._h for t in trees]), (ctypes.c_void_p * ntrees)(*[x.ptr for x in vecs]),
+                                                (ctypes.c_uint64 * len(flat))(*flat), (ctypes.c_uint64 * ntrees)(*[len(r) for r in reqs]), el, pa))
+        eo = po_ = 0
+        for d_, m, r in zip(datas, sizes, reqs):
+            d = m.bit_length() - 1
+            for i in r:
+                assert el.raw[eo:eo + 16] == d_[16 * i:16 * i + 16]
+                if d:
+                    assert pa.raw[po_:po_ + 64 * d] == b"".join(C.merkle_open(d_, m, i))
+                eo += 16
+                po_ += 64 * d
