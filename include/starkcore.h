@@ -173,6 +173,10 @@ int sc_merkle_build_dev(const void* d_elems, uint64_t N, uint8_t root_out[64], s
  * sc_fri_fold_commit_dev = one round in one call: the fold of fri.py:85 into d_out (N/2 elements), then the asynchronous
  * build of the tree over d_out.  Fetch the root (or free the tree) before destroying a caller-owned stream the build ran on. */
 int sc_merkle_build_async_dev(const void* d_elems, uint64_t N, sc_merkle_t** tree, void* stream);
+/* the same, for a tree whose ROOT nobody is expected to read (a rank's local subtree of a sharded commit, whose sub-root level is
+ * copied out with sc_merkle_level_copy_dev on the same stream): takes none of the 256 pinned root slots and runs no publish
+ * kernel, so any number of such trees may be alive; sc_merkle_root still works (it then waits for the whole device). */
+int sc_merkle_build_noroot_dev(const void* d_elems, uint64_t N, sc_merkle_t** tree, void* stream);
 int sc_merkle_root(sc_merkle_t* tree, uint8_t root_out[64]);
 int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* d_out,
                            sc_merkle_t** tree, void* stream);

@@ -122,9 +122,10 @@ class Field:
 
     def sample(self, byte_array):
         # algebra.py:123-127 folds the bytes in with acc = (acc << 8) ^ b: for byte values that is the big-endian integer
-        try:
-            acc = int.from_bytes(bytes(byte_array), "big")
-        except (TypeError, ValueError):
+        # (only for byte strings: bytes(n) of an int n would be n zero bytes, where the reference's loop raises TypeError)
+        if isinstance(byte_array, (bytes, bytearray, memoryview)):
+            acc = int.from_bytes(byte_array, "big")
+        else:
             acc = 0
             for b in byte_array:
                 acc = (acc << 8) ^ int(b)

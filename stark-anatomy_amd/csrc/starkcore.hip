@@ -265,6 +265,7 @@ struct sc_merkle {
     uint64_t seq = 0;
     hipStream_t st = nullptr;
     bool have_root = false;
+    bool lazy = false;    // built "enqueue only" (BUILD_NOROOT): no slot, no publish kernel; the root is copied out if ever asked for
     uint8_t root[64] = {};
 };
 
@@ -784,9 +785,13 @@ int root_slot_get() {
 
 // async: nothing is waited for; the root travels to a pinned slot behind the build (tree required).  Without a free slot the
 // call degrades to the synchronous form.
-int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st, bool async = false) {
+// BUILD_NOROOT: only enqueued as well, but nobody is expected to ask for the root (a rank's local subtree of a sharded commit: its
+// sub-root level is copied out on the same stream): no pinned slot is taken and no publish kernel runs, so any number of such
+// trees can be alive at once without degrading the asynchronous builds of Fri.commit to the synchronous path.
+enum BuildMode { BUILD_SYNC = 0, BUILD_ASYNC = 1, BUILD_NOROOT = 2 };
+int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st, BuildMode mode = BUILD_SYNC) {
     if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
-    const int slot = (async && tree) ? root_slot_get() : -1;
+    const int slot = (mode == BUILD_ASYNC && tree) ? root_slot_get() : -1;
     uint8_t root_tmp[64];
     if (!root_out) root_out = root_tmp;
     uint64_t* levels = nullptr;
@@ -808,6 +813,13 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (slot >= 0) g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    if (mode == BUILD_NOROOT && tree) {
+        sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
+        t->st = st;
+        t->lazy = true;
+        *tree = t;
+        return SC_OK;
+    }
     if (slot >= 0) {
         // the root is WRITTEN to the host slot by a one-wave kernel behind the build (then its sequence number): the waiting
         // host sees it a microsecond later, without a copy engine, a completion signal or a runtime call in between
@@ -838,8 +850,19 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
 }
 
 // the root of a tree, waiting for an asynchronous build if that is what made it
-int merkle_root_wait(sc_merkle* t) {
+// from_free: called by sc_merkle_free only to get the slot back -- the stream the build ran on may have been destroyed by its
+// owner by then (destroying a stream lets its work finish, so the root has landed or is about to): poll, then wait for the
+// device, never touch the stream handle.
+int merkle_root_wait(sc_merkle* t, bool from_free = false) {
     if (t->have_root) return SC_OK;
+    if (t->lazy) {
+        if (from_free) return SC_OK;
+        // nobody was expected to ask: the whole device is waited for (the build's stream may be gone), then one small copy
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(t->root, t->d_levels + 8 * (2 * t->N - 2), 64, hipMemcpyDeviceToHost));
+        t->have_root = true;
+        return SC_OK;
+    }
     if (t->slot < 0) return fail(SC_ERR_BAD_ARG, "tree has no root");
     // the prover's serial chain waits here once per round: poll the slot's sequence number (a blocking wait that has gone to
     // sleep costs tens of microseconds to wake up); every so often ask the stream, so that a failed launch cannot hang the
@@ -850,6 +873,7 @@ int merkle_root_wait(sc_merkle* t) {
     for (long spin = 0; spin < SPIN_POLLS; ++spin) {
         if (__atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == t->seq) { landed = true; break; }
         if ((spin & 4095) == 4095) {
+            if (from_free) { e = hipDeviceSynchronize(); break; }
             e = hipStreamQuery(t->st);
             if (e != hipErrorNotReady) break;              // finished (the number is there now) or failed
             (void)hipGetLastError();
@@ -857,12 +881,13 @@ int merkle_root_wait(sc_merkle* t) {
         }
     }
     if (!landed) {
-        if (e == hipSuccess || e == hipErrorNotReady) { (void)hipGetLastError(); e = hipStreamSynchronize(t->st); }
+        if (from_free) { if (e != hipSuccess) (void)hipGetLastError(); }
+        else if (e == hipSuccess || e == hipErrorNotReady) { (void)hipGetLastError(); e = hipStreamSynchronize(t->st); }
         landed = (e == hipSuccess) && __atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == t->seq;
         if (e == hipSuccess && !landed) e = hipErrorUnknown;
     }
     memcpy(t->root, (const void*)slot, 64);
-    if (e != hipSuccess) (void)hipStreamSynchronize(t->st);      // nothing may still write to the slot when it is reused
+    if (e != hipSuccess) { if (from_free) (void)hipDeviceSynchronize(); else (void)hipStreamSynchronize(t->st); }      // nothing may still write to the slot when it is reused
     g.free_root_slots.push_back(t->slot);
     t->slot = -1;
     if (e != hipSuccess) return fail(SC_ERR_HIP, hipGetErrorString(e));
@@ -1697,7 +1722,15 @@ int sc_merkle_build_async_dev(const void* d_elems, uint64_t N, sc_merkle_t** tre
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!tree || !d_elems) return fail(SC_ERR_BAD_ARG, "null argument");
-    return merkle_build_device((const Fe*)d_elems, N, nullptr, tree, pick_stream(stream), true);
+    return merkle_build_device((const Fe*)d_elems, N, nullptr, tree, pick_stream(stream), BUILD_ASYNC);
+}
+// enqueue only, for a tree whose root nobody is expected to read (takes no root slot, runs no publish kernel); sc_merkle_root
+// still works on it (it then waits for the device)
+int sc_merkle_build_noroot_dev(const void* d_elems, uint64_t N, sc_merkle_t** tree, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!tree || !d_elems) return fail(SC_ERR_BAD_ARG, "null argument");
+    return merkle_build_device((const Fe*)d_elems, N, nullptr, tree, pick_stream(stream), BUILD_NOROOT);
 }
 int sc_merkle_root(sc_merkle_t* tree, uint8_t root_out[64]) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1715,7 +1748,7 @@ int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2]
     if (!tree || !d_in || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
     hipStream_t st = pick_stream(stream);
     SCCHK(fold_device((const Fe*)d_in, N, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)d_out, st));
-    return merkle_build_device((const Fe*)d_out, N / 2, nullptr, tree, st, true);
+    return merkle_build_device((const Fe*)d_out, N / 2, nullptr, tree, st, BUILD_ASYNC);
 }
 int sc_merkle_build(const void* elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1888,7 +1921,7 @@ uint64_t sc_merkle_leaves(const sc_merkle_t* tree) { return tree ? tree->N : 0; 
 int sc_merkle_free(sc_merkle_t* tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree) return SC_OK;
-    if (tree->slot >= 0) (void)merkle_root_wait(tree);        // a root still in flight: let it land, return the slot
+    if (tree->slot >= 0) (void)merkle_root_wait(tree, true);  // a root still in flight: let it land, return the slot
     sync_before_free();
     pool_free(tree->d_levels, (2 * tree->N - 1) * 64);
     delete tree;

@@ -38,13 +38,13 @@ class Fri:
 
     def sample_index(byte_array, size):
         # fri.py:30-34 folds the bytes in with acc = (acc << 8) ^ b: the big-endian integer of the array
-        try:
-            return int.from_bytes(bytes(byte_array), "big") % size
-        except (TypeError, ValueError):
-            acc = 0
-            for b in byte_array:
-                acc = (acc << 8) ^ int(b)
-            return acc % size
+        # (only for byte strings: bytes(n) of an int n would be n zero bytes, where the reference's loop raises TypeError)
+        if isinstance(byte_array, (bytes, bytearray, memoryview)):
+            return int.from_bytes(byte_array, "big") % size
+        acc = 0
+        for b in byte_array:
+            acc = (acc << 8) ^ int(b)
+        return acc % size
 
     def sample_indices(self, seed, size, reduced_size, number):
         assert(number <= reduced_size), f"cannot sample more indices than available in last codeword; requested: {number}, available: {reduced_size}"

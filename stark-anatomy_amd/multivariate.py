@@ -102,14 +102,22 @@ class MPolynomial:
 
     def evaluate_symbolic(self, point):
         device = self._evaluate_symbolic_value_domain(point)
-        if device is not None:
+        if device is not None and device is not NotImplemented:
             return device
+        to_device = None
         if any(hasattr(q, "vec") for q in point):
-            # device operands and nothing to compute pointwise: every term vanishes (a zero factor kills its term,
-            # univariate.py:139-140), so the sum is the zero polynomial
+            # device operands the value-domain route declined (an exponent above 255, another field, more exponents than
+            # variables -- NOT "every term vanishes", which it answers itself with a zero polynomial): the reference's sums of
+            # products on the host, then back to HBM, because the caller works there
             from ntt import DevicePolynomial
-            import starkcore as _sc
-            return DevicePolynomial(_sc.DeviceVector(1), next(q.field for q in point if hasattr(q, "vec")), 0)
+            to_device = next(q.field for q in point if hasattr(q, "vec"))
+            point = [q.to_polynomial() if hasattr(q, "vec") else q for q in point]
+        acc = self._evaluate_symbolic_host(point)
+        if to_device is not None:
+            return DevicePolynomial.from_polynomial(acc, to_device)
+        return acc
+
+    def _evaluate_symbolic_host(self, point):
         # Same sums of products as multivariate.py:83-90.  The reference recomputes point[i] ^ e for every term; the powers
         # are the same polynomials each time, so they are computed once per call, and a factor that is the constant 1
         # (e = 0) is not multiplied out: `term * Polynomial([1])` has the same coefficient list as `term`.
@@ -132,9 +140,11 @@ class MPolynomial:
         the degree of the result (one zero-padded NTT each), the AIR is evaluated value by value (`mpoly_eval_kernel`), and
         one inverse NTT returns the coefficients.  The result is the unique polynomial the reference builds from schoolbook
         products; only its list length (trailing zeros) may differ, which no caller observes (fast_stark.py:110 divides it
-        by the transition zerofier, which trims by degree).  Returns None when the point is too small to be worth it."""
+        by the transition zerofier, which trims by degree).  Returns None when the point is too small to be worth it (host
+        operands only), NotImplemented for a shape mpoly_eval_kernel does not take, and -- for device operands -- the zero
+        polynomial when every term vanishes."""
         if not self.dictionary or not point:
-            return None
+            return None if not any(hasattr(q, "vec") for q in point) else NotImplemented
         on_device = [hasattr(q, "vec") for q in point]        # DevicePolynomial operands: coefficients already in HBM
         field = None
         for q, dev in zip(point, on_device):
@@ -145,13 +155,15 @@ class MPolynomial:
                 field = q.coefficients[0].field
                 break
         if field is None or field.p != Field.P_MAIN:
-            return None
+            return NotImplemented if any(on_device) else None
         nvars = len(point)
+        if nvars > 255:
+            return NotImplemented
         degs = [q.degree() for q in point]
         bound, terms = -1, []
         for k, v in self.dictionary.items():
             if len(k) > nvars or max(k, default=0) > 255:
-                return None
+                return NotImplemented
             d, dead = 0, False
             for i, e in enumerate(k):
                 if degs[i] < 0:
@@ -162,7 +174,15 @@ class MPolynomial:
                 continue
             terms.append((tuple(k) + (0,) * (nvars - len(k)), v.value))
             bound = max(bound, d)
-        if (bound < MPolynomial.VALUE_DOMAIN_MIN_DEGREE and not any(on_device)) or nvars > 255 or bound < 0:
+        if bound < 0:
+            # no live term: a zero factor kills its term whatever the exponent (univariate.py:139-140), zero coefficients add
+            # nothing -- the sum is the zero polynomial
+            if any(on_device):
+                from ntt import DevicePolynomial
+                import starkcore as _sc
+                return DevicePolynomial(_sc.DeviceVector(1), field, 0)
+            return None
+        if bound < MPolynomial.VALUE_DOMAIN_MIN_DEGREE and not any(on_device):
             return None
         import ctypes
         import starkcore as _sc

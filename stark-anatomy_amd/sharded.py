@@ -392,9 +392,11 @@ class ShardedNtt:
     def _run(self, fn):
         if self.stream is not None and torch.cuda.current_stream(self.device).cuda_stream != self.stream.cuda_stream:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self.stream):
-                fn()
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            try:
+                with torch.cuda.stream(self.stream):
+                    fn()
+            finally:        # also when fn raises ("divide by zero"): later work on the current stream stays ordered behind the engine's
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
         else:
             fn()
 
@@ -453,7 +455,7 @@ class HipFriEngine:
         sptr = self._stream()
         if need_root or sptr is None:
             return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr(elems.data_ptr(), elems.numel() // 2, sptr), elems)
-        return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr_async(elems.data_ptr(), elems.numel() // 2, sptr), elems)
+        return HipFriEngine._Tree(self.sc.MerkleTree.from_device_ptr_noroot(elems.data_ptr(), elems.numel() // 2, sptr), elems)
 
     def level(self, tree, level):
         count = tree.tree.n >> level

@@ -62,6 +62,7 @@ SIGNATURES = {
     "sc_merkle_build": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp)]),
     "sc_merkle_build_dev": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_merkle_build_async_dev": (_int, [_vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "sc_merkle_build_noroot_dev": (_int, [_vp, _u64, ctypes.POINTER(_vp), _vp]),
     "sc_merkle_root": (_int, [_vp, _vp]),
     "sc_fri_fold_commit_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
@@ -92,18 +93,34 @@ _lib = None
 def _one_hip_runtime():
     """torch wheels carry their own copy of the HIP runtime (same soname as /opt/rocm's).  Two copies in one process do not share
     the device: if libstarkcore.so pulled in the system copy first, a later `import torch` would find "No HIP GPUs".  When torch is
-    installed it is therefore imported (not initialised) before the library is loaded, so that both bind to one runtime --
-    sharded.py and bench.py use torch for memory, streams and collectives in the same process.  STARKCORE_NO_TORCH=1 skips this
-    (a process that never touches torch)."""
+    installed but not imported yet, its copy of libamdhip64 is therefore loaded (by path, RTLD_GLOBAL) before the library, so
+    that libstarkcore's DT_NEEDED binds to it by soname and a later `import torch` (sharded.py and bench.py use torch for memory,
+    streams and collectives in the same process) finds the same runtime -- without importing torch here: a pure C-ABI user pays
+    milliseconds, not the seconds and side effects of the import.  Only if that preload fails torch itself is imported; a failure
+    of both is reported, not hidden.  STARKCORE_NO_TORCH=1 skips all of it (a process that never touches torch)."""
     import importlib.util
     import sys
+    import warnings
     if "torch" in sys.modules or os.environ.get("STARKCORE_NO_TORCH") == "1":
         return
     try:
-        if importlib.util.find_spec("torch") is not None:
-            import torch  # noqa: F401
-    except Exception:      # noqa: BLE001  a broken torch install must not take the library down with it
-        pass
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    runtime = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    try:
+        if os.path.exists(runtime):
+            ctypes.CDLL(runtime, mode=ctypes.RTLD_GLOBAL)
+            return
+    except OSError as e:
+        warnings.warn("starkcore: could not preload torch's HIP runtime (%s); importing torch instead" % e)
+    try:
+        import torch  # noqa: F401
+    except Exception as e:      # noqa: BLE001  a broken torch install must not take the library down with it -- but say so
+        warnings.warn("starkcore: torch is installed but neither its HIP runtime nor torch itself could be loaded (%r); a later "
+                      "`import torch` in this process may not see the GPU (set STARKCORE_NO_TORCH=1 to silence)" % (e,))
 
 
 def lib():
@@ -379,6 +396,14 @@ class MerkleTree:
         root, never waits at all -- copy_level on the same stream is ordered behind the build)"""
         h = _vp()
         _check(lib().sc_merkle_build_async_dev(ptr, n, ctypes.byref(h), stream))
+        return cls(h, None, n)
+
+    @classmethod
+    def from_device_ptr_noroot(cls, ptr, n, stream=None):
+        """enqueue-only build of a tree whose root is not expected to be read (a rank's local subtree of a sharded commit): no
+        pinned root slot, no publish kernel.  `.root` still works, at the price of a device-wide wait."""
+        h = _vp()
+        _check(lib().sc_merkle_build_noroot_dev(ptr, n, ctypes.byref(h), stream))
         return cls(h, None, n)
 
     @classmethod

@@ -123,7 +123,8 @@ def test_table_cache_eviction_keeps_tables_in_use(sc):
 
 @pytest.mark.parametrize("logn", [22, 24])
 def test_ntt_full_size_properties(sc, logn):
-    """BASELINE sizes: round trip, agreement of two different pass decompositions, and DC / Nyquist sums."""
+    """BASELINE sizes: round trip, agreement of two different pass decompositions, DC / Nyquist sums, and the forward and
+    inverse transforms element for element against the C oracle (north_star: "2^24 ... bit-exact vs code/ntt.py")."""
     n = 1 << logn
     root = po.primitive_nth_root(n)
     x = sc.DeviceVector.from_bytes(packed(700 + logn, n))
@@ -155,8 +156,15 @@ def test_ntt_full_size_properties(sc, logn):
     finally:
         sc.set_tuning("loge", 2)
         sc.set_tuning("max_col_log", -1)
-    if logn == 22:
-        assert yb == C.ntt(root, xin, n)            # the oracle still finishes in seconds here
+    # directly against the C oracle (reference code/ntt.py:3-30), forward AND inverse, at both BASELINE sizes (2^24: ~15 s of
+    # oracle time per transform).  The inverse is taken of an independent vector, not of the forward output, so it is pinned by
+    # the oracle and not only by the round trip.
+    assert yb == C.ntt(root, xin, n)
+    del yb
+    w = sc.DeviceVector.from_bytes(packed(900 + logn, n))
+    sc._check(lib.sc_ntt_dev(w.ptr, z.ptr, n, sc.fe_bytes(root), 1, None))
+    sc.synchronize()
+    assert z.to_bytes() == C.intt(root, w.to_bytes(), n)
 
 
 def test_ntt_four_pass_plan_2p25(sc):
@@ -587,6 +595,15 @@ def test_async_commit_round_and_wide_query(sc):
     del many
     unfetched = sc.MerkleTree.from_device_async(vs[0])         # freed with its root still in flight
     del unfetched
+    # enqueue-only builds whose root nobody reads (local subtrees of a sharded commit): they take no root slot, so
+    # more of them than there are slots can be alive while asynchronous builds still publish; their levels and (on demand)
+    # their root are right
+    quiet = [sc.MerkleTree.from_device_ptr_noroot(vs[i % 8].ptr, 256) for i in range(300)]
+    again = sc.MerkleTree.from_device_async(vs[3])
+    assert again.root == C.merkle_commit(packed(1603, 256), 256)
+    assert quiet[299].open_batch([17]) == [C.merkle_open(packed(1600 + 299 % 8, 256), 256, 17)]
+    assert quiet[5].root == C.merkle_commit(packed(1605, 256), 256)
+    del quiet, again
     # one commit round in one call
     from algebra import Field
     field = Field.main()

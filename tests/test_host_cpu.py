@@ -3,6 +3,8 @@ Fri index sampling) against golden vectors captured from the reference."""
 import hashlib
 import pickle
 
+import pytest
+
 from conftest import load_golden
 import synth
 from algebra import Field, FieldElement, xgcd
@@ -162,6 +164,13 @@ def test_byte_sampling_matches_the_shift_xor_loop():
                 assert Fri.sample_index(data, size) == loop(data, size)
     assert Fri.sample_index([1, 2, 300], 1000) == loop([1, 2, 300], 1000)      # not byte values: the reference's loop verbatim
     assert field.sample([7, 1000]).value == loop([7, 1000], field.p)
+    # an int is not a byte array: the reference's loop raises TypeError (iterating an int); bytes(n) -- n zero bytes, value 0 --
+    # must not be mistaken for it
+    for bad in (5, 0):
+        with pytest.raises(TypeError):
+            field.sample(bad)
+        with pytest.raises(TypeError):
+            Fri.sample_index(bad, 16)
 
 
 def test_colinearity_shortcut_matches_interpolation():
