@@ -6,12 +6,16 @@
 
 N = 1: workload = BASELINE configs[1]: forward + inverse 2^20-point NTT, data resident in HBM.
        One step = one forward + one inverse transform;  value = 2 * n * K / elapsed  (field elements / s).
-N > 1: four-step NTT sharded over the ranks with one RCCL all-to-all (see stark-anatomy_amd/sharded.py).  A bare
-       `python bench.py --gpus N` re-launches itself under torch.distributed.run; the N > 1 line also carries the whole
-       BASELINE configs[4] call census on the sharded layout (extras.stark_census_sharded); `--workload stark_census` makes that
-       the timed step.  With fewer GPUs than ranks the ranks share devices and exchange through gloo (labelled functional run).
-       Both forms of the corner turn (one blocking collective / 4 asynchronous row blocks) are checked and timed for a few steps
-       first; the faster one is measured (`config.corner_turn`).
+       `extras.ntt_2p24_strong` carries the N = 1 member of the north_star series (forward + inverse at 2^24, with `frac`).
+N > 1: the north_star line: forward + inverse 2^24-point NTT as a four-step transform sharded over the ranks (STRONG scaling:
+       the same 2^24 for every N; `--scaling weak` times 2^21 elements per GPU instead, `--log2n` any size), one corner turn per
+       transform (stark-anatomy_amd/sharded.py).  A bare `python bench.py --gpus N` re-launches itself under
+       torch.distributed.run; the line also carries the whole BASELINE configs[4] call census on the sharded layout
+       (extras.stark_census_sharded); `--workload stark_census` makes that the timed step.  With fewer GPUs than ranks the
+       ranks share devices and exchange through gloo (labelled functional run).
+       The forms of the corner turn (torch.distributed or the library's own RCCL communicator; one blocking exchange or row
+       blocks overlapped with the row stage) are each checked against the first and timed for a few steps; the fastest correct
+       one is measured (`config.corner_turn` names it and lists the probe times).
 
 Timing: W untimed steps, then exactly K steps between barrier + torch.cuda.synchronize(), max over ranks -> `value`,
 `ms_per_step`, `roofline` (launch duration by HIP events on the launch stream).  The same window is then repeated after
@@ -179,15 +183,20 @@ def sharded_census(log_fri, rank, world, dev, stream, group=None, checks=40):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="default 2000 (10 for a functional run whose ranks share GPUs)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 200 (2 for a functional run whose ranks share GPUs)")
     ap.add_argument("--workload", choices=("ntt", "stark_census"), default="ntt",
                     help="ntt (headline, BASELINE configs[1]; N > 1: the sharded four-step transform) or stark_census (BASELINE configs[4] on the sharded layout)")
     ap.add_argument("--log2n", type=int, default=None, help="override the transform size (ntt) / the FRI domain (stark_census)")
     ap.add_argument("--cpu-sample-log2n", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the Fri.prove / LDE / census side measurements")
-    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU four-step code path (process group, all-to-all) even with one rank")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU four-step code path (process group, corner turn) even with one rank")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = the north_star's 2^24 transform for every N (default); weak = 2^21 elements per GPU")
+    ap.add_argument("--force-diag-exchange", action="store_true",
+                    help="send the block a rank keeps for itself through the collective as well (a one-rank world then exercises the whole RCCL path)")
+    ap.add_argument("--no-native-exchange", action="store_true", help="do not probe the library's own RCCL communicator, only torch.distributed")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -204,6 +213,10 @@ def main():
     # One rank per GPU over RCCL is the production shape.  With fewer GPUs than ranks (functional runs on a 1-GPU box) the ranks
     # share devices and the collectives go through gloo, staged over the host: correct, labelled, and not a scaling measurement.
     shared_gpus = world > ngpu
+    if args.steps is None:
+        args.steps = 10 if shared_gpus else 2000
+    if args.warmup is None:
+        args.warmup = 2 if shared_gpus else 200
     dev_index = local_rank % ngpu
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -238,65 +251,18 @@ def main():
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             if args.workload == "ntt":
-                from sharded import ShardedNtt
-                log2n = args.log2n or (20 + (world.bit_length() - 1) + 1)     # 2^21 per GPU: 8 GPUs -> 2^24
+                if args.log2n:
+                    log2n = args.log2n
+                elif args.scaling == "strong" and world > 1:
+                    log2n = 24                                                   # north_star: the same 2^24 for every N
+                else:
+                    log2n = 20 + (world.bit_length() - 1) + 1                   # 2^21 per GPU: 8 GPUs -> 2^24
                 n = 1 << log2n
-                corner_turn = None
-                candidates = {}
-                for chunks in (4, 1):
-                    # the overlapped corner turn (4 asynchronous row blocks) and the single blocking all_to_all_single: each is
-                    # checked (round trip; the overlapped forward transform against the blocking one, element for element), then
-                    # timed for a few steps; the faster one that is correct runs the measurement and the JSON line says which
-                    try:
-                        eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True, overlap_chunks=chunks)
-                        x = eng.synthetic_input(seed=1)
-                        y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
-                        z = torch.empty_like(x)
-
-                        def step(eng=eng, x=x, y=y, z=z):
-                            eng.forward(x, y)
-                            eng.inverse(y, z)
-
-                        step()
-                        dist.barrier()
-                        torch.cuda.synchronize()
-                        same = torch.equal(z, x)
-                        if chunks > 1:
-                            ref_eng = ShardedNtt(log2n, nth_root(n), rank, world, dev, always_exchange=True, overlap_chunks=1)
-                            y_ref = torch.empty_like(y)
-                            ref_eng.forward(x, y_ref)
-                            torch.cuda.synchronize()
-                            same = same and torch.equal(y_ref, y)
-                            del ref_eng, y_ref
-                        good = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-                        dist.all_reduce(good, op=dist.ReduceOp.MIN)
-                        if int(good.item()) != 1:
-                            raise RuntimeError("round trip mismatch with %d corner-turn blocks" % chunks)
-                        for _ in range(2):
-                            step()
-                        dist.barrier()
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        for _ in range(4):
-                            step()
-                        dist.barrier()
-                        torch.cuda.synchronize()
-                        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                        candidates[chunks] = (float(t.item()) / 4, step, eng, x, y, z)
-                    except Exception as e1:       # noqa: BLE001
-                        sys.stderr.write("bench.py: corner turn with %d block(s) unavailable (%r)\n" % (chunks, e1))
-                if not candidates:
-                    raise RuntimeError("no working corner turn")
-                best = min(candidates, key=lambda c: candidates[c][0])         # the same choice on every rank (times are all-reduced)
-                _, step, eng, x, y, z = candidates[best]
-                corner_turn = ("%d asynchronous row blocks overlapped with the row stage" % best if best > 1 else "one blocking all_to_all_single") + \
-                    "; probe ms/step: " + ", ".join("%d block(s) %.3f" % (c, candidates[c][0] * 1e3) for c in sorted(candidates))
-                del candidates
-                launches_per_step = 2      # N > 1: roofline is reported per whole transform (local passes + all-to-all)
+                step, eng, (x, y, z), corner_turn = sharded_setup(args, log2n, rank, world, dev, dist, backend)
+                launches_per_step = 2      # N > 1: roofline is reported per whole transform (local passes + corner turn)
                 workload = "ntt_fwd_inv_2^%d_fourstep_%dgpu" % (log2n, world)
                 total_n = n
-                parallelism = "four-step, column-sharded, 1 all-to-all per transform"
+                parallelism = "four-step, column-sharded, 1 corner turn per transform"
         except Exception as e:       # noqa: BLE001
             replicas_reason = repr(e)[:300]
             sharded = False
@@ -318,7 +284,7 @@ def main():
             sc._check(lib.sc_ntt_dev(x.data_ptr(), y.data_ptr(), n, root, 0, sptr))
             sc._check(lib.sc_ntt_dev(y.data_ptr(), z.data_ptr(), n, root, 1, sptr))
 
-        launches_per_step = 2 * ntt_passes(log2n)
+        launches_per_step = 2 * int(lib.sc_ntt_num_passes(n))
         if world == 1:
             workload = "ntt_fwd_inv_2^%d_1gpu" % log2n
             parallelism = "single"
@@ -377,6 +343,12 @@ def main():
         except Exception as e:       # noqa: BLE001  side measurements never invalidate the headline
             census = {"error": repr(e)[:300]}
 
+    # what N means for the work: the N > 1 default is the north_star's strong-scaling series (2^24 for every N; its N = 1 member is
+    # extras.ntt_2p24_strong of the N = 1 run, whose headline stays BASELINE configs[1] = 2^20); --scaling weak / replicas: work per GPU fixed
+    if not sharded or world == 1:
+        scaling_label = "weak"
+    else:
+        scaling_label = args.scaling
     if rank == 0:
         value = 2.0 * total_n * args.steps / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
@@ -393,7 +365,7 @@ def main():
         out = {
             "metric": "ntt_field_elements_per_sec", "value": value, "unit": "field-elements/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u128", "data": "synthetic",
+            "scaling": scaling_label, "vs_baseline": None, "dtype": "u128", "data": "synthetic",
             "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
                        "passes_per_transform": passes, "roundtrip_bit_exact": ok},
             "clock_ramp": {"untimed_steps_between_windows": ramp_steps, "target_ms": CLOCK_RAMP_MS,
@@ -413,6 +385,11 @@ def main():
             out["config"]["world_size"] = world
             out["config"]["corner_turn"] = corner_turn
             out["config"]["all_to_all_bytes_sent_per_rank_per_step"] = 2 * (total_n // world) * 16 * (world - 1) // world
+            out["config"]["series"] = ("north_star strong-scaling series: forward + inverse 2^%d for every N; the N = 1 member is extras.ntt_2p24_strong of the "
+                                       "N = 1 run (whose headline is BASELINE configs[1], 2^20)" % log2n) if scaling_label == "strong" else \
+                ("2^%d elements per GPU (weak); the N = 1 headline is BASELINE configs[1], 2^20 on the single-GPU plan" % (log2n - (world.bit_length() - 1)))
+            if log2n == 24:
+                out.setdefault("extras", {})["ntt_2p24_strong"] = strong_record(24, world, elapsed / args.steps, ok, corner_turn, out["config"]["all_to_all_bytes_sent_per_rank_per_step"])
         if census is not None:
             out.setdefault("extras", {})["stark_census_sharded"] = census
         if not args.no_extras and not sharded and world == 1:
@@ -434,6 +411,93 @@ def main():
             pass
     if not ok:
         sys.exit("round trip mismatch")
+
+
+def strong_record(log2n, world, seconds_per_pair, roundtrip_ok, corner_turn, bytes_sent_per_rank_per_pair, extra=None):
+    """one member of the north_star series: forward + inverse 2^log2n at `world` GPUs, absolute and as a fraction of the HBM
+    roofline (32 B per element per transform, over the N x 8 TB/s of the GPUs taking part)"""
+    n = 1 << log2n
+    rec = {"log2n": log2n, "n_gpus": world, "ms_per_pair": seconds_per_pair * 1e3, "elements_per_s": 2 * n / seconds_per_pair,
+           "alg_GBps": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * n / seconds_per_pair / 1e9,
+           "frac": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * n / seconds_per_pair / 1e9 / (HBM_PEAK_GBS * world),
+           "roundtrip_bit_exact": bool(roundtrip_ok), "roundtrip_check": "all 2^%d elements" % log2n,
+           "corner_turn": corner_turn, "bytes_sent_per_rank_per_pair": bytes_sent_per_rank_per_pair}
+    if extra:
+        rec.update(extra)
+    return rec
+
+
+def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4):
+    """The sharded transform of length 2^log2n ready to be timed: every form of the corner turn this job can run is built, its
+    forward transform compared with the first form's element for element, its round trip checked, and timed for a few steps;
+    the fastest correct one is returned as (step, engine, (x, y, z), description).  The choice is the same on every rank."""
+    import torch
+    from sharded import ShardedNtt, init_native_comm
+    n = 1 << log2n
+    root = nth_root(n)
+    on_dev = backend == "nccl"
+    forms = []                                    # (label, ShardedNtt kwargs)
+    own = dict(always_exchange=True) if args.force_diag_exchange else {}
+    if world == 1 and not args.force_diag_exchange:
+        forms.append(("one rank: nothing to exchange, the column stage writes the rank's own block in place", {}))
+    else:
+        forms.append(("torch.distributed, one blocking exchange", dict(own)))
+        forms.append(("torch.distributed, 4 asynchronous row blocks overlapped with the row stage", dict(own, overlap_chunks=4)))
+        native = False
+        if on_dev and not args.no_native_exchange:
+            try:
+                native = init_native_comm(rank, world, dev)
+            except Exception as e1:       # noqa: BLE001
+                sys.stderr.write("bench.py: the library's RCCL communicator is unavailable (%r)\n" % (e1,))
+        if native:
+            forms.append(("library RCCL communicator, one exchange on the compute stream", dict(own, native_exchange=True)))
+            forms.append(("library RCCL communicator, 2 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=2)))
+            forms.append(("library RCCL communicator, 4 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=4)))
+    candidates, y_ref = [], None
+    for label, kw in forms:
+        try:
+            eng = ShardedNtt(log2n, root, rank, world, dev, **kw)
+            if kw.get("native_exchange"):
+                eng.stages.native = True
+            x = eng.synthetic_input(seed=1)
+            y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
+            z = torch.empty_like(x)
+
+            def step(eng=eng, x=x, y=y, z=z):
+                eng.forward(x, y)
+                eng.inverse(y, z)
+
+            step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            same = torch.equal(z, x)
+            if y_ref is None:
+                y_ref = y.clone()
+            else:
+                same = same and torch.equal(y_ref, y)
+            good = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if int(good.item()) != 1:
+                raise RuntimeError("wrong result")
+            for _ in range(2):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(probe_steps):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if on_dev else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            candidates.append((float(t.item()) / probe_steps, label, step, eng, (x, y, z)))
+        except Exception as e1:       # noqa: BLE001
+            sys.stderr.write("bench.py: corner turn form '%s' unavailable (%r)\n" % (label, e1))
+    if not candidates:
+        raise RuntimeError("no working corner turn")
+    best = min(candidates, key=lambda c: c[0])         # the same choice on every rank (times are all-reduced)
+    desc = best[1] + "; probe ms/step: " + ", ".join("[%s] %.3f" % (c[1], c[0] * 1e3) for c in candidates)
+    return best[2], best[3], best[4], desc
 
 
 def collective_label(backend, world, ngpu, shared_gpus):
@@ -585,8 +649,18 @@ def extras(sc, lib, stream=None):
             best = device_time(pair, 40 if lg == 22 else 10)
             if stream is not None:
                 torch.cuda.synchronize()
-            res["ntt_fwd_inv_2p%d" % lg] = {"ms_per_pair": best * 1e3, "elements_per_s": 2 * nn / best, "roundtrip_bit_exact": c.to_bytes(0, 4096) == a.to_bytes(0, 4096),
+            same = c.to_bytes() == a.to_bytes()                      # the whole vector, not a sample
+            res["ntt_fwd_inv_2p%d" % lg] = {"ms_per_pair": best * 1e3, "elements_per_s": 2 * nn / best, "roundtrip_bit_exact": same,
+                                            "roundtrip_check": "all 2^%d elements" % lg,
+                                            "alg_GBps": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * nn / best / 1e9,
+                                            "frac": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * nn / best / 1e9 / HBM_PEAK_GBS,
+                                            "passes_per_transform": int(lib.sc_ntt_num_passes(nn)),
                                             "timing": "HIP events, pairs back to back, best of 3"}
+            if lg == 24:
+                # the N = 1 member of the north_star series (forward + inverse 2^24 at 1/2/4/8 GPUs; the N > 1 members are the
+                # headline of `bench.py --gpus N`)
+                res["ntt_2p24_strong"] = strong_record(24, 1, best, same, "single GPU: three-pass plan, no exchange", 0,
+                                                       {"timing": "HIP events, pairs back to back, best of 3"})
             del a, b, c
         except Exception as e:
             res["ntt_fwd_inv_2p%d" % lg] = {"error": repr(e)}
@@ -714,14 +788,6 @@ def measured_traffic(log2n):
 def ctypes_void(v):
     import ctypes
     return ctypes.c_void_p(v)
-
-
-def ntt_passes(log2n):
-    """passes the library plans for a 2^log2n transform at default tuning (mirrors csrc/ntt_plan.h plan_num_passes)."""
-    if log2n <= 11:
-        return 1
-    digit = 10 if log2n <= 20 else 8
-    return max(2, (log2n + digit - 1) // digit)
 
 
 if __name__ == "__main__":

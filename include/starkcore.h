@@ -16,8 +16,8 @@
  *     a hipStream_t (NULL = the library's own stream) and are asynchronous on that stream.
  *   - sc_vec_t / sc_merkle_t are library-owned device objects behind opaque handles.
  *   - one context per PROCESS: sc_init(device) binds the process to one GPU (one process per GPU is the multi-GPU model,
- *     stark-anatomy_amd/sharded.py + torch.distributed/RCCL; there is no sc_init(ndev) and no sc_ntt_sharded -- the
- *     sharded transform is the Python class sharded.ShardedNtt over sc_ntt_batch_ex_dev).
+ *     stark-anatomy_amd/sharded.py + torch.distributed/RCCL; there is no sc_init(ndev) -- a rank's share of the sharded
+ *     transform is the sc_fourstep_* plan object below, driven by sharded.ShardedNtt).
  *   - streams: the library keeps a few scratch buffers (transform work space, temporaries) that every call reuses.  Calls
  *     that pass the SAME stream (or NULL) are ordered by that stream and need nothing else.  Calls on DIFFERENT streams must
  *     not overlap in time: order them with events, or synchronize, before switching streams (sharded.py does).  Frees of
@@ -56,6 +56,9 @@ int sc_synchronize(void);              /* wait for the library stream */
  *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune"}.  Plans are re-derived on the next call; results
  * never depend on the tuning. */
 int sc_set_tuning(const char* key, int value);
+/* kernel launches (passes over the vector) one sc_ntt_dev of length n takes at the current tuning: 1 up to 2^11, 2 up to 2^20,
+ * 3 up to 2^24, 4 beyond (0: n is not a power of two >= 2).  bench.py derives the algorithmic bytes per launch from it. */
+int sc_ntt_num_passes(uint64_t n);
 /* diagnostics (tools/pass_trace.py): while d_buf != NULL every geometry-specialised NTT pass launch writes 16 u64 per wave
  * (s_memtime at the phase boundaries of its workgroup; slot 15 = s_memrealtime at entry) to d_buf[(block*waves + wave)*16 ..];
  * the caller sizes the buffer for the launch it traces and passes NULL afterwards. */
@@ -95,6 +98,39 @@ int sc_ntt_batch_ex_dev(const void* d_in, void* d_out, uint64_t len, uint64_t ba
  * [chunks][batch][len/chunks] and writes them as `batch` adjacent columns of a wider transposed output [len][out_ld]
  * (d_out points at the block's first column). */
 int sc_ntt_rows_t_ld_dev(const void* d_in, void* d_out, uint64_t len, uint64_t batch, const uint64_t root[2], uint64_t chunks, uint64_t out_ld, void* stream);
+/* The sharded transform as one plan object per rank (what SURVEY.md 8(b) sketched as `sc_ntt_sharded`): computes exactly
+ * ntt.py:3-18 (inverse: ntt.py:20-30) of a length-2^log2n vector partitioned over `world` ranks.  n = n1 * n2 (n1 = 2^8 above
+ * 2^16, else the square split); rank g holds the column slab [R][C/G] of the row-major R x C matrix of its input (forward: R = n1,
+ * C = n2; inverse: R = n2, C = n1) and receives the column slab [C][R/G] of the output (sc_fourstep_shape returns R and C).
+ * `d_send` and `d_recv` are caller-owned buffers of n/G elements laid out [G][R/G][C/G].  All entries are asynchronous on `stream`.
+ *   sc_fourstep_cols_dev : column transforms + outer twiddle (+ n^-1 for the inverse), d_src -> d_send; block h of d_send is what
+ *       rank h must receive into block g of ITS d_recv.  With d_recv_diag != NULL the block the rank keeps (h == g) is written
+ *       straight into d_recv_diag (= the rank's d_recv) and the matching block of d_send is left untouched: it is never
+ *       copied or sent.
+ *   sc_fourstep_rows_dev : row transforms of the rank's rows [block * R/(G nblocks), ...) (nblocks = 1: all of them) read in
+ *       place from d_recv, written transposed into d_dst [C][R/G].  defer_last_pass != 0 with a two-pass row transform runs
+ *       only the first pass here; sc_fourstep_rows_finish_dev then runs the second pass for ALL rows in one launch (and is a
+ *       no-op when nothing was deferred).
+ *   sc_fourstep_run_dev : the whole transform, with the corner turn issued over the library's own RCCL communicator
+ *       (sc_comm_init; grouped ncclSend/ncclRecv to the G - 1 peers, straight from d_send into the peers' d_recv).  nblocks > 1
+ *       issues the exchange as row blocks on the library's communication stream and starts the row transforms of a block as
+ *       soon as it has landed.  force_diag_exchange (tests): the rank's own block goes through RCCL too. */
+typedef struct sc_fourstep sc_fourstep_t;
+typedef struct { char internal[128]; } sc_rccl_id_t;   /* = ncclUniqueId */
+int sc_fourstep_create(int log2n, const uint64_t root[2], int rank, int world, sc_fourstep_t** plan);
+int sc_fourstep_free(sc_fourstep_t* plan);
+int sc_fourstep_shape(const sc_fourstep_t* plan, int inverse, uint64_t* rows, uint64_t* cols_total);
+int sc_fourstep_cols_dev(const sc_fourstep_t* plan, int inverse, const void* d_src, void* d_send, void* d_recv_diag, void* stream);
+int sc_fourstep_rows_dev(const sc_fourstep_t* plan, int inverse, const void* d_recv, void* d_dst, uint64_t block, uint64_t nblocks, int defer_last_pass, void* stream);
+int sc_fourstep_rows_finish_dev(const sc_fourstep_t* plan, int inverse, void* d_dst, void* stream);
+/* the library's RCCL communicator (one per process; RCCL is dlopen'ed: rccl_path NULL = the copy already in the process, e.g.
+ * torch's, else librccl.so.1): rank 0 makes an id, the launcher distributes its 128 bytes (torch.distributed broadcast), every rank
+ * calls sc_comm_init with it (collective, blocking).  SC_ERR_UNSUPPORTED without RCCL. */
+int sc_comm_unique_id(const char* rccl_path, sc_rccl_id_t* id_out);
+int sc_comm_init(const char* rccl_path, const sc_rccl_id_t* id, int rank, int world);
+int sc_comm_destroy(void);
+int sc_fourstep_run_dev(const sc_fourstep_t* plan, int inverse, const void* d_src, void* d_send, void* d_recv, void* d_dst, uint64_t nblocks, int defer_last_pass,
+                        int force_diag_exchange, void* stream);
 /* d_data[r][c] *= root^((row_base + r) * (col_base + c)) * scale, root of order `order` (scale may be NULL = 1) */
 int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t row_base, uint64_t col_base, const uint64_t root[2], uint64_t order,
                           const uint64_t scale[2], void* stream);

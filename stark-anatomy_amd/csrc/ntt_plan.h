@@ -249,6 +249,14 @@ struct BatchExtras {
     // BATCH_ROWS_T: leading dimension of the transposed output (0 = batch): the rows of this call are `batch` adjacent columns
     // of a wider [len][out_ld] matrix -- a row block of the corner turn transformed as soon as it has landed (overlap)
     uint64_t out_ld = 0;
+    // BATCH_ROWS_T with chunks_log > 0: distance (in elements) between consecutive chunks; 0 = batch * len / chunks, i.e. the
+    // chunks of THIS call's rows lie back to back.  A row block of a bigger [chunks][all rows][len / chunks] buffer passes the
+    // bigger buffer's chunk size here and points `in` at its first row.
+    uint64_t chunk_stride = 0;
+    // BATCH_COLS: natural output rows [diag_lo, diag_lo + diag_n) are stored into diag_out (same element index) instead of
+    // `out` (PassParams::out_alt): the block of the corner turn a rank keeps for itself
+    Fe* diag_out = nullptr;
+    uint32_t diag_lo = 0, diag_n = 0;
 };
 
 inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, const NttTables& tb,
@@ -327,6 +335,13 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
                     p.tw_col_base = 0;
                 }
             }
+            if (lastp && ex.diag_out && ex.diag_n) {
+                p.out_alt = ex.diag_out;
+                p.alt_lo = ex.diag_lo;
+                p.alt_n = ex.diag_n;
+                p.alt_row_k = 1u << logA;                       // natural output row = t_mid + N_1 * k (two passes) or k (one pass)
+                p.alt_row_mid = (m == 2) ? 1u : 0u;
+            }
             pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
         } else if (!lastp) {
             // rows, first digit: [batch][R][B = N_2]: t_lo = column block, t_mid = (none), t_hi = batch row
@@ -344,10 +359,11 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
             p.in_cs = p.out_cs = 1;
             if (ex.chunks_log) {
                 // element (b, j) of the row sits at chunk (j / cw), row b, offset (j % cw), cw = len / chunks
-                if (ex.chunks_log >= logR) return false;          // chunk boundaries must fall on whole rows of this pass
+                if (ex.chunks_log > logR) return false;           // chunk boundaries must fall on whole rows of this pass
+                const uint64_t cs = ex.chunk_stride ? ex.chunk_stride : (len >> ex.chunks_log) << logbatch;     // next chunk
                 p.in_hi = len >> ex.chunks_log;                   // next batch row inside a chunk
-                p.in_split = logR - ex.chunks_log;
-                p.in_rs_hi = (len >> ex.chunks_log) << logbatch;  // next chunk
+                if (ex.chunks_log == logR) p.in_rs = cs;          // every row of this pass is a chunk of its own
+                else { p.in_split = logR - ex.chunks_log; p.in_rs_hi = cs; }
             }
             p.rfast_load = 0;
             p.tw_enable = 1;
@@ -370,11 +386,12 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
             p.in_mid = 1ull << logR;
             if (ex.chunks_log && m == 1) {
                 // single (transposing) pass straight from the chunked layout
-                if (ex.chunks_log >= logR) return false;
+                if (ex.chunks_log > logR) return false;
+                const uint64_t cs = ex.chunk_stride ? ex.chunk_stride : (len >> ex.chunks_log) << logbatch;
                 p.in_cs = len >> ex.chunks_log;
                 p.in_hi = (len >> ex.chunks_log) << logC;
-                p.in_split = logR - ex.chunks_log;
-                p.in_rs_hi = (len >> ex.chunks_log) << logbatch;
+                if (ex.chunks_log == logR) p.in_rs = cs;          // one element per chunk
+                else { p.in_split = logR - ex.chunks_log; p.in_rs_hi = cs; }
             }
             const uint64_t ld = ex.out_ld ? ex.out_ld : batch;
             p.out_cs = 1;

@@ -74,6 +74,13 @@ struct PassParams {
     // round, so the waves of a SIMD reach the barrier together instead of the oldest always winning the VALU arbitration and
     // the youngest finishing alone at half the issue rate (+2-4 % at 2^20; -3..5 % when other workgroups fill the gaps anyway)
     int prio_balance;
+    // optional second destination for a RANGE of natural output rows (column stage of the multi-GPU four-step: the rows a rank
+    // keeps for itself go straight into its receive buffer, so the diagonal block of the corner turn is neither copied nor
+    // sent): elements whose natural row  k * alt_row_k + t_mid * alt_row_mid  lies in [alt_lo, alt_lo + alt_n) are stored at
+    // out_alt[j] instead of out[j] (same index j).  nullptr = off.
+    Fe* out_alt;
+    uint32_t alt_lo, alt_n;
+    uint32_t alt_row_k, alt_row_mid;
     // diagnostics (tools/pass_trace.py): per-wave s_memtime stamps of the phases of a workgroup; nullptr in production
     unsigned long long* trace;
 };
@@ -346,7 +353,12 @@ struct Round {
         for (int i = 0; i < E; ++i) {
             const uint32_t k = bitrev32(row(i, 0), logR), c = cc[i >> S];
             uint64_t j = (uint64_t)t_hi * P.out_hi + (uint64_t)t_mid * P.out_mid + (uint64_t)t_lo * P.out_lo + (uint64_t)k * P.out_rs + (uint64_t)c * P.out_cs;
-            P.out[j] = v[i];
+            Fe* dst = P.out;
+            if (P.out_alt) {
+                const uint32_t nat = k * P.alt_row_k + t_mid * P.alt_row_mid;
+                if (nat - P.alt_lo < P.alt_n) dst = P.out_alt;
+            }
+            dst[j] = v[i];
         }
     }
 };

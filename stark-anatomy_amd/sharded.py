@@ -98,31 +98,9 @@ class HipEngine:
         """pointwise quotient (code/ntt.py:172); a zero divisor raises the reference's AssertionError("divide by zero")"""
         self.sc._check(self.lib.sc_pointwise_div_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), count, self.sptr))
 
-    # fused variants (one kernel sequence each; no separate twiddle pass, no reassembly copy)
-    def cols_ntt_twiddled(self, src, dst, length, batch, root, outer_root, order, col_base, scale_ninv):
-        rc = self.lib.sc_ntt_batch_ex_dev(src.data_ptr(), dst.data_ptr(), length, batch, 0, _fe(root), _fe(outer_root), order, col_base,
-                                          1 if scale_ninv else 0, 1, self.sptr)
-        if rc == -7:            # SC_ERR_UNSUPPORTED shape: caller falls back to the unfused steps
-            return False
-        self.sc._check(rc)
-        return True
-
-    def rows_ntt_t_chunked(self, src, dst, length, batch, chunks, root):
-        rc = self.lib.sc_ntt_batch_ex_dev(src.data_ptr(), dst.data_ptr(), length, batch, 1, _fe(root), None, 0, 0, 0, chunks, self.sptr)
-        if rc == -7:
-            return False
-        self.sc._check(rc)
-        return True
-
-
-    def rows_ntt_t_block(self, src, dst, col0, length, batch, chunks, root, out_ld):
-        """one ROW BLOCK of the corner turn: `batch` rows given as [chunks][batch][length/chunks] -> columns [col0, col0 + batch)
-        of the transposed output dst [length][out_ld]"""
-        rc = self.lib.sc_ntt_rows_t_ld_dev(src.data_ptr(), dst.data_ptr() + 16 * col0, length, batch, _fe(root), chunks, out_ld, self.sptr)
-        if rc == -7:
-            return False
-        self.sc._check(rc)
-        return True
+    def fourstep(self, log2n, root, rank, world):
+        """the rank's stage object for the sharded transform (sc_fourstep_t)"""
+        return HipFourstep(self.sc, log2n, root, rank, world, self.sptr)
 
 
 class _DoneWork:
@@ -130,17 +108,101 @@ class _DoneWork:
         return True
 
 
+class _Works:
+    """several asynchronous point-to-point operations as one handle"""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+
+class HipFourstep:
+    """A rank's share of the sharded transform as ONE library object (sc_fourstep_t, include/starkcore.h): roots, stage shapes,
+    the outer-twiddle table and the kernel plans are fixed once; a stage is one ctypes call with pointers only."""
+
+    def __init__(self, sc, log2n, root, rank, world, sptr):
+        import ctypes
+        self.sc, self.lib, self.sptr, self.ct = sc, sc.lib(), sptr, ctypes
+        h = ctypes.c_void_p()
+        sc._check(self.lib.sc_fourstep_create(log2n, _fe(root), rank, world, ctypes.byref(h)))
+        self._h = h
+        self.native = False            # sc_comm_init has been called for this world: run() may be used
+
+    def cols(self, inverse, src, send, recv_diag):
+        self.sc._check(self.lib.sc_fourstep_cols_dev(self._h, inverse, src.data_ptr(), send.data_ptr(), None if recv_diag is None else recv_diag.data_ptr(), self.sptr))
+
+    def rows(self, inverse, recv, dst, q, K, defer):
+        self.sc._check(self.lib.sc_fourstep_rows_dev(self._h, inverse, recv.data_ptr(), dst.data_ptr(), q, K, 1 if defer else 0, self.sptr))
+
+    def rows_finish(self, inverse, dst):
+        self.sc._check(self.lib.sc_fourstep_rows_finish_dev(self._h, inverse, dst.data_ptr(), self.sptr))
+
+    def run(self, inverse, src, send, recv, dst, K, defer, force_diag):
+        self.sc._check(self.lib.sc_fourstep_run_dev(self._h, inverse, src.data_ptr(), send.data_ptr(), recv.data_ptr(), dst.data_ptr(), K, 1 if defer else 0,
+                                                    1 if force_diag else 0, self.sptr))
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                self.lib.sc_fourstep_free(self._h)
+        except Exception:      # noqa: BLE001
+            pass
+        self._h = None
+
+
+def init_native_comm(rank, world, device, group=None):
+    """The library's own RCCL communicator (sc_comm_init), so that the corner turn is issued from C next to the kernels it
+    separates (sc_fourstep_run_dev): rank 0 makes the id, torch.distributed carries its 128 bytes to the others.  Returns True
+    when the communicator is up on EVERY rank (the ranks agree on the outcome), False when RCCL is not available."""
+    import ctypes
+    import os
+    import starkcore as sc
+    lib = sc.lib()
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    path = cand.encode() if os.path.exists(cand) else None
+    buf = ctypes.create_string_buffer(128)
+    ok = 1
+    if rank == 0 and lib.sc_comm_unique_id(path, buf) != 0:
+        ok = 0
+    on_dev = world > 1 and dist.get_backend(group) == "nccl"
+    t = torch.tensor([ok] + list(buf.raw), dtype=torch.int32)
+    if world > 1:
+        t = t.to(device) if on_dev else t
+        dist.broadcast(t, 0, group=group)
+        t = t.cpu()
+    if int(t[0]) != 1:
+        return False
+    ident = bytes(int(v) & 255 for v in t[1:].tolist())
+    rc = lib.sc_comm_init(path, ident, rank, world)
+    flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
+    if world > 1:
+        flag = flag.to(device) if on_dev else flag
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
 class ShardedNtt:
-    def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False, overlap_chunks=4):
+    def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False, overlap_chunks=1, native_exchange=False,
+                 defer_last_pass=True):
         assert world & (world - 1) == 0, "world size must be a power of two"
         self.log2n, self.n = log2n, 1 << log2n
         self.root = int(root)
         assert pow(self.root, self.n, P) == 1 and pow(self.root, self.n // 2, P) != 1, "root must be a primitive n-th root"
         self.rank, self.world, self.device, self.group = rank, world, device, group
-        self.always_exchange = always_exchange     # run the all-to-all even for a world of one rank (exercises the RCCL path)
+        # run the exchange even where there is nothing to exchange: the block a rank keeps for itself goes through the collective
+        # too (a world of one rank then exercises the whole RCCL path) instead of being written in place by the column stage
+        self.always_exchange = always_exchange
         # the corner turn is issued as this many row blocks; the row stage of block q runs while blocks q+1.. are still in
-        # flight on the collective's own stream (1 = one blocking all_to_all_single)
+        # flight on the collective's own stream (1 = one blocking exchange)
         self.overlap_chunks = overlap_chunks
+        # with row blocks: the second pass of a two-pass row stage runs once over all rows instead of once per block
+        self.defer_last_pass = defer_last_pass
+        # issue the exchange from C over the library's own RCCL communicator (init_native_comm) instead of torch.distributed
+        self.native_exchange = native_exchange
         # n = n1 * n2.  Small domains: square split.  Large ones: n1 = 2^8, so that the column stage of forward() is ONE
         # pass (256-point transforms) and the row stage two, and the other way round for inverse(): 3 passes per
         # transform instead of 4 (measured per-rank compute at 2^21 local elements: 138 us -> see profiles/).
@@ -156,6 +218,9 @@ class ShardedNtt:
         else:
             self.stream = None
         self.engine = engine
+        # stage object: one library (or test-oracle) object per rank that owns roots, shapes and plans; engines without one
+        # take the primitive-by-primitive path (_transform_primitives)
+        self.stages = engine.fourstep(log2n, self.root, rank, world) if hasattr(engine, "fourstep") else None
         self._bufs = {}
         self._a2a_single = True
         self.bytes_exchanged = 0                   # bytes this rank has sent through the corner turn so far
@@ -181,7 +246,6 @@ class ShardedNtt:
         import synth
         R, C = self.n1, self.n2
         w = C // self.world
-        full_rows = []
         # row r of the slab = elements r*C + rank*w .. + w
         out = np.empty((R, w, 2), dtype=np.uint64)
         for r in range(R):
@@ -189,6 +253,85 @@ class ShardedNtt:
         return torch.from_numpy(out.view(np.int64)).to(self.device)
 
     # -- the transform ---------------------------------------------------------------------------
+    def _transform(self, src, dst, inverse):
+        """cols -> corner turn -> rows for one direction (inverse: the roles of n1 and n2 swap, root^-1, n^-1 in the twiddle)"""
+        R, C = (self.n2, self.n1) if inverse else (self.n1, self.n2)
+        if self.stages is None:
+            return self._transform_primitives(src, dst, R, C, self.root_inv if inverse else self.root, self.n_inv if inverse else 1)
+        st, G, K = self.stages, self.world, self.overlap_chunks
+        rw, cw = R // G, C // G
+        send = self._buf("send", (G * rw * cw, 2)).view(G, rw, cw, 2)
+        recv = self._buf("recv", (G * rw * cw, 2)).view(G, rw, cw, 2)
+        inv = 1 if inverse else 0
+        exchange = G > 1 or self.always_exchange
+        if K > 1 and (rw % K or (rw // K) & (rw // K - 1)):
+            K = 1
+        if exchange:
+            self.bytes_exchanged += send.numel() * 8 * (G - 1) // G
+        if not exchange:
+            st.cols(inv, src, send, recv)                      # world of one rank: the whole output is the rank's own block
+            st.rows(inv, recv, dst, 0, 1, False)
+            return
+        if self.native_exchange and getattr(st, "native", False):
+            st.run(inv, src, send, recv, dst, K, self.defer_last_pass, self.always_exchange)
+            return
+        # the block a rank keeps for itself is written into `recv` by the column stage: neither copied nor sent
+        diag_in_place = not self.always_exchange
+        st.cols(inv, src, send, recv if diag_in_place else None)
+        if K == 1:
+            self._exchange_blocks(recv, send, diag_in_place, async_op=False)
+            st.rows(inv, recv, dst, 0, 1, False)
+            return
+        rk = rw // K
+        s5, r5 = send.view(G, K, rk, cw, 2), recv.view(G, K, rk, cw, 2)
+        works = [self._exchange_blocks(r5[:, q], s5[:, q], diag_in_place, async_op=True) for q in range(K)]
+        for q in range(K):
+            works[q].wait()
+            st.rows(inv, recv, dst, q, K, self.defer_last_pass)
+        if self.defer_last_pass:
+            st.rows_finish(inv, dst)
+
+    def _exchange_blocks(self, recv, send, skip_own, async_op):
+        """The corner turn of `send` [G][...] into `recv` [G][...]: block h of send -> rank h, block g of recv <- rank g.  With
+        skip_own the rank's own block is left alone on both sides.  RCCL: one grouped send/recv straight from / into the
+        (possibly strided) blocks.  gloo (functional runs on CPU, or with several ranks sharing one GPU): point-to-point
+        messages, device tensors staged through the host.  Returns a handle with wait() when async_op."""
+        G, g = self.world, self.rank
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            if not skip_own and not async_op and send.is_contiguous() and recv.is_contiguous():
+                dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+                return _DoneWork()
+            empty = send.new_empty((0,))
+            outs = [empty if (skip_own and h == g) else recv[h] for h in range(G)]
+            ins = [empty if (skip_own and h == g) else send[h] for h in range(G)]
+            work = dist.all_to_all(outs, ins, group=self.group, async_op=async_op)
+            return work if async_op else _DoneWork()
+        peers = [h for h in range(G) if h != g]
+        if not skip_own:
+            recv[g].copy_(send[g])
+        staged = send.is_cuda
+        if staged:
+            torch.cuda.current_stream(self.device).synchronize()
+        inbox = {h: torch.empty(recv[h].shape, dtype=recv.dtype) if (staged or not recv[h].is_contiguous()) else recv[h] for h in peers}
+        works = [dist.irecv(inbox[h], h, group=self.group) for h in peers]
+        works += [dist.isend(send[h].cpu().contiguous() if staged else send[h].contiguous(), h, group=self.group) for h in peers]
+
+        def land():
+            for w in works:
+                w.wait()
+            for h in peers:
+                if inbox[h] is not recv[h]:
+                    recv[h].copy_(inbox[h])
+            return True
+        if async_op and not staged:
+            done = _Works(works)
+            done.wait = land
+            return done
+        land()
+        return _DoneWork()
+
+    # -- the same transform primitive by primitive (engines without a stage object: the CPU oracle engine of the tests) ----------
     def stage_cols(self, src, R, C, root, scale):
         """(1) column transforms (out of place) + (2) outer twiddle with the GLOBAL column index -> [R][C/G]."""
         cw = C // self.world
@@ -196,16 +339,6 @@ class ShardedNtt:
         self.engine.cols_ntt(src, a, R, cw, pow(root, C, P))          # root^C is a primitive R-th root
         self.engine.twiddle(a, R, cw, 0, self.rank * cw, root, self.n, scale)
         return a
-
-    def exchange(self, a, R, C):
-        """(3) corner turn: rank h receives rows [h*R/G, (h+1)*R/G) of every rank's slab -> [R/G][C]."""
-        G = self.world
-        if G == 1 and not self.always_exchange:
-            return a
-        rw, cw = R // G, C // G
-        recv = self._buf("recv", (G, rw, cw, 2))
-        self._all_to_all(recv, a)
-        return self.assemble_rows(recv, R, C)
 
     def _all_to_all(self, recv, a):
         """recv[g'] <- rows [rank*rw, (rank+1)*rw) of rank g's slab.  One collective; the list form is only a fallback for
@@ -236,75 +369,16 @@ class ShardedNtt:
         """(4) row transforms of length C, transposed output [C][R/G]."""
         self.engine.rows_ntt_t(rows, dst, C, R // self.world, pow(root, R, P))
 
-    def _transform(self, src, dst, R, C, root, scale):
-        eng, G = self.engine, self.world
-        fused = hasattr(eng, "cols_ntt_twiddled")
+    def _transform_primitives(self, src, dst, R, C, root, scale):
+        G = self.world
         cw, rw = C // G, R // G
-        # (1)+(2) column transforms with the outer twiddle in their store epilogue
-        a = None
-        if fused:
-            a = self._buf("a", (R, cw, 2))
-            if not eng.cols_ntt_twiddled(src, a, R, cw, pow(root, C, P), root, self.n, self.rank * cw, scale != 1):
-                a = None
-        if a is None:
-            a = self.stage_cols(src, R, C, root, scale)
-        # (3) corner turn
+        a = self.stage_cols(src, R, C, root, scale)
         if G == 1 and not self.always_exchange:
             self.stage_rows(a, dst, R, C, root)
             return
-        if fused and self._transform_overlapped(a, dst, R, C, root):
-            return
         recv = self._buf("recv", (G, rw, cw, 2))
         self._all_to_all(recv, a)
-        # (4) row transforms straight from the chunked layout the all-to-all left behind
-        if fused and eng.rows_ntt_t_chunked(recv, dst, C, rw, G, pow(root, R, P)):
-            return
         self.stage_rows(self.assemble_rows(recv, R, C), dst, R, C, root)
-
-    def _transform_overlapped(self, a, dst, R, C, root):
-        """(3)+(4) pipelined: the rows each rank receives are split into K blocks; block q's exchange is a grouped send/recv
-        of G messages (all links busy, like the single collective), issued asynchronously one after the other, and the row
-        transforms of block q start as soon as it has landed -- while blocks q+1.. are still on the wire.  Returns False
-        (nothing issued) when the shapes do not allow it; the caller then runs the blocking form."""
-        eng, G, K = self.engine, self.world, self.overlap_chunks
-        rw, cw = R // G, C // G
-        if K <= 1 or rw % K or not hasattr(eng, "rows_ntt_t_block"):
-            return False
-        rk = rw // K
-        if rk & (rk - 1):
-            return False
-        a5 = a.view(G, K, rk, cw, 2)
-        recv = self._buf("recv_blocks", (K, G, rk, cw, 2))
-        works = [self._all_to_all_blocks(recv[q], [a5[h, q] for h in range(G)]) for q in range(K)]
-        root_rows = pow(root, R, P)
-        done = True
-        for q in range(K):
-            works[q].wait()
-            if done and not eng.rows_ntt_t_block(recv[q], dst, q * rk, C, rk, G, root_rows, rw):
-                done = False                              # shape not supported by the fused kernel: finish the exchange, then
-        if not done:                                      # transform from the reassembled rows
-            rows = self._buf("rows", (rw, G, cw, 2))
-            rows.view(K, rk, G, cw, 2).copy_(recv.permute(0, 2, 1, 3, 4))
-            self.stage_rows(rows.view(rw, C, 2), dst, R, C, root)
-        return True
-
-    def _all_to_all_blocks(self, recv_q, send_blocks):
-        """one row block of the corner turn: block h of `send_blocks` goes to rank h, recv_q[g] comes from rank g.  Asynchronous on
-        the collective's own stream (RCCL) / thread (gloo on CPU tensors); returns a work handle with wait()."""
-        G = self.world
-        self.bytes_exchanged += sum(b.numel() for b in send_blocks) * 8 * (G - 1) // G
-        if dist.get_backend(self.group) == "gloo":
-            # gloo has no list all-to-all: gather the G blocks into one contiguous send buffer and use the single form.
-            # Device tensors (functional tests: ranks sharing one GPU) are staged through the host, synchronously.
-            send = torch.stack([b for b in send_blocks], dim=0)
-            if recv_q.is_cuda:
-                host = torch.empty(recv_q.shape, dtype=recv_q.dtype)
-                dist.all_to_all_single(host.view(-1), send.cpu().view(-1), group=self.group)
-                recv_q.copy_(host)
-                return _DoneWork()
-            return dist.all_to_all_single(recv_q.view(-1), send.view(-1), group=self.group, async_op=True)
-        # RCCL: grouped send/recv straight from the strided blocks of the slab (no staging copy)
-        return dist.all_to_all(list(recv_q.unbind(0)), list(send_blocks), group=self.group, async_op=True)
 
     def slab_of(self, coeffs, key="slab_of"):
         """This rank's column slab [n1][n2/G] (zero-padded) of a coefficient vector `coeffs` [m][2] that is REPLICATED on every
@@ -383,11 +457,11 @@ class ShardedNtt:
 
     def forward(self, x_local, y_local):
         """x_local [n1][n2/G] -> y_local [n2][n1/G]  (column slab of X[k2*n1 + k1])."""
-        self._run(lambda: self._transform(x_local, y_local, self.n1, self.n2, self.root, 1))
+        self._run(lambda: self._transform(x_local, y_local, False))
 
     def inverse(self, y_local, x_local):
         """y_local [n2][n1/G] -> x_local [n1][n2/G]; uses root^-1 and folds n^-1 into the outer twiddle (ntt.py:27-30)."""
-        self._run(lambda: self._transform(y_local, x_local, self.n2, self.n1, self.root_inv, self.n_inv))
+        self._run(lambda: self._transform(y_local, x_local, True))
 
     def _run(self, fn):
         if self.stream is not None and torch.cuda.current_stream(self.device).cuda_stream != self.stream.cuda_stream:

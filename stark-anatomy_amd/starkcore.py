@@ -29,6 +29,7 @@ SIGNATURES = {
     "sc_last_error": (ctypes.c_char_p, []),
     "sc_synchronize": (_int, []),
     "sc_set_tuning": (_int, [ctypes.c_char_p, _int]),
+    "sc_ntt_num_passes": (_int, [_u64]),
     "sc_debug_trace": (_int, [_vp]),
     "sc_field_selftest": (_int, [_int, _vp, _vp, _vp, _u64]),
     "sc_vec_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
@@ -44,6 +45,16 @@ SIGNATURES = {
     "sc_ntt_batch_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp]),
     "sc_ntt_batch_ex_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _u64, _int, _u64, _vp]),
     "sc_ntt_rows_t_ld_dev": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _vp]),
+    "sc_fourstep_create": (_int, [_int, _vp, _int, _int, ctypes.POINTER(_vp)]),
+    "sc_fourstep_free": (_int, [_vp]),
+    "sc_fourstep_shape": (_int, [_vp, _int, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
+    "sc_fourstep_cols_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
+    "sc_fourstep_rows_dev": (_int, [_vp, _int, _vp, _vp, _u64, _u64, _int, _vp]),
+    "sc_fourstep_rows_finish_dev": (_int, [_vp, _int, _vp, _vp]),
+    "sc_comm_unique_id": (_int, [ctypes.c_char_p, _vp]),
+    "sc_comm_init": (_int, [ctypes.c_char_p, _vp, _int, _int]),
+    "sc_comm_destroy": (_int, []),
+    "sc_fourstep_run_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _u64, _int, _int, _vp]),
     "sc_twiddle_matrix_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _u64, _vp, _vp]),
     "sc_coset_evaluate": (_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     "sc_coset_evaluate_dev": (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),

@@ -122,9 +122,20 @@ extern "C" void emu_field(const uint64_t* a, const uint64_t* b, uint64_t* out /*
 }
 
 // batched transforms (multi-GPU building blocks): kind 0 = columns of [len][batch], kind 1 = rows of [batch][len] -> [len][batch]
+// extras of the four-step plan object (sc_fourstep_*): a second destination for a range of natural output rows (kind 0), an
+// explicit chunk stride (kind 1), a caller-owned work buffer and a pass range (row blocks with a deferred second pass)
+struct EmuExtras {
+    uint64_t* diag_out = nullptr;
+    uint32_t diag_lo = 0, diag_n = 0;
+    uint64_t chunk_stride = 0;
+    uint64_t* work = nullptr;
+    int pass_lo = 0, pass_hi = 4;
+};
+
 static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,
                                int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log,
-                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log, int inner_direct, uint64_t out_ld) {
+                               const uint64_t* outer_root, int outer_logorder, uint64_t outer_col_base, int outer_ninv, int chunks_log, int inner_direct, uint64_t out_ld,
+                               const EmuExtras& xx = EmuExtras()) {
     const uint64_t len = 1ull << loglen, batch = 1ull << logbatch;
     Fe r_m = to_mont(Fe{root[0], root[1]});
     NttTuning tu;
@@ -136,10 +147,15 @@ static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int log
     fill_table(tl, len < 4096 ? len : 4096, r_m, 1, fe_mont_one());
     fill_table(th, len > 4096 ? len >> 12 : 1, r_m, 4096, fe_mont_one());
     tb.mt = mt.data(); tb.tl = tl.data(); tb.th = th.data();
-    std::vector<Fe> work(len * batch);
+    std::vector<Fe> work_own(xx.work ? 0 : len * batch);
+    Fe* work_p = xx.work ? (Fe*)xx.work : work_own.data();
     BatchExtras ex;
     ex.chunks_log = chunks_log;
     ex.out_ld = out_ld;
+    ex.chunk_stride = xx.chunk_stride;
+    ex.diag_out = (Fe*)xx.diag_out;
+    ex.diag_lo = xx.diag_lo;
+    ex.diag_n = xx.diag_n;
     std::vector<Fe> otl, oth, otw;
     if (outer_root) {
         Fe o_m = to_mont(Fe{outer_root[0], outer_root[1]});
@@ -156,7 +172,7 @@ static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int log
         }
     }
     NttPlanDesc d;
-    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu, ex)) return -1;
+    if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work_p, (Fe*)out, tu, ex)) return -1;
     std::vector<Fe> itw;
     if ((inner_direct & 1) && d.npasses == 2) {
         // the library's direct inter-pass table (twiddle_table_kernel): [k][b] = w^(b*k), B = len >> digits[0]
@@ -164,9 +180,10 @@ static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int log
         itw.resize(len);
         for (uint64_t i = 0; i < len; ++i) itw[i] = pow2level(tb.tl, tb.th, (i & ((1ull << logB) - 1)) * (i >> logB));
         ex.inner_twd = itw.data();
-        if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work.data(), (Fe*)out, tu, ex)) return -1;
+        if (!plan_batched(d, kind == 0 ? BATCH_COLS : BATCH_ROWS_T, loglen, logbatch, tb, (const Fe*)in, work_p, (Fe*)out, tu, ex)) return -1;
     }
     for (int i = 0; i < d.npasses; ++i) {
+        if (i < xx.pass_lo || i >= xx.pass_hi) continue;
         switch (d.pass[i].loge) {
             case 1: run_pass<1>(d.pass[i]); break;
             case 2: run_pass<2>(d.pass[i]); break;
@@ -176,6 +193,36 @@ static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int log
         }
     }
     return d.npasses;
+}
+
+// the stages of sc_fourstep_* on one rank's buffers (csrc/starkcore.hip: fourstep_cols / fourstep_rows / fourstep_rows_finish)
+extern "C" int emu_fourstep_cols(const uint64_t* src, uint64_t* send, uint64_t* recv_diag, int logR, int logcw, const uint64_t* root_cols,
+                                 const uint64_t* outer_root, int outer_logorder, uint64_t col_base, int ninv, uint32_t diag_lo, uint32_t diag_n,
+                                 int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log) {
+    EmuExtras xx;
+    xx.diag_out = recv_diag; xx.diag_lo = diag_lo; xx.diag_n = recv_diag ? diag_n : 0;
+    return emu_batched_impl(src, send, 0, logR, logcw, root_cols, max_tile_log, loge, min_tiles_log, max_col_log, max_digit_log,
+                            outer_root, outer_logorder, col_base, ninv, 0, 3, 0, xx);
+}
+// rows [row0, row0 + 2^logrk) of the rank, read in place from recv [2^chunks_log][rw][C >> chunks_log]; work: rank-sized [rw][C]
+extern "C" int emu_fourstep_rows(const uint64_t* recv, uint64_t* dst, uint64_t* work, int logC, int logrk, uint64_t row0, uint64_t rw, int chunks_log,
+                                 const uint64_t* root_rows, int pass_lo, int pass_hi,
+                                 int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log) {
+    const uint64_t C = 1ull << logC, cw = C >> chunks_log;
+    EmuExtras xx;
+    xx.chunk_stride = rw * cw;
+    xx.work = work + 2 * row0 * C;
+    xx.pass_lo = pass_lo; xx.pass_hi = pass_hi;
+    return emu_batched_impl(recv + 2 * row0 * cw, dst + 2 * row0, 1, logC, logrk, root_rows, max_tile_log, loge, min_tiles_log, max_col_log, max_digit_log,
+                            nullptr, 0, 0, 0, chunks_log, 1, rw, xx);
+}
+extern "C" int emu_fourstep_rows_finish(uint64_t* dst, uint64_t* work, int logC, int logrw, const uint64_t* root_rows,
+                                        int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log) {
+    EmuExtras xx;
+    xx.work = work;
+    xx.pass_lo = 1; xx.pass_hi = 2;
+    return emu_batched_impl(work + 2, dst, 1, logC, logrw, root_rows, max_tile_log, loge, min_tiles_log, max_col_log, max_digit_log,
+                            nullptr, 0, 0, 0, 0, 1, 0, xx);
 }
 
 extern "C" int emu_ntt_batched(const uint64_t* in, uint64_t* out, int kind, int loglen, int logbatch, const uint64_t* root,

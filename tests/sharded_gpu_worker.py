@@ -31,18 +31,25 @@ def main():
     for log2n in (12, 17, 20):
         n = 1 << log2n
         root = po.primitive_nth_root(n)
-        eng = ShardedNtt(log2n, root, rank, world, dev, always_exchange=True)
-        x = eng.synthetic_input(seed=3)
-        y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
-        z = torch.empty_like(x)
-        eng.forward(x, y)
-        eng.inverse(y, z)
-        torch.cuda.synchronize()
         full_in = synth.synth_packed(3, n).tobytes()
-        got = gather_natural(y.cpu(), eng.n2, eng.n1, world).numpy().tobytes()
         want = po.C.ntt(root, full_in, n)
-        ok &= got == want
-        ok &= torch.equal(z, x)
+        # the forms of the corner turn: the rank's own block written in place (default) or through the exchange; one blocking
+        # exchange or row blocks, with the second pass of the row stage deferred or not -- always the same transform
+        for kw in (dict(), dict(overlap_chunks=4), dict(overlap_chunks=2, defer_last_pass=False), dict(always_exchange=True), dict(always_exchange=True, overlap_chunks=2)):
+            eng = ShardedNtt(log2n, root, rank, world, dev, **kw)
+            x = eng.synthetic_input(seed=3)
+            y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
+            z = torch.empty_like(x)
+            eng.forward(x, y)
+            eng.inverse(y, z)
+            torch.cuda.synchronize()
+            got = gather_natural(y.cpu(), eng.n2, eng.n1, world).numpy().tobytes()
+            ok &= got == want
+            ok &= torch.equal(z, x)
+            if not ok:
+                print("rank", rank, "MISMATCH at log2n", log2n, kw, flush=True)
+                break
+        eng = ShardedNtt(log2n, root, rank, world, dev)
         m = n // 8 + 3
         coeffs = synth.synth_packed(9, m)
         lde = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)

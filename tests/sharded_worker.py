@@ -63,39 +63,80 @@ class OracleEngine:
                 a[r, c, 0], a[r, c, 1] = v & ((1 << 64) - 1), v >> 64
 
 
-class FusedOracleEngine(OracleEngine):
-    """The fused / chunked entry points of the HIP engine, served by the oracle: lets the overlapped corner turn (row blocks
-    exchanged asynchronously, each transformed as it lands) run under gloo on the CPU."""
+class OracleStages:
+    """The stage object of the HIP engine (sharded.HipFourstep over sc_fourstep_t) served by the oracle: same layouts, same
+    contract -- column stage into `send` [G][R/G][C/G] with the rank's own block optionally written straight into `recv`, row
+    stage reading `recv` in place, in row blocks, with an optionally deferred second pass (modelled by doing the whole
+    transform of a block's rows either right away or in rows_finish) -- so that the orchestration of ShardedNtt._transform
+    (blocks never written are poisoned) runs under gloo on the CPU."""
 
-    def cols_ntt_twiddled(self, src, dst, length, batch, root, outer_root, order, col_base, scale_ninv):
-        self.cols_ntt(src, dst, length, batch, root)
-        self.twiddle(dst, length, batch, 0, col_base, outer_root, order, pow(order, P - 2, P) if scale_ninv else 1)
-        return True
+    def __init__(self, log2n, root, rank, world):
+        self.n, self.root, self.rank, self.world = 1 << log2n, root, rank, world
+        self.n1 = 1 << ((log2n + 1) // 2 if log2n <= 16 else 8)
+        self.n2 = self.n // self.n1
+        self.pending = {}
 
-    def _rows_from_chunks(self, src, length, batch, chunks):
-        a = self._np(src).reshape(chunks, batch, length // chunks, 2)
-        return np.ascontiguousarray(a.transpose(1, 0, 2, 3)).reshape(batch, length, 2)
+    def _dir(self, inverse):
+        R, C = (self.n2, self.n1) if inverse else (self.n1, self.n2)
+        root = pow(self.root, self.n - 1, P) if inverse else self.root
+        return R, C, root, (pow(self.n, P - 2, P) if inverse else 1)
 
-    def rows_ntt_t_chunked(self, src, dst, length, batch, chunks, root):
-        self.rows_ntt_t(torch.from_numpy(self._rows_from_chunks(src, length, batch, chunks).view(np.int64)), dst, length, batch, root)
-        return True
+    def cols(self, inverse, src, send, recv_diag):
+        R, C, root, scale = self._dir(inverse)
+        G, g = self.world, self.rank
+        rw, cw = R // G, C // G
+        eng = OracleEngine()
+        a = torch.empty((R, cw, 2), dtype=torch.int64)
+        eng.cols_ntt(src.contiguous(), a, R, cw, pow(root, C, P))
+        eng.twiddle(a, R, cw, 0, g * cw, root, self.n, scale)
+        blocks = a.view(G, rw, cw, 2)
+        for h in range(G):
+            if h == g and recv_diag is not None:
+                recv_diag.view(G, rw, cw, 2)[g].copy_(blocks[g])
+                send.view(G, rw, cw, 2)[g].fill_(-1)               # never sent: poison it
+            else:
+                send.view(G, rw, cw, 2)[h].copy_(blocks[h])
 
-    def rows_ntt_t_block(self, src, dst, col0, length, batch, chunks, root, out_ld):
-        rows = self._rows_from_chunks(src, length, batch, chunks)
-        out = self._np(dst).reshape(length, out_ld, 2)
-        for r in range(batch):
-            out[:, col0 + r, :] = np.frombuffer(po.C.ntt(root, rows[r].tobytes(), length), dtype=np.uint64).reshape(length, 2)
-        return True
+    def _rows_now(self, R, C, root, recv, dst, row0, nrows):
+        G = self.world
+        rw, cw = R // G, C // G
+        a = recv.numpy().view(np.uint64).reshape(G, rw, cw, 2)
+        out = dst.numpy().view(np.uint64).reshape(C, rw, 2)
+        rt = pow(root, R, P)
+        for r in range(row0, row0 + nrows):
+            row = np.ascontiguousarray(a[:, r]).reshape(C, 2)          # [G][cw] -> the row's C elements in column order
+            out[:, r, :] = np.frombuffer(po.C.ntt(rt, row.tobytes(), C), dtype=np.uint64).reshape(C, 2)
+
+    def rows(self, inverse, recv, dst, q, K, defer):
+        R, C, root, _ = self._dir(inverse)
+        rk = R // self.world // K
+        if defer:
+            self.pending.setdefault(inverse, []).append((recv.clone(), q * rk, rk))   # a snapshot: later blocks must not be needed
+            return
+        self._rows_now(R, C, root, recv, dst, q * rk, rk)
+
+    def rows_finish(self, inverse, dst):
+        R, C, root, _ = self._dir(inverse)
+        for recv, row0, nrows in self.pending.pop(inverse, []):
+            self._rows_now(R, C, root, recv, dst, row0, nrows)
+
+
+class StagesOracleEngine(OracleEngine):
+    def fourstep(self, log2n, root, rank, world):
+        return OracleStages(log2n, root, rank, world)
 
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ok = True
-    for log2n, engine, chunks in ((6, OracleEngine(), 4), (7, FusedOracleEngine(), 2), (10, FusedOracleEngine(), 4), (10, FusedOracleEngine(), 1), (10, OracleEngine(), 4)):
+    # (size, engine, row blocks of the corner turn, deferred second pass, own block through the exchange)
+    for log2n, engine, chunks, defer, always in ((6, OracleEngine(), 1, True, False), (7, StagesOracleEngine(), 2, True, False), (10, StagesOracleEngine(), 4, True, False),
+                                                 (10, StagesOracleEngine(), 4, False, True), (10, StagesOracleEngine(), 1, True, False), (10, StagesOracleEngine(), 1, True, True),
+                                                 (10, OracleEngine(), 1, True, True)):
         n = 1 << log2n
         root = po.primitive_nth_root(n)
-        eng = ShardedNtt(log2n, root, rank, world, torch.device("cpu"), engine=engine, overlap_chunks=chunks)
+        eng = ShardedNtt(log2n, root, rank, world, torch.device("cpu"), engine=engine, overlap_chunks=chunks, defer_last_pass=defer, always_exchange=always)
         x = eng.synthetic_input(seed=3)
         assert tuple(x.shape) == eng.local_shape(True)
         y = torch.empty(eng.local_shape(False), dtype=torch.int64)

@@ -213,3 +213,75 @@ def test_emu_batched(emu, cfg):
                     rc = emu.emu_ntt_rows_ld(part, dst, loglen, logbatch - 1, root.to_bytes(16, "little"), tile, loge, min_tiles, max_col, digit, chunks_log, 1, bt)
                     assert rc > 0, (cfg, chunks_log, blk)
                 assert wide.raw == expect, (cfg, chunks_log, "row blocks")
+
+
+@pytest.mark.parametrize("log2n,world,blocks,defer,diag", [(8, 2, 1, False, True), (10, 4, 2, True, True), (12, 4, 4, True, True), (12, 2, 2, False, True),
+                                                         (12, 4, 2, True, False), (12, 1, 4, True, True), (10, 8, 1, False, True)])
+def test_emu_fourstep_stages(emu, log2n, world, blocks, defer, diag):
+    """The stages of the sharded transform's plan object (sc_fourstep_cols_dev / _rows_dev / _rows_finish_dev) with the kernel
+    body and planner the device uses: column stage with the outer twiddle, the rank's own block written straight into its
+    receive buffer (PassParams::out_alt); row stage reading [G][R/G][C/G] in place with an explicit chunk stride, in row blocks,
+    second pass deferred to one full launch.  A simulated world of ranks against the oracle's transform of the whole vector."""
+    import numpy as np
+    n = 1 << log2n
+    root = po.primitive_nth_root(n)
+    log1 = (log2n + 1) // 2
+    n1, n2 = 1 << log1, n >> log1
+    tune = (8, 2, 2, 3, 4)       # tile, loge, min_tiles, max_col, digit: two-pass stages from 2^5 up, several tiles per pass
+    i32, u64, vp = ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p
+    emu.emu_fourstep_cols.restype = i32
+    emu.emu_fourstep_cols.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, u64, i32, ctypes.c_uint32, ctypes.c_uint32] + [i32] * 5
+    emu.emu_fourstep_rows.restype = i32
+    emu.emu_fourstep_rows.argtypes = [vp, vp, vp, i32, i32, u64, u64, i32, vp, i32, i32] + [i32] * 5
+    emu.emu_fourstep_rows_finish.restype = i32
+    emu.emu_fourstep_rows_finish.argtypes = [vp, vp, i32, i32, vp] + [i32] * 5
+    full = synth.synth_packed(77 + log2n, n)
+    want = np.frombuffer(po.C.ntt(root, full.tobytes(), n), dtype=np.uint64).reshape(n2, n1, 2)
+    G = world
+    lg = G.bit_length() - 1
+
+    def direction(slabs, R, C, rt, ninv):
+        rw, cw = R // G, C // G
+        logR, logC = R.bit_length() - 1, C.bit_length() - 1
+        sends, recvs = [], []
+        for g_ in range(G):
+            send = np.full((G, rw, cw, 2), 0xEE, dtype=np.uint64)
+            recv = np.full((G, rw, cw, 2), 0xDD, dtype=np.uint64)
+            src = np.ascontiguousarray(slabs[g_])
+            rc = emu.emu_fourstep_cols(src.ctypes.data, send.ctypes.data, recv.ctypes.data if diag else None, logR, cw.bit_length() - 1,
+                                       pow(rt, C, P).to_bytes(16, "little"), rt.to_bytes(16, "little"), log2n, g_ * cw, ninv, g_ * rw, rw, *tune)
+            assert rc > 0, rc
+            sends.append(send)
+            recvs.append(recv)
+        for h in range(G):
+            for g_ in range(G):
+                if g_ != h or not diag:
+                    recvs[h][g_] = sends[g_][h]
+        outs = []
+        K = blocks if rw % blocks == 0 else 1
+        rk = rw // K
+        for h in range(G):
+            dst = np.full((C, rw, 2), 0xCC, dtype=np.uint64)
+            work = np.zeros((rw, C, 2), dtype=np.uint64)
+            two_pass = logC > tune[4]
+            for q in range(K):
+                lo, hi = (0, 1) if (defer and K > 1 and two_pass) else (0, 4)
+                rc = emu.emu_fourstep_rows(recvs[h].ctypes.data, dst.ctypes.data, work.ctypes.data, logC, rk.bit_length() - 1, q * rk, rw, lg,
+                                           pow(rt, R, P).to_bytes(16, "little"), lo, hi, *tune)
+                assert rc > 0, rc
+            if defer and K > 1 and two_pass:
+                rc = emu.emu_fourstep_rows_finish(dst.ctypes.data, work.ctypes.data, logC, rw.bit_length() - 1, pow(rt, R, P).to_bytes(16, "little"), *tune)
+                assert rc > 0, rc
+            outs.append(dst)
+        return outs
+
+    m = full.reshape(n1, n2, 2)
+    cw = n2 // G
+    xs = [m[:, g_ * cw:(g_ + 1) * cw] for g_ in range(G)]
+    ys = direction(xs, n1, n2, root, 0)
+    rw = n1 // G
+    for g_ in range(G):
+        assert ys[g_].tobytes() == np.ascontiguousarray(want[:, g_ * rw:(g_ + 1) * rw]).tobytes(), ("forward", g_)
+    zs = direction(ys, n2, n1, pow(root, n - 1, P), 1)
+    for g_ in range(G):
+        assert zs[g_].tobytes() == np.ascontiguousarray(xs[g_]).tobytes(), ("inverse", g_)

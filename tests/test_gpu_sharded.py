@@ -21,7 +21,10 @@ def sc():
     return starkcore
 
 
-def _simulate(sc, log2n, world, seed, fused=True):
+def _simulate(sc, log2n, world, seed, fused=True, blocks=1, defer=True, diag_in_place=True):
+    """fused: the ranks' stage objects (sc_fourstep_*: column stage with the outer twiddle and, with diag_in_place, the rank's own
+    block written straight into its receive buffer; row stage reading the [G][R/G][C/G] layout in place, optionally in `blocks`
+    row blocks with the second pass deferred); otherwise the primitive-by-primitive path (separate twiddle and reassembly)."""
     from sharded import ShardedNtt
     dev = torch.device("cuda", 0)
     n = 1 << log2n
@@ -32,28 +35,41 @@ def _simulate(sc, log2n, world, seed, fused=True):
         xs = [e.synthetic_input(seed) for e in engs]
         n1, n2 = engs[0].n1, engs[0].n2
 
-        def run(srcs, R, C, rt, scale):
+        def run(srcs, R, C, inverse):
+            rt, scale = (engs[0].root_inv, engs[0].n_inv) if inverse else (root, 1)
             rw, cw = R // world, C // world
-            a = []
-            for e, s_ in zip(engs, srcs):
-                buf = torch.empty((R, cw, 2), dtype=torch.int64, device=dev)
-                if fused and e.engine.cols_ntt_twiddled(s_, buf, R, cw, pow(rt, C, po.P), rt, n, e.rank * cw, scale != 1):
-                    a.append(buf)
-                else:
-                    a.append(e.stage_cols(s_, R, C, rt, scale).clone())
             outs = []
-            for h, e in enumerate(engs):
-                # what all_to_all_single delivers to rank h: from every rank g its rows [h*rw, (h+1)*rw)
-                recv = torch.stack([a[g][h * rw:(h + 1) * rw] for g in range(world)], dim=0).contiguous()
+            if not fused:
+                a = [e.stage_cols(s_, R, C, rt, scale).clone() for e, s_ in zip(engs, srcs)]
+                for h, e in enumerate(engs):
+                    # what all_to_all_single delivers to rank h: from every rank g its rows [h*rw, (h+1)*rw)
+                    recv = torch.stack([a[g][h * rw:(h + 1) * rw] for g in range(world)], dim=0).contiguous()
+                    dst = torch.empty((C, rw, 2), dtype=torch.int64, device=dev)
+                    e.stage_rows(e.assemble_rows(recv, R, C) if world > 1 else a[0], dst, R, C, rt)
+                    outs.append(dst)
+                return outs
+            inv = 1 if inverse else 0
+            # poisoned buffers: whatever is not written by the stage that owns it shows up in the result
+            sends = [torch.full((world, rw, cw, 2), -1, dtype=torch.int64, device=dev) for _ in engs]
+            recvs = [torch.full((world, rw, cw, 2), -1, dtype=torch.int64, device=dev) for _ in engs]
+            for e, s_, snd, rcv in zip(engs, srcs, sends, recvs):
+                e.stages.cols(inv, s_, snd, rcv if diag_in_place else None)
+            for h in range(world):
+                for g_ in range(world):
+                    if g_ != h or not diag_in_place:
+                        recvs[h][g_].copy_(sends[g_][h])          # the corner turn: block h of rank g -> block g of rank h
+            K = blocks if (rw % blocks == 0 and rw // blocks >= 1) else 1
+            for e, rcv in zip(engs, recvs):
                 dst = torch.empty((C, rw, 2), dtype=torch.int64, device=dev)
-                if not (fused and world > 1 and e.engine.rows_ntt_t_chunked(recv, dst, C, rw, world, pow(rt, R, po.P))):
-                    rows = e.assemble_rows(recv, R, C) if world > 1 else a[0]
-                    e.stage_rows(rows, dst, R, C, rt)
+                for q in range(K):
+                    e.stages.rows(inv, rcv, dst, q, K, defer and K > 1)
+                if defer and K > 1:
+                    e.stages.rows_finish(inv, dst)
                 outs.append(dst)
             return outs
 
-        ys = run(xs, n1, n2, root, 1)
-        zs = run(ys, n2, n1, engs[0].root_inv, engs[0].n_inv)
+        ys = run(xs, n1, n2, False)
+        zs = run(ys, n2, n1, True)
     torch.cuda.synchronize()
     full_in = synth.synth_packed(seed, n).tobytes()
     got = torch.cat(ys, dim=1).reshape(n, 2).cpu().numpy().tobytes()
@@ -65,6 +81,17 @@ def _simulate(sc, log2n, world, seed, fused=True):
 @pytest.mark.parametrize("log2n,world", [(8, 1), (10, 2), (13, 4), (16, 8), (18, 8), (21, 2)])
 def test_sharded_simulated_world(sc, log2n, world, fused):
     full_in, got, back, root = _simulate(sc, log2n, world, seed=11, fused=fused)
+    n = 1 << log2n
+    assert got == po.C.ntt(root, full_in, n)
+    assert back == full_in
+
+
+@pytest.mark.parametrize("blocks,defer,diag", [(2, True, True), (4, True, True), (4, False, True), (1, False, False), (2, True, False)])
+@pytest.mark.parametrize("log2n,world", [(10, 2), (16, 4), (18, 8), (21, 8), (21, 1)])
+def test_sharded_row_blocks_and_diagonal(sc, log2n, world, blocks, defer, diag):
+    """the row stage in row blocks (what an overlapped corner turn needs), with and without the deferred second pass, and the
+    rank's own block written in place or travelling through the exchange: always the same transform"""
+    full_in, got, back, root = _simulate(sc, log2n, world, seed=13, blocks=blocks, defer=defer, diag_in_place=diag)
     n = 1 << log2n
     assert got == po.C.ntt(root, full_in, n)
     assert back == full_in
@@ -133,6 +160,16 @@ def test_bench_sharded_path_under_torchrun_one_rank():
     out = json.loads(line)
     assert out["config"]["roundtrip_bit_exact"] is True and out["n_gpus"] == 1 and out["value"] > 0
     assert "fourstep" in out["config"]["workload"]
+    assert "nothing to exchange" in out["config"]["corner_turn"]            # a world of one rank moves no bytes
+    # the same with the rank's own block pushed through the collectives: torch.distributed over RCCL and the library's own RCCL
+    # communicator (sc_comm_init / sc_fourstep_run_dev), one exchange and row blocks, are all probed and must all be correct
+    r = subprocess.run(cmd + ["--force-diag-exchange"], capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["roundtrip_bit_exact"] is True
+    probes = out["config"]["corner_turn"]
+    assert "torch.distributed, one blocking exchange" in probes and "torch.distributed, 4 asynchronous row blocks" in probes
+    assert "library RCCL communicator, one exchange" in probes and "library RCCL communicator, 4 row blocks" in probes, probes + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -226,6 +263,23 @@ def _run_bench(args, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_two_ranks_print_the_north_star_record(sc):
+    """`python bench.py --gpus 2` times the north_star's transform -- forward + inverse at 2^24, strong scaling --
+    and carries it as extras.ntt_2p24_strong with the roofline fraction, the bytes exchanged, the form of the corner turn and a
+    round trip checked on every element (on this box: two ranks sharing the GPU over gloo, labelled functional)."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["log2n"] == 24
+    assert "ntt_fwd_inv_2^24_fourstep_2gpu" == out["config"]["workload"] and "north_star" in out["config"]["series"]
+    rec = out["extras"]["ntt_2p24_strong"]
+    assert rec["log2n"] == 24 and rec["n_gpus"] == 2 and rec["roundtrip_bit_exact"] is True and "all 2^24" in rec["roundtrip_check"]
+    assert 0 < rec["frac"] < 1 and rec["elements_per_s"] > 0 and rec["bytes_sent_per_rank_per_pair"] == 2 * (1 << 23) * 16 // 2
+    assert abs(rec["elements_per_s"] - out["value"]) < 1e-6 * out["value"]
+    assert rec["corner_turn"] == out["config"]["corner_turn"]
+    # the weak series is still there on request
+    weak = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--scaling", "weak"])
+    assert weak["scaling"] == "weak" and weak["config"]["log2n"] == 22 and "ntt_2p24_strong" not in weak.get("extras", {})
 
 
 def test_bench_bare_launch_two_ranks_and_census_parity(sc):

@@ -17,7 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd"))
 
 
-def run(log2n, steps, chunks):
+def run(log2n, steps):
     import ctypes
     import torch
     import torch.distributed as dist
@@ -37,8 +37,24 @@ def run(log2n, steps, chunks):
     torch.cuda.set_stream(stream)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     out = {"log2n": log2n, "steps": steps}
-    for k in chunks:
-        eng = ShardedNtt(log2n, r, 0, 1, dev, always_exchange=True, overlap_chunks=k)
+    from sharded import init_native_comm
+    native = init_native_comm(0, 1, dev)
+    out["native_rccl_comm"] = bool(native)
+    forms = [("in_place_nothing_to_exchange", {}),
+             ("torch_own_block_through_rccl", dict(always_exchange=True)),
+             ("torch_own_block_through_rccl_4_blocks", dict(always_exchange=True, overlap_chunks=4))]
+    if native:
+        forms += [("native_own_block_through_rccl", dict(always_exchange=True, native_exchange=True)),
+                  ("native_own_block_through_rccl_2_blocks", dict(always_exchange=True, native_exchange=True, overlap_chunks=2)),
+                  ("native_own_block_through_rccl_4_blocks", dict(always_exchange=True, native_exchange=True, overlap_chunks=4)),
+                  ("native_own_block_through_rccl_4_blocks_not_deferred", dict(always_exchange=True, native_exchange=True, overlap_chunks=4, defer_last_pass=False))]
+    only = os.environ.get("TIMELINE_FORMS")
+    for name, kw in forms:
+        if only and name not in only.split(","):
+            continue
+        eng = ShardedNtt(log2n, r, 0, 1, dev, **kw)
+        if kw.get("native_exchange"):
+            eng.stages.native = True
         x = eng.synthetic_input(seed=1)
         y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
         z = torch.empty_like(x)
@@ -50,7 +66,7 @@ def run(log2n, steps, chunks):
         for _ in range(20):
             step()
         torch.cuda.synchronize()
-        assert torch.equal(z, x)
+        assert torch.equal(z, x), name
         best = None
         for _ in range(3):
             torch.cuda.synchronize()
@@ -63,7 +79,7 @@ def run(log2n, steps, chunks):
             rec = {"ms_per_step": 1e3 * (t2 - t0) / steps, "host_enqueue_ms_per_step": 1e3 * (t1 - t0) / steps}
             if best is None or rec["ms_per_step"] < best["ms_per_step"]:
                 best = rec
-        out["sharded_world1_rccl_blocks_%d" % k] = best
+        out[name] = best
     # the plain transform of the same size through the same stream
     lib = sc.lib()
     a, b, c = sc.DeviceVector(n), sc.DeviceVector(n), sc.DeviceVector(n)
@@ -134,4 +150,4 @@ if __name__ == "__main__":
         args = [a for a in sys.argv[1:] if a != "run"]
         log2n = int(args[0]) if args else 21
         steps = int(args[1]) if len(args) > 1 else 200
-        run(log2n, steps, (1, 4))
+        run(log2n, steps)
