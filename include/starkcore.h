@@ -21,7 +21,8 @@
  *   - streams: the library keeps a few scratch buffers (transform work space, temporaries) that every call reuses.  Calls
  *     that pass the SAME stream (or NULL) are ordered by that stream and need nothing else.  Calls on DIFFERENT streams must
  *     not overlap in time: order them with events, or synchronize, before switching streams (sharded.py does).  Frees of
- *     library objects wait for the whole device once a caller stream has been seen.
+ *     library objects never wait: the memory is parked behind an event on every stream in use (the library's and the caller
+ *     streams seen so far) and goes back to the library's pool when those have completed.
  */
 #ifndef STARKCORE_H
 #define STARKCORE_H
@@ -216,6 +217,24 @@ int sc_merkle_build_noroot_dev(const void* d_elems, uint64_t N, sc_merkle_t** tr
 int sc_merkle_root(sc_merkle_t* tree, uint8_t root_out[64]);
 int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2], const uint64_t offset[2], const uint64_t omega[2], void* d_out,
                            sc_merkle_t** tree, void* stream);
+/* Fri.commit's whole round loop (fri.py:66-94) in one call, the Fiat-Shamir step included: per round the tree of the codeword
+ * (built asynchronously, the root polled from its pinned slot), alpha = Field.sample(SHAKE-256(pickle.dumps(transcript)))
+ * (ip.py:18-25, algebra.py:116-120) computed by the library, and the fold of fri.py:85 enqueued the moment alpha exists --
+ * nothing crosses the language boundary between a root arriving and the next launch.  The transcript is the list of the
+ * `prior_count` byte strings already in the proof stream (prior_lens[i] < 256 bytes each, concatenated in prior_data; the
+ * caller checks that the stream holds nothing else) followed by this call's roots: that list has a fixed pickle layout
+ * (csrc/transcript.h).  omega and offset are squared from round to round (fri.py:86-87).
+ * Out: trees_out[rounds] ([0] over d_codeword), vecs_out[rounds - 1] folded codewords (library-owned: sc_vec_free),
+ * roots_out[64 * rounds], alphas_out[2 * (rounds - 1)].  SC_ERR_UNSUPPORTED: the transcript does not have the fixed layout. */
+int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
+                      const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
+                      sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream);
+/* the host-side pieces of that step on their own (no GPU needed; tests pin them to hashlib / pickle):
+ * SHAKE-256 (FIPS 202); Field.sample = big-endian integer of the bytes mod p; pickle.dumps of a list of `count` byte strings
+ * (*out_len = bytes needed, copied into out when out_cap suffices) */
+int sc_shake256(const void* in, uint64_t len, void* out, uint64_t out_len);
+int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]);
+int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len);
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */
 int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out /* k*64*log2 N */);
 /* opened elements AND their paths in one call: elems_out[i] = d_elems[indices[i]] (d_elems = the device vector the tree was built from) */

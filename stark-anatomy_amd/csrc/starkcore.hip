@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -16,6 +17,7 @@
 #include "merkle.cuh"
 #include "polytree.cuh"
 #include "ntt_plan.h"
+#include "transcript.h"
 
 using namespace sc;
 
@@ -346,6 +348,7 @@ constexpr long SPIN_POLLS = 40000000;     // ~ tens of milliseconds of polling b
 
 Ctx g;
 std::mutex g_mu;
+hipStream_t g_comm_stream_for_free = nullptr;   // the library's communication stream once it exists (sc_fourstep_run_dev)
 
 // Small caching allocator for the big short-lived device objects (vectors, Merkle trees): hipMalloc/hipFree of
 // hundreds of MiB cost more than the kernels that fill them.  Exact-size free lists, bounded total.
@@ -353,7 +356,9 @@ std::multimap<size_t, void*> g_pool;
 size_t g_pool_bytes = 0;
 constexpr size_t POOL_CAP = 8ull << 30;
 
+void reap_pending(bool block);
 hipError_t pool_alloc(void** p, size_t bytes) {
+    reap_pending(false);
     auto it = g_pool.find(bytes);
     if (it != g_pool.end()) {
         *p = it->second;
@@ -362,7 +367,19 @@ hipError_t pool_alloc(void** p, size_t bytes) {
         return hipSuccess;
     }
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && !g_pool.empty()) {          // out of memory: drop the cache and retry
+    if (e != hipSuccess) {                             // out of memory: first what is parked behind events
+        (void)hipGetLastError();
+        reap_pending(true);
+        auto it2 = g_pool.find(bytes);
+        if (it2 != g_pool.end()) {
+            *p = it2->second;
+            g_pool.erase(it2);
+            g_pool_bytes -= bytes;
+            return hipSuccess;
+        }
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess && !g_pool.empty()) {          // still out of memory: drop the cache and retry
         (void)hipDeviceSynchronize();
         for (auto& kv : g_pool) (void)hipFree(kv.second);
         g_pool.clear();
@@ -375,7 +392,7 @@ hipError_t pool_alloc(void** p, size_t bytes) {
 
 void pool_free(void* p, size_t bytes) {
     if (!p) return;
-    if (bytes >= (1u << 16) && g_pool_bytes + bytes <= POOL_CAP) {
+    if (g_pool_bytes + bytes <= POOL_CAP) {            // (small buffers too: hipFree waits for the whole device)
         g_pool.emplace(bytes, p);
         g_pool_bytes += bytes;
     } else {
@@ -387,6 +404,43 @@ void pool_clear() {
     for (auto& kv : g_pool) (void)hipFree(kv.second);
     g_pool.clear();
     g_pool_bytes = 0;
+}
+
+// Frees never wait.  A buffer handed back while a stream may still be using it (the *_dev entries take raw device pointers on
+// caller streams, so the library cannot know which) is parked with one event per stream in use -- recorded at the moment of the
+// free, i.e. behind everything enqueued so far -- and returns to the pool once those events have completed; that is checked
+// when the next buffer is allocated or freed (a query per event, no blocking).
+struct PendingFree {
+    void* p;
+    size_t bytes;
+    std::vector<hipEvent_t> evs;
+};
+std::deque<PendingFree> g_pending;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t event_get() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+}
+
+// block: wait for the events instead of asking (out of memory, shutdown)
+void reap_pending(bool block) {
+    for (size_t i = 0; i < g_pending.size();) {
+        PendingFree& f = g_pending[i];
+        bool done = true;
+        for (hipEvent_t e : f.evs) {
+            hipError_t q = block ? hipEventSynchronize(e) : hipEventQuery(e);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); done = false; break; }
+            if (q != hipSuccess) (void)hipGetLastError();          // a failed event cannot hold the buffer for ever
+        }
+        if (!done) { ++i; continue; }
+        for (hipEvent_t e : f.evs) g_event_pool.push_back(e);
+        pool_free(f.p, f.bytes);
+        g_pending[i] = std::move(g_pending.back());
+        g_pending.pop_back();
+    }
 }
 
 int fail(int code, const std::string& msg) {
@@ -446,27 +500,36 @@ inline hipStream_t pick_stream(void* s) {
     }
     return s ? (hipStream_t)s : g.stream;
 }
-// Before a buffer goes back to the pool nothing may still be using it.  Frees come in bursts when the streams are already
-// idle (a prover dropping its codewords and trees): ask each stream that has been used (a microsecond each) and wait only
-// for a busy one.  A stream that no longer answers (destroyed by its owner), or more streams than are tracked: wait for the
-// whole device.
-inline void sync_before_free() {
-    if (!g.foreign_streams) { (void)hipStreamSynchronize(g.stream); return; }
-    bool device_wide = g.seen_streams.size() > SEEN_STREAMS;
-    if (!device_wide) {
-        if (hipStreamQuery(g.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(g.stream); }
-        for (hipStream_t st : g.seen_streams) {
-            hipError_t e = hipStreamQuery(st);
-            if (e == hipSuccess) continue;
-            (void)hipGetLastError();
-            if (e == hipErrorNotReady && hipStreamSynchronize(st) == hipSuccess) continue;
-            (void)hipGetLastError();
-            device_wide = true;
-            g.seen_streams.clear();                   // stale handles: forget them, start over
-            break;
-        }
+// A buffer goes back to the pool when nothing can still be using it: an event is recorded on the library stream and on every
+// caller stream seen so far, and the buffer is parked until they have completed (reap_pending).  A stream that no longer takes
+// an event (destroyed by its owner: its work is done) is forgotten; more streams than are tracked: wait for the whole device.
+inline void release_after_streams(void* p, size_t bytes) {
+    if (!p) return;
+    if (g.seen_streams.size() > SEEN_STREAMS) {
+        (void)hipDeviceSynchronize();
+        g.seen_streams.clear();
+        pool_free(p, bytes);
+        return;
     }
-    if (device_wide) (void)hipDeviceSynchronize();
+    PendingFree f{p, bytes, {}};
+    auto mark = [&](hipStream_t st) -> bool {
+        if (hipStreamQuery(st) == hipSuccess) return true;          // idle: nothing of it can still touch the buffer
+        (void)hipGetLastError();
+        hipEvent_t e = event_get();
+        if (!e) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); return true; }
+        if (hipEventRecord(e, st) != hipSuccess) { (void)hipGetLastError(); g_event_pool.push_back(e); return false; }
+        f.evs.push_back(e);
+        return true;
+    };
+    if (g.stream) (void)mark(g.stream);
+    if (g_comm_stream_for_free) (void)mark(g_comm_stream_for_free);
+    for (size_t i = 0; i < g.seen_streams.size();) {
+        if (mark(g.seen_streams[i])) ++i;
+        else g.seen_streams.erase(g.seen_streams.begin() + i);      // stale handle
+    }
+    if (f.evs.empty()) { pool_free(p, bytes); return; }
+    g_pending.push_back(std::move(f));
+    reap_pending(false);
 }
 inline Fe fe_from(const uint64_t v[2]) { return Fe{v[0], v[1]}; }
 inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
@@ -1226,6 +1289,9 @@ int sc_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.init) return SC_OK;
     hipDeviceSynchronize();
+    reap_pending(true);
+    for (hipEvent_t e : g_event_pool) (void)hipEventDestroy(e);
+    g_event_pool.clear();
     free_plans();
     pool_clear();
     for (auto& b : g.scratch) { if (b.p) hipFree(b.p); b = DevBuf{}; }
@@ -1292,8 +1358,7 @@ int sc_vec_alloc(uint64_t n, sc_vec_t** out) {
 int sc_vec_free(sc_vec_t* v) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!v) return SC_OK;
-    sync_before_free();
-    pool_free(v->d, (v->n ? v->n : 1) * sizeof(Fe));
+    release_after_streams(v->d, (v->n ? v->n : 1) * sizeof(Fe));
     delete v;
     return SC_OK;
 }
@@ -1746,7 +1811,7 @@ int sc_comm_destroy(void) {
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : g_comm_events) (void)hipEventDestroy(e);
     g_comm_events.clear();
-    if (g_comm_stream) { (void)hipStreamDestroy(g_comm_stream); g_comm_stream = nullptr; }
+    if (g_comm_stream) { (void)hipStreamDestroy(g_comm_stream); g_comm_stream = nullptr; g_comm_stream_for_free = nullptr; }
     int r = rccl.CommDestroy(g_comm);
     g_comm = nullptr; g_comm_rank = -1; g_comm_world = 0;
     if (r != 0) return fail(SC_ERR_HIP, "ncclCommDestroy failed");
@@ -1789,7 +1854,7 @@ int sc_fourstep_run_dev(const sc_fourstep_t* plan, int inverse, const void* d_sr
         }
         return fourstep_rows(plan, dirn, recv, (Fe*)d_dst, 0, 1, false, st);
     }
-    if (!g_comm_stream) HIPCHK(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
+    if (!g_comm_stream) { HIPCHK(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking)); g_comm_stream_for_free = g_comm_stream; }
     while (g_comm_events.size() < 1 + K) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g_comm_events.push_back(e); }
     HIPCHK(hipEventRecord(g_comm_events[0], st));
     HIPCHK(hipStreamWaitEvent(g_comm_stream, g_comm_events[0], 0));
@@ -2088,6 +2153,114 @@ int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2]
     SCCHK(fold_device((const Fe*)d_in, N, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)d_out, st));
     return merkle_build_device((const Fe*)d_out, N / 2, nullptr, tree, st, BUILD_ASYNC);
 }
+// ---- the Fiat-Shamir step on the host side of the library (csrc/transcript.h); no GPU needed
+static Fe sample_field(const uint8_t* bytes, size_t len) {
+    // Field.sample (algebra.py:116-120): the big-endian integer of the bytes, mod p
+    Fe acc{0, 0};
+    const Fe k256{256, 0};
+    for (size_t i = 0; i < len; ++i) acc = fe_add(fe_mul(acc, k256), Fe{bytes[i], 0});
+    return acc;
+}
+int sc_shake256(const void* in, uint64_t len, void* out, uint64_t out_len) {
+    if ((!in && len) || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    shake256((const uint8_t*)in, (size_t)len, (uint8_t*)out, (size_t)out_len);
+    return SC_OK;
+}
+int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]) {
+    if ((!bytes && len) || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    const Fe v = sample_field((const uint8_t*)bytes, (size_t)len);
+    out[0] = v.lo; out[1] = v.hi;
+    return SC_OK;
+}
+// pickle.dumps of a list of `count` bytes objects (lens[i] < 256 bytes each, concatenated in `data`): the transcript prefix of
+// ip.py:18-19 for a proof stream that holds nothing but digests.  *out_len = bytes needed; copied when out_cap suffices.
+int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len) {
+    if ((!data && count) || (!lens && count) || !out_len) return fail(SC_ERR_BAD_ARG, "null argument");
+    std::vector<uint8_t> items, bytes;
+    const uint8_t* p = (const uint8_t*)data;
+    for (uint64_t i = 0; i < count; ++i) {
+        if (lens[i] > 255) return fail(SC_ERR_UNSUPPORTED, "transcript item too long for the fixed layout");
+        transcript_item(items, p, lens[i]);
+        p += lens[i];
+    }
+    if (!transcript_bytes(items, (size_t)count, bytes)) return fail(SC_ERR_UNSUPPORTED, "transcript too large for the fixed layout");
+    *out_len = bytes.size();
+    if (out && out_cap >= bytes.size()) memcpy(out, bytes.data(), bytes.size());
+    return SC_OK;
+}
+
+// Fri.commit's round loop (fri.py:66-94) in ONE call: per round the Merkle tree of the codeword (asynchronous build, the root
+// polled from its pinned slot), the Fiat-Shamir step on the host side of the library -- the transcript is the pickled list of
+// the `prior_count` digests already in the proof stream plus this call's roots; alpha = Field.sample(SHAKE-256(transcript)) --
+// and the fold of fri.py:85 with that alpha, enqueued the moment alpha exists.  Nothing crosses the language boundary between a
+// root arriving and the next launch.  omega and offset are squared from round to round (fri.py:86-87).
+// Out: trees_out[r] (rounds trees; [0] is over d_codeword), vecs_out[r] (rounds - 1 folded codewords, library-owned),
+// roots_out (64 * rounds bytes), alphas_out (2 u64 per fold).
+int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
+                      const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
+                      sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!d_codeword || !trees_out || !roots_out || (rounds > 1 && (!vecs_out || !alphas_out)) || rounds < 1) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (N < 2 || !is_pow2(N) || (N >> (rounds - 1)) < 1) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
+    if (prior_count + rounds > TRANSCRIPT_MAX_ITEMS) return fail(SC_ERR_UNSUPPORTED, "transcript too long for the fixed layout");
+    std::vector<uint8_t> items, bytes;
+    {
+        const uint8_t* p = (const uint8_t*)prior_data;
+        for (uint64_t i = 0; i < prior_count; ++i) {
+            if (prior_lens[i] > 255) return fail(SC_ERR_UNSUPPORTED, "transcript item too long for the fixed layout");
+            transcript_item(items, p, prior_lens[i]);
+            p += prior_lens[i];
+        }
+    }
+    if (items.size() + 67ull * rounds > TRANSCRIPT_MAX_BYTES) return fail(SC_ERR_UNSUPPORTED, "transcript too large for the fixed layout");
+    hipStream_t st = pick_stream(stream);
+    Fe off = fe_from(offset), om = fe_from(omega);
+    const Fe* cur = (const Fe*)d_codeword;
+    uint64_t n = N;
+    uint32_t made_trees = 0, made_vecs = 0;
+    auto undo = [&](int rc) {
+        (void)hipStreamSynchronize(st);
+        for (uint32_t i = 0; i < made_trees; ++i) { sc_merkle* t = trees_out[i]; if (t->slot >= 0) (void)merkle_root_wait(t, true); pool_free(t->d_levels, (2 * t->N - 1) * 64); delete t; trees_out[i] = nullptr; }
+        for (uint32_t i = 0; i < made_vecs; ++i) { pool_free(vecs_out[i]->d, (vecs_out[i]->n ? vecs_out[i]->n : 1) * sizeof(Fe)); delete vecs_out[i]; vecs_out[i] = nullptr; }
+        return rc;
+    };
+    int rc = merkle_build_device(cur, n, nullptr, &trees_out[0], st, BUILD_ASYNC);
+    if (rc != SC_OK) return rc;
+    made_trees = 1;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        // everything that does not need the root first: the next round's output vector
+        sc_vec* nxt = nullptr;
+        if (r + 1 < rounds) {
+            nxt = new sc_vec{nullptr, n / 2};
+            hipError_t e = pool_alloc((void**)&nxt->d, (n / 2 ? n / 2 : 1) * sizeof(Fe));
+            if (e != hipSuccess) { delete nxt; return undo(fail(SC_ERR_HIP, hipGetErrorString(e))); }
+            vecs_out[r] = nxt;
+            ++made_vecs;
+        }
+        rc = merkle_root_wait(trees_out[r]);
+        if (rc != SC_OK) return undo(rc);
+        memcpy(roots_out + 64 * r, trees_out[r]->root, 64);
+        if (r + 1 == rounds) break;
+        transcript_item(items, trees_out[r]->root, 64);
+        if (!transcript_bytes(items, (size_t)(prior_count + r + 1), bytes)) return undo(fail(SC_ERR_UNSUPPORTED, "transcript too large for the fixed layout"));
+        uint8_t digest[32];
+        shake256(bytes.data(), bytes.size(), digest, 32);
+        const Fe alpha = sample_field(digest, 32);
+        alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
+        rc = fold_device(cur, n, alpha, off, om, nxt->d, st);
+        if (rc != SC_OK) return undo(rc);
+        rc = merkle_build_device(nxt->d, n / 2, nullptr, &trees_out[r + 1], st, BUILD_ASYNC);
+        if (rc != SC_OK) return undo(rc);
+        ++made_trees;
+        cur = nxt->d;
+        n /= 2;
+        om = fe_mul(om, om);
+        off = fe_mul(off, off);
+    }
+    return SC_OK;
+}
+
 int sc_merkle_build(const void* elems, uint64_t N, uint8_t root_out[64], sc_merkle_t** tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
@@ -2260,8 +2433,7 @@ int sc_merkle_free(sc_merkle_t* tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree) return SC_OK;
     if (tree->slot >= 0) (void)merkle_root_wait(tree, true);  // a root still in flight: let it land, return the slot
-    sync_before_free();
-    pool_free(tree->d_levels, (2 * tree->N - 1) * 64);
+    release_after_streams(tree->d_levels, (2 * tree->N - 1) * 64);
     delete tree;
     return SC_OK;
 }
@@ -2309,10 +2481,9 @@ int sc_polytree_interpolate_dev(sc_polytree_t* tree, const void* d_values, void*
 int sc_polytree_free(sc_polytree_t* tree) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree) return SC_OK;
-    sync_before_free();
-    pool_free(tree->zc, tree->zc_bytes);
-    pool_free(tree->zf, tree->zf_bytes);
-    if (tree->invg_f) pool_free(tree->invg_f, 2 * tree->K * sizeof(Fe));
+    release_after_streams(tree->zc, tree->zc_bytes);
+    release_after_streams(tree->zf, tree->zf_bytes);
+    if (tree->invg_f) release_after_streams(tree->invg_f, 2 * tree->K * sizeof(Fe));
     delete tree;
     return SC_OK;
 }

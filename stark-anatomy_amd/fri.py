@@ -68,17 +68,55 @@ class Fri:
         return DeviceCodeword.from_list(codeword, self.field)
 
     def commit(self, codeword, proof_stream, round_index=0):
-        """fri.py:66-94.  The chain root -> alpha -> fold -> next root is strictly serial, so the loop keeps both sides busy:
-        a round's fold and tree are ENQUEUED in one library call (sc_fri_fold_commit_dev) and everything the host can do without
-        the root (the order check of the next omega, the next output vector) happens while the device hashes; only the
-        Fiat-Shamir step sits between a root arriving and the next launch."""
-        omega, offset = self.omega, self.offset
+        """fri.py:66-94.  The chain root -> alpha -> fold -> next root is strictly serial.  When the proof stream holds nothing but
+        digests so far (always the case for Fri.prove on its own and inside FastStark.prove) the whole round loop -- trees, the
+        Fiat-Shamir step of ip.py:18-25, folds -- is ONE library call (sc_fri_commit_dev): nothing crosses the language boundary
+        between a root arriving and the next launch.  Otherwise (_commit_rounds) a round's fold and tree are enqueued in one call
+        and only the Fiat-Shamir step sits between a root arriving and the next launch."""
         codeword = self._on_device(codeword)
-        codewords = []
         rounds = self.num_rounds()
+        # fri.py:68 asserts omega_r^(N_r - 1) == omega_r^-1, i.e. omega_r^(N_r) == 1, in every round; omega_r = omega^(2^r) and
+        # N_r = N / 2^r, so every round's condition is omega^N == 1: checked once, before anything is enqueued
+        assert(self.omega ^ (len(codeword) - 1) == self.omega.inverse()), "error in commit: omega does not have the right order!"
+        prior = proof_stream.objects
+        if (len(codeword) >= 2 and codeword._tree is None and len(prior) + rounds < 999 and all(type(o) is bytes and len(o) < 256 for o in prior)
+                and len(set(map(id, prior))) == len(prior) and sum(map(len, prior)) + 67 * rounds < 60000):
+            codewords = self._commit_in_library(codeword, proof_stream, rounds)
+        else:
+            codewords = self._commit_rounds(codeword, proof_stream, rounds)
+        # the last codeword goes out in the clear, as a plain list (it is pickled into the transcript)
+        proof_stream.push(codewords[-1].tolist())
+        return codewords
+
+    def _commit_in_library(self, codeword, proof_stream, rounds):
+        import ctypes
+        prior = proof_stream.objects
+        k = len(prior)
+        vecs = (ctypes.c_void_p * max(1, rounds - 1))()
+        trees = (ctypes.c_void_p * rounds)()
+        roots = ctypes.create_string_buffer(64 * rounds)
+        alphas = (ctypes.c_uint64 * max(2, 2 * (rounds - 1)))()
+        _sc._check(_sc.lib().sc_fri_commit_dev(codeword.vec.ptr, len(codeword), _sc.fe_bytes(self.offset.value), _sc.fe_bytes(self.omega.value), rounds,
+                                               b"".join(prior), (ctypes.c_uint32 * max(1, k))(*map(len, prior)), k, vecs, trees, roots, alphas, None))
+        codewords, cur, raw = [], codeword, roots.raw
+        for r in range(rounds):
+            n = len(codeword) >> r
+            if r > 0:
+                cur = DeviceCodeword(DeviceVector.adopt(vecs[r - 1], n), self.field)
+            root = raw[64 * r:64 * r + 64]
+            cur._tree = _sc.MerkleTree(ctypes.c_void_p(trees[r]), root, n)
+            proof_stream.push(root)
+            codewords.append(cur)
+        return codewords
+
+    def _commit_rounds(self, codeword, proof_stream, rounds):
+        """the same loop with the Fiat-Shamir step in Python (any proof stream): a round's fold and tree are ENQUEUED in one library
+        call (sc_fri_fold_commit_dev) and everything the host can do without the root (the next output vector) happens while the
+        device hashes"""
+        omega, offset = self.omega, self.offset
+        codewords = []
         for r in range(rounds):
             N = len(codeword)
-            assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
             if r == 0:
                 codeword.start_tree()
             folded = DeviceVector(N // 2) if r < rounds - 1 else None
@@ -91,8 +129,6 @@ class Fri:
             codeword = codeword.fold_commit(alpha, offset, omega, folded)
             omega = omega ^ 2
             offset = offset ^ 2
-        # the last codeword goes out in the clear, as a plain list (it is pickled into the transcript)
-        proof_stream.push(codeword.tolist())
         codewords.append(codeword)
         return codewords
 

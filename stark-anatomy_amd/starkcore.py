@@ -76,6 +76,10 @@ SIGNATURES = {
     "sc_merkle_build_noroot_dev": (_int, [_vp, _u64, ctypes.POINTER(_vp), _vp]),
     "sc_merkle_root": (_int, [_vp, _vp]),
     "sc_fri_fold_commit_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
+    "sc_fri_commit_dev": (_int, [_vp, _u64, _vp, _vp, ctypes.c_uint32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "sc_shake256": (_int, [_vp, _u64, _vp, _u64]),
+    "sc_field_sample": (_int, [_vp, _u64, _vp]),
+    "sc_transcript_bytes": (_int, [_vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_u64)]),
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
     "sc_merkle_open_batch": (_int, [_vp, _vp, _u64, _vp]),
     "sc_merkle_query_dev": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
@@ -191,11 +195,24 @@ def pack(values):
 
 
 def unpack(buf, count=None):
-    mv = bytes(buf)
+    """packed elements -> Python ints (one C-level pass over the limbs, then lo | hi << 64)"""
     if count is None:
-        count = len(mv) // 16
-    frm = int.from_bytes
-    return [frm(mv[16 * i:16 * i + 16], "little") for i in range(count)]
+        count = len(buf) // 16
+    limbs = _limb_struct(count).unpack_from(buf)
+    return [lo | (hi << 64) for lo, hi in zip(limbs[0::2], limbs[1::2])]
+
+
+_limb_structs = {}
+
+
+def _limb_struct(count):
+    import struct
+    st = _limb_structs.get(count)
+    if st is None:
+        if len(_limb_structs) > 64:
+            _limb_structs.clear()
+        st = _limb_structs[count] = struct.Struct("<%dQ" % (2 * count))
+    return st
 
 
 # ------------------------------------------------------------------------------------------------
@@ -207,6 +224,14 @@ class DeviceVector:
         h = _vp()
         _check(lib().sc_vec_alloc(self.n, ctypes.byref(h)))
         self._h = h
+
+    @classmethod
+    def adopt(cls, handle, n):
+        """owner of an sc_vec_t the library handed out (sc_fri_commit_dev's folded codewords)"""
+        v = cls.__new__(cls)
+        v.n = int(n)
+        v._h = _vp(handle) if not isinstance(handle, _vp) else handle
+        return v
 
     @classmethod
     def from_bytes(cls, data):
@@ -456,6 +481,19 @@ class MerkleTree:
             pass
 
 
+_FieldElement = None
+
+
+def _field_element():
+    """algebra.FieldElement, imported on first use (algebra does not depend on this module, but importing it at load time would
+    make every C-ABI-only user pay for it)"""
+    global _FieldElement
+    if _FieldElement is None:
+        from algebra import FieldElement
+        _FieldElement = FieldElement
+    return _FieldElement
+
+
 class DeviceCodeword(Sequence):
     """A list-like view of a device-resident codeword.
 
@@ -488,8 +526,7 @@ class DeviceCodeword(Sequence):
         return self.vec.n
 
     def _fe(self, v):
-        from algebra import FieldElement
-        return FieldElement(v, self.field)
+        return _field_element()(v, self.field)
 
     def tolist(self):
         if self._full is None:
@@ -570,9 +607,8 @@ class DeviceCodeword(Sequence):
         """FieldElement objects for freshly fetched residues, created once per index (see __init__)"""
         if self._full is not None:
             return [self._full[i] for i in indices]
-        out, known = [], self._elems
+        known, fe, field = self._elems, _field_element(), self.field
         for i, v in zip(indices, values):
             if i not in known:
-                known[i] = self._fe(v)
-            out.append(known[i])
-        return out
+                known[i] = fe(v, field)
+        return [known[i] for i in indices]

@@ -242,6 +242,53 @@ def test_fri_prove_synthetic_goldens():
             assert fr.prove(cw.tolist(), ps2) == top and ps2.serialize() == ser
 
 
+def test_fri_commit_in_library_and_in_python_agree(monkeypatch):
+    """Fri.commit has two forms of its round loop: sc_fri_commit_dev (trees, Fiat-Shamir step and folds in one library call, taken
+    when the proof stream holds only digests) and the per-round loop with the Fiat-Shamir step in Python.  Both must produce the
+    reference's proof: the same golden hash, byte-identical streams also after digests pushed beforehand (FastStark pushes its
+    commitments before FRI), and a stream that holds something else takes the Python loop and still verifies."""
+    import starkcore as sc
+    calls = []
+    real = Fri._commit_in_library
+    monkeypatch.setattr(Fri, "_commit_in_library", lambda self, *a: (calls.append(1), real(self, *a))[1])
+    rec = [r for r in load_golden("fri.json")["prove_synth"] if r["logN"] == 12][0]
+    N = 1 << rec["logN"]
+    om = field.primitive_nth_root(N)
+    poly = Polynomial([FieldElement(v, field) for v in synth.synth_ints(rec["coeff_seed"], N // 4)])
+    fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+
+    def prove(prior, force_python=False):
+        cw = fast_coset_evaluate_device(poly, field.generator(), om, N)
+        ps = ProofStream()
+        for o in prior:
+            ps.push(o)
+        if force_python:
+            with monkeypatch.context() as m:
+                m.setattr(Fri, "_commit_in_library", lambda self, codeword, proof_stream, rounds: self._commit_rounds(codeword, proof_stream, rounds))
+                top = fr.prove(cw, ps)
+        else:
+            top = fr.prove(cw, ps)
+        return top, ps
+    top, ps = prove([])
+    assert calls and top == rec["top_level_indices"] and hashlib.sha256(ps.serialize()).hexdigest() == rec["serialized_sha256"]
+    top2, ps2 = prove([], force_python=True)
+    assert top2 == top and ps2.serialize() == ps.serialize()
+    prior = [bytes([i]) * 64 for i in range(3)] + [b"short", b""]
+    n_calls = len(calls)
+    top3, ps3 = prove(prior)
+    top4, ps4 = prove(prior, force_python=True)
+    assert len(calls) == n_calls + 1 and top3 == top4 and ps3.serialize() == ps4.serialize() and top3 != top
+    # the same object twice is a pickle memo hit, a list is not a digest: neither has the fixed layout -> the Python loop
+    same = b"r" * 64
+    for odd in ([same, same], [[1, 2, 3]], [b"x" * 300]):
+        n_calls = len(calls)
+        top5, ps5 = prove(odd)
+        assert len(calls) == n_calls
+        for _ in odd:
+            ps5.pull()
+        assert fr.verify(ps5, []) is True
+
+
 def test_merkle_through_host_api():
     g = load_golden("merkle.json")
     for rec in g["commit"]:

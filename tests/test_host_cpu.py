@@ -225,3 +225,69 @@ def test_mpolynomial_evaluate_against_term_by_term():
                 want = (want + t) % field.p
             assert mp.evaluate(point).value == want
             mp.dictionary[tuple(rng.randrange(0, 4) for _ in range(nvars))] = fe(rng.randrange(field.p))   # mutate, evaluate again
+
+
+def test_library_fiat_shamir_step_matches_pickle_and_hashlib():
+    """Fri.commit's hand-over (ip.py:18-25, algebra.py:116-120) runs inside the library (sc_fri_commit_dev); its
+    host-side pieces need no GPU and are pinned here: SHAKE-256 against hashlib, Field.sample against the shift-xor loop, and
+    the transcript bytes against pickle.dumps / ProofStream.serialize() for lists of digests -- 0, 1, 2, ... items (the layout
+    changes between them), mixed lengths, and the golden transcript challenges captured from the reference."""
+    import ctypes
+    import random
+    from hashlib import shake_256
+    import starkcore
+    lib = starkcore.lib()
+    rng = random.Random(11)
+    for length in (0, 1, 135, 136, 137, 272, 1000, 70000):
+        data = bytes(rng.randrange(256) for _ in range(length))
+        for outlen in (32, 1, 136, 200, 300):
+            out = ctypes.create_string_buffer(outlen)
+            assert lib.sc_shake256(data, length, out, outlen) == 0
+            assert out.raw == shake_256(data).digest(outlen), (length, outlen)
+    for length in (0, 1, 16, 17, 32, 64):
+        for _ in range(20):
+            data = bytes(rng.randrange(256) for _ in range(length))
+            got = (ctypes.c_uint64 * 2)()
+            assert lib.sc_field_sample(data, length, got) == 0
+            assert got[0] | (got[1] << 64) == field.sample(data).value
+    all_ones = bytes([255]) * 32
+    got = (ctypes.c_uint64 * 2)()
+    lib.sc_field_sample(all_ones, 32, got)
+    assert got[0] | (got[1] << 64) == int.from_bytes(all_ones, "big") % field.p
+
+    def c_transcript(items):
+        lens = (ctypes.c_uint32 * max(1, len(items)))(*[len(i) for i in items])
+        need = ctypes.c_uint64(0)
+        assert lib.sc_transcript_bytes(b"".join(items), lens, len(items), None, 0, ctypes.byref(need)) == 0
+        buf = ctypes.create_string_buffer(need.value)
+        assert lib.sc_transcript_bytes(b"".join(items), lens, len(items), buf, need.value, ctypes.byref(need)) == 0
+        return buf.raw
+    for count in (0, 1, 2, 3, 15, 40, 300):
+        items = [bytes(rng.randrange(256) for _ in range(64)) for _ in range(count)]
+        ps = ProofStream()
+        for it in items:
+            ps.push(it)
+        assert c_transcript(items) == ps.serialize() == pickle.dumps(items), count
+    mixed = [b"", b"a", bytes(range(255)), b"x" * 64]
+    assert c_transcript(mixed) == pickle.dumps(mixed)
+    lens = (ctypes.c_uint32 * 1)(256)
+    need = ctypes.c_uint64(0)
+    assert lib.sc_transcript_bytes(b"z" * 256, lens, 1, None, 0, ctypes.byref(need)) == -7      # BINBYTES, not SHORT_BINBYTES: not this layout
+    # the transcripts of the reference's own Fri.prove runs (tests/golden/fri.json: the roots the reference pushed, round by
+    # round): challenge and alpha from the library == from ProofStream / Field.sample
+    checked = 0
+    for rec in load_golden("fri.json")["prove_synth"]:
+        roots = [bytes.fromhex(h) for h in rec["roots"]]
+        ps = ProofStream()
+        for r, root in enumerate(roots):
+            ps.push(root)
+            raw = c_transcript(roots[:r + 1])
+            assert raw == ps.serialize()
+            out = ctypes.create_string_buffer(32)
+            lib.sc_shake256(raw, len(raw), out, 32)
+            assert out.raw == ps.prover_fiat_shamir()
+            got = (ctypes.c_uint64 * 2)()
+            lib.sc_field_sample(out.raw, 32, got)
+            assert got[0] | (got[1] << 64) == field.sample(ps.prover_fiat_shamir()).value
+            checked += 1
+    assert checked >= 10
