@@ -185,8 +185,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 2000 (10 for a functional run whose ranks share GPUs)")
     ap.add_argument("--warmup", type=int, default=None, help="default 200 (2 for a functional run whose ranks share GPUs)")
-    ap.add_argument("--workload", choices=("ntt", "stark_census"), default="ntt",
-                    help="ntt (headline, BASELINE configs[1]; N > 1: the sharded four-step transform) or stark_census (BASELINE configs[4] on the sharded layout)")
+    ap.add_argument("--workload", choices=("ntt", "stark_census", "stark_prove"), default="ntt",
+                    help="ntt (headline, BASELINE configs[1]; N > 1: the sharded four-step transform), stark_census (the polynomial-core call census of "
+                         "BASELINE configs[4] on the sharded layout) or stark_prove (sharded_stark.ShardedFastStark.prove on a synthetic AIR: configs[4] as a prover)")
     ap.add_argument("--log2n", type=int, default=None, help="override the transform size (ntt) / the FRI domain (stark_census)")
     ap.add_argument("--cpu-sample-log2n", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -226,7 +227,7 @@ def main():
     sc.init(dev_index)
     lib = sc.lib()
 
-    sharded = world > 1 or args.force_sharded or args.workload == "stark_census"
+    sharded = world > 1 or args.force_sharded or args.workload in ("stark_census", "stark_prove")
 
     # a dedicated (non-null) HIP stream: the library launches on it and the timing events are recorded on it
     stream = torch.cuda.Stream(device=dev)
@@ -270,6 +271,8 @@ def main():
 
     if sharded and args.workload == "stark_census":
         return run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gpus)
+    if sharded and args.workload == "stark_prove":
+        return run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shared_gpus)
 
     if not sharded:
         log2n = args.log2n or (20 if world == 1 else 21)
@@ -553,6 +556,74 @@ def run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gp
                "stages_best_run": rec}
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()
+
+
+def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shared_gpus):
+    """--workload stark_prove: one step = sharded_stark.ShardedFastStark.prove (reference code/fast_stark.py:76-178) from the
+    trace to the serialized proof, on the synthetic 2-register AIR (a, b) -> (b, a*a + b) with a 2^k-row randomized trace
+    (FRI domain 2^(k+4)); value = ms per proof (max over ranks).  Every rank must end with the same proof; rank 0 verifies it
+    with FastStark.verify outside the timed region."""
+    import hashlib
+    import torch
+    from algebra import Field, FieldElement
+    from multivariate import MPolynomial
+    from sharded_stark import ShardedFastStark
+    ngpu = torch.cuda.device_count()
+    log_fri = args.log2n or (16 if shared_gpus else 20)
+    k, s = log_fri - 4, 40
+    field = Field.main()
+    T = (1 << k) - 4 * s
+    a, b, rows = 3, 5, []
+    for _ in range(T):
+        rows.append((a, b))
+        a, b = b, (a * a + b) % field.p
+    trace = [[FieldElement(x, field), FieldElement(y, field)] for x, y in rows]
+    v = MPolynomial.variables(5, field)                  # X, a, b, a', b'
+    air = [v[3] - v[2], v[4] - v[1] * v[1] - v[2]]
+    boundary = [(0, 0, trace[0][0]), (0, 1, trace[0][1]), (T - 1, 1, trace[T - 1][1])]
+    stark = ShardedFastStark(field, 4, s, 2 * s, 2, T, rank, world, dev)
+    assert stark.fri_domain_length == 1 << log_fri
+    t0 = time.perf_counter()
+    tz, layer, root = stark.preprocess()
+    torch.cuda.synchronize()
+    preprocess_s = time.perf_counter() - t0
+    steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 1))
+    for _ in range(warmup):
+        stark.prove(trace, air, boundary, tz, layer)
+    dist.barrier()
+    torch.cuda.synchronize()
+    totals, proof = [], None
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        proof = stark.prove(trace, air, boundary, tz, layer)
+        torch.cuda.synchronize()
+        totals.append(time.perf_counter() - t0)
+    dist.barrier()
+    t = torch.tensor(totals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)              # per step: the slowest rank
+    elapsed = float(t.sum().item())
+    digest = hashlib.sha256(proof).digest()
+    mine = torch.tensor(list(digest[:8]), dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same_everywhere = bool(torch.equal(lo, hi))
+    if rank == 0:
+        t0 = time.perf_counter()
+        verifies = bool(stark.verify(proof, air, boundary, root))
+        verify_s = time.perf_counter() - t0
+        out = {"metric": "stark_prove_ms", "value": 1e3 * elapsed / steps, "unit": "ms", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "u128", "data": "synthetic",
+               "config": {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_%dgpu" % (k, log_fri, world), "log2n": log_fri, "world_size": world,
+                          "registers": 2, "colinearity_checks": s, "expansion_factor": 4,
+                          "collective_backend": collective_label(backend, world, ngpu, shared_gpus),
+                          "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace-domain polynomials replicated",
+                          "proof_bytes": len(proof), "proof_sha256_16": digest.hex()[:16], "same_proof_on_every_rank": same_everywhere,
+                          "verify_accepts": verifies, "verify_s": verify_s, "preprocess_s": preprocess_s, "runs_ms": [round(x * 1e3, 3) for x in t.tolist()]}}
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+    if not same_everywhere:
+        sys.exit("ranks disagree on the proof")
 
 
 def extras(sc, lib, stream=None):

@@ -78,6 +78,8 @@ int sc_vec_zero(sc_vec_t* v);                                   /* all elements 
 int sc_vec_upload(sc_vec_t* v, uint64_t offset, const void* host, uint64_t count);
 int sc_vec_download(const sc_vec_t* v, uint64_t offset, void* host, uint64_t count);
 int sc_vec_gather(const sc_vec_t* v, const uint64_t* indices, uint64_t k, void* host_out); /* host_out[i] = v[indices[i]] */
+/* `count` elements device to device, asynchronous on `stream` (a library vector <-> caller-owned device memory, e.g. a torch tensor) */
+int sc_memcpy_dev(void* d_dst, const void* d_src, uint64_t count, void* stream);
 
 /* ---- ntt / intt : code/ntt.py:3-18, :20-30 -------------------------------------------------- */
 /* out[i] = sum_j in[j] * root^(i*j); inverse != 0: uses root^-1 and scales by n^-1 (ntt.py:27-30).

@@ -1385,6 +1385,13 @@ int sc_vec_download(const sc_vec_t* v, uint64_t offset, void* host, uint64_t cou
     if (!v || offset + count > v->n) return fail(SC_ERR_BAD_ARG, "download out of range");
     return download(host, v->d + offset, count * sizeof(Fe), g.stream);
 }
+int sc_memcpy_dev(void* d_dst, const void* d_src, uint64_t count, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (count && (!d_dst || !d_src)) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (count) HIPCHK(hipMemcpyAsync(d_dst, d_src, count * sizeof(Fe), hipMemcpyDeviceToDevice, pick_stream(stream)));
+    return SC_OK;
+}
 int sc_vec_gather(const sc_vec_t* v, const uint64_t* indices, uint64_t k, void* host_out) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());

@@ -195,6 +195,9 @@ class FastStark:
     def _combine_on_device(self, shifted, weights, max_degree):
         """sum_i weights[i] * terms[i] (fast_stark.py:130-145) as axpys over coefficient vectors in HBM, then the LDE straight from
         the accumulator: `Polynomial([w]) * t` scales t, `(x ^ k) * t` shifts it by k places.  The combination never visits the host."""
+        return self._combination_on_device(shifted, weights, max_degree).coset_evaluate(self.generator, self.omega, self.fri_domain_length)
+
+    def _combination_on_device(self, shifted, weights, max_degree):
         width = max(max_degree + 1, max(len(p) + (k or 0) for p, k in shifted))
         acc = DeviceVector.zeros(width)
         w = iter(weights)
@@ -203,7 +206,7 @@ class FastStark:
                 weight = next(w)
                 if len(poly):
                     acc.axpy_shift(_View(poly.vec, len(poly)), k, weight.value)
-        return DevicePolynomial(acc, self.field, width).coset_evaluate(self.generator, self.omega, self.fri_domain_length)
+        return DevicePolynomial(acc, self.field, width)
 
     def _open_all(self, codeword, indices, proof_stream):
         """leaf, path, leaf, path, ... for one codeword -- one resident tree, one batched gather of all paths."""

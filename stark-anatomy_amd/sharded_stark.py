@@ -1,0 +1,206 @@
+"""FastStark.prove with its FRI-domain work sharded over the GPUs of one node (BASELINE configs[4]).
+
+Interface and transcript of reference code/fast_stark.py:76-178 (`FastStark.prove`), one process per GPU.  What is sharded is
+what is big -- everything that lives on the FRI domain (expansion_factor x the trace domain):
+
+  * every low-degree extension (fast_stark.py:103-104, :119, :148) is `ShardedNtt.coset_evaluate`: the coefficient vector (1/blowup
+    of the domain) is replicated, each rank transforms its column slab, ONE corner turn per LDE;
+  * every Merkle commitment (fast_stark.py:105, :120) is `ShardedFri.commit`: local subtrees + one all-gather of sub-roots;
+  * the transition and boundary quotients (fast_stark.py:93-98, :113) are `ShardedNtt.coset_divide` on the trace domain's
+    coset (pointwise division on slabs, no exchange beyond the transforms' corner turns); the quotient's coefficients are
+    all-gathered once, because the next steps need them replicated;
+  * the low-degree test is `ShardedFri.prove` (slab-local folds, no element exchange), and the openings of the committed
+    codewords (fast_stark.py:154-175) are answered by the owning ranks and merged with one collective per codeword.
+
+What is small stays replicated on every rank and runs exactly as in fast_stark.FastStark (same code): the trace interpolation
+over the subproduct tree, the AIR substitution in the value domain, the degree bookkeeping and the weighted sum of the
+nonlinear combination -- polynomials of the trace domain's size.  Byte parity ties the rest to the host: the os.urandom draws
+(rank 0 draws, in the reference's order, and broadcasts the bytes), Fiat-Shamir, the proof stream.  Every rank ends with the
+same proof, byte-identical to `FastStark.prove` on one GPU with the same random bytes (tests/test_gpu_sharded.py).
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+import fast_stark as _fs
+from fast_stark import *                      # noqa: F401,F403  (FastStark and the reference's star-imported names)
+from ntt import DevicePolynomial, DeviceDomain, _shrink_order, coset_divide_device, fast_interpolate_device
+from sharded import ShardedNtt, ShardedFri
+import starkcore as _sc
+
+
+class ShardedFastStark(FastStark):
+    # divisions whose transform is shorter than this stay on one GPU (replicated): nothing to win from an exchange of a few KiB
+    MIN_SHARDED_LOG2 = 10
+
+    def __init__(self, field, expansion_factor, num_colinearity_checks, security_level, num_registers, num_cycles, rank, world, device, group=None,
+                 transition_constraints_degree=2):
+        super().__init__(field, expansion_factor, num_colinearity_checks, security_level, num_registers, num_cycles, transition_constraints_degree)
+        assert field.p == Field.P_MAIN, "the sharded prover works in the main field"
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self._ntts = {}
+        self.ntt_fri = self._ntt(self.fri_domain_length, self.omega.value)
+        self.sfri = ShardedFri(self.fri, self.ntt_fri.n1, rank, world, device, group=group)
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _ntt(self, order, root):
+        key = (order, int(root))
+        if key not in self._ntts:
+            self._ntts[key] = ShardedNtt(order.bit_length() - 1, int(root), self.rank, self.world, self.device, group=self.group)
+        return self._ntts[key]
+
+    def _stream_ptr(self):
+        cur = torch.cuda.current_stream(self.device)
+        return None if cur.cuda_stream == 0 else ctypes.c_void_p(cur.cuda_stream)
+
+    def _join(self):
+        """the replicated steps run on the library's stream, the sharded ones on torch's: meet before switching sides"""
+        _sc.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def _tensor(self, poly, length=None):
+        """coefficients of a DevicePolynomial as a torch tensor [length][2] (a copy: torch owns what the collectives touch)"""
+        length = len(poly) if length is None else length
+        t = torch.empty((max(length, 1), 2), dtype=torch.int64, device=self.device)
+        if length:
+            self._join()
+            _sc._check(_sc.lib().sc_memcpy_dev(t.data_ptr(), poly.vec.ptr, length, None))
+            _sc.synchronize()
+        return t[:length]
+
+    def _polynomial(self, tensor, length):
+        """the first `length` rows of a [..][2] tensor as a DevicePolynomial"""
+        vec = _sc.DeviceVector(max(length, 1))
+        if length:
+            self._join()
+            _sc._check(_sc.lib().sc_memcpy_dev(vec.ptr, tensor.contiguous().data_ptr(), length, None))
+            _sc.synchronize()
+        return DevicePolynomial(vec, self.field, length)
+
+    def _gather_natural(self, slab, rows, cols):
+        """column slabs [rows][cols/G] of every rank -> the whole natural-order vector [rows*cols][2], on every rank"""
+        parts = self.sfri._all_gather(slab)                           # [G][rows][cols/G][2]
+        return parts.permute(1, 0, 2, 3).reshape(rows * cols, 2).contiguous()
+
+    def _shared_random_bytes(self, count):
+        """`count` draws of os.urandom(17) in the reference's order (fast_stark.py:80, :117), made by rank 0 and broadcast: every
+        rank must randomise the same trace"""
+        raw = b"".join(_fs.os.urandom(17) for _ in range(count)) if self.rank == 0 else bytes(17 * count)
+        if self.world > 1:
+            on_dev = dist.get_backend(self.group) == "nccl"
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            t = t.to(self.device) if on_dev else t
+            dist.broadcast(t, 0, group=self.group)
+            raw = bytes(t.cpu().numpy())
+        return [raw[17 * i:17 * i + 17] for i in range(count)]
+
+    # -- sharded building blocks ---------------------------------------------------------------------
+    def _lde_commit(self, poly):
+        """fast_coset_evaluate onto the FRI coset (fast_stark.py:58-59) + Merkle.commit, both sharded: the layer record ShardedFri
+        answers openings from; layer["root"] is the commitment"""
+        slab = torch.empty(self.ntt_fri.local_shape(False), dtype=torch.int64, device=self.device)
+        self.ntt_fri.coset_evaluate(self._tensor(poly), self.generator.value, slab)
+        return self.sfri.commit(slab, self.ntt_fri.n2)
+
+    def _coset_divide(self, lhs, rhs, exact=False):
+        """fast_coset_divide (code/ntt.py:137-176) with the transforms and the pointwise division sharded; the quotient's
+        coefficients replicated again.  Transform order chosen like ntt.py:155-157, so the result is the reference's also when
+        the division is not exact.  exact=True: Polynomial.__truediv__'s zero-remainder assertion (univariate.py:99-103)."""
+        assert(not rhs.is_zero()), "cannot divide by zero polynomial"
+        if lhs.is_zero():
+            return DevicePolynomial(_sc.DeviceVector(1), self.field, 0)
+        dl, dr = lhs.degree(), rhs.degree()
+        assert(dr <= dl), "cannot divide by polynomial of larger degree"
+        root, order = _shrink_order(self.omicron, self.omicron_domain_length, max(dl, dr))
+        log2 = order.bit_length() - 1
+        if log2 < ShardedFastStark.MIN_SHARDED_LOG2 or (1 << (log2 // 2)) < self.world:
+            return coset_divide_device(lhs, rhs, self.generator, self.omicron, self.omicron_domain_length, exact=exact)
+        ntt = self._ntt(order, root.value)
+        num = ntt.slab_of(self._tensor(lhs, dl + 1), "div_num").clone()
+        den = ntt.slab_of(self._tensor(rhs, dr + 1), "div_den").clone()
+        q = torch.empty(ntt.local_shape(True), dtype=torch.int64, device=self.device)
+        ntt.coset_divide(num, den, self.generator.value, q)
+        full = self._gather_natural(q, ntt.n1, ntt.n2)
+        n_out = dl - dr + 1
+        if exact:
+            tail = self._polynomial(full[n_out:], order - n_out)
+            assert(tail.degree() == -1), "cannot perform polynomial division because remainder is not zero"
+        return self._polynomial(full, n_out)
+
+    # -- preprocessing (fast_stark.py:36-40) -----------------------------------------------------------
+    def preprocess(self):
+        """-> (transition_zerofier, its committed codeword as a sharded layer record, the root)"""
+        transition_zerofier = fast_zerofier(self.omicron_domain[:(self.original_trace_length - 1)], self.omicron, len(self.omicron_domain))
+        layer = self._lde_commit(DevicePolynomial.from_polynomial(transition_zerofier, self.field))
+        return transition_zerofier, layer, layer["root"]
+
+    # -- prover (fast_stark.py:76-178) -------------------------------------------------------------------
+    def prove(self, trace, transition_constraints, boundary, transition_zerofier, transition_zerofier_layer, proof_stream=None):
+        if proof_stream == None:
+            proof_stream = ProofStream()
+        field, registers = self.field, range(self.num_registers)
+
+        # randomizer rows appended to the trace (draw order: row by row, register by register)
+        draws = iter(self._shared_random_bytes(self.num_randomizers * self.num_registers))
+        for _ in range(self.num_randomizers):
+            trace = trace + [[field.sample(next(draws)) for s in registers]]
+
+        interpolants = self.boundary_interpolants(boundary)
+        zerofiers = self.boundary_zerofiers(boundary)
+        # replicated: the trace polynomials through {omicron^i} over the subproduct tree (fast_stark.py:84-87)
+        dom, acc = [], 1
+        for _ in range(len(trace)):
+            dom.append(acc)
+            acc = acc * self.omicron.value % field.p
+        trace_domain = DeviceDomain(DeviceVector.from_ints(dom), field)
+        trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, DeviceCodeword.from_list([row[s] for row in trace], field)))
+                             for s in registers]
+        # sharded: boundary quotients, their LDEs and commitments (fast_stark.py:89-105)
+        zerofiers_dev = [DevicePolynomial.from_polynomial(z, field) for z in zerofiers]
+        boundary_quotients = [self._coset_divide(trace_polynomials[s].minus(interpolants[s]), zerofiers_dev[s], exact=True) for s in registers]
+        boundary_layers = []
+        for s in registers:
+            boundary_layers.append(self._lde_commit(boundary_quotients[s]))
+            proof_stream.push(boundary_layers[s]["root"])
+
+        # replicated: the AIR substituted in (X, trace(X), trace(omicron X)) in the value domain; sharded: the quotients
+        x = Polynomial([field.zero(), field.one()])
+        point = [DevicePolynomial.from_polynomial(x, field)] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
+        transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
+        tz_dev = DevicePolynomial.from_polynomial(transition_zerofier, field)
+        transition_quotients = [self._coset_divide(tp, tz_dev) for tp in transition_polynomials]
+
+        # randomizer polynomial (rank 0's draws), its sharded LDE and commitment
+        max_degree = self.max_degree(transition_constraints)
+        randomizer_polynomial = DevicePolynomial.from_polynomial(Polynomial([field.sample(b) for b in self._shared_random_bytes(max_degree + 1)]), field)
+        randomizer_layer = self._lde_commit(randomizer_polynomial)
+        proof_stream.push(randomizer_layer["root"])
+
+        weights = self.sample_weights(1 + 2 * len(transition_quotients) + 2 * len(boundary_quotients), proof_stream.prover_fiat_shamir())
+        tq_bounds = self.transition_quotient_degree_bounds(transition_constraints)
+        assert([tq.degree() for tq in transition_quotients] == tq_bounds), "transition quotient degrees do not match with expectation"
+
+        # nonlinear combination (replicated axpys over coefficient vectors), its sharded LDE, the sharded low-degree test
+        bq_bounds = self.boundary_quotient_degree_bounds(len(trace), boundary)
+        shifted = [(randomizer_polynomial, None)]
+        for i, tq in enumerate(transition_quotients):
+            shifted.append((tq, max_degree - tq_bounds[i]))
+        for i in registers:
+            shifted.append((boundary_quotients[i], max_degree - bq_bounds[i]))
+        combination = self._combination_on_device(shifted, weights, max_degree)
+        slab = torch.empty(self.ntt_fri.local_shape(False), dtype=torch.int64, device=self.device)
+        self.ntt_fri.coset_evaluate(self._tensor(combination), self.generator.value, slab)
+        indices = self.sfri.prove(slab, proof_stream)
+
+        # open the queried positions (and their expansion_factor / half-domain companions) on every committed codeword
+        N = self.fri.domain_length
+        duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
+        quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
+        quadrupled_indices.sort()
+        for layer in boundary_layers + [randomizer_layer, transition_zerofier_layer]:
+            entries, paths = self.sfri._open(layer, quadrupled_indices)
+            for entry, path in zip(entries, paths):
+                proof_stream.push(entry)
+                proof_stream.push(path)
+        return proof_stream.serialize()

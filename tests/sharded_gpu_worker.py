@@ -66,6 +66,7 @@ def main():
                 print("rank", rank, "POLY MISMATCH at log2n", log2n, flush=True)
                 break
     ok &= fri_check(rank, world, dev)
+    ok &= stark_check(rank, world, dev)
     dist.barrier()
     dist.destroy_process_group()
     if not ok:
@@ -100,6 +101,47 @@ def poly_check(eng, rank, world, n, dev):
     except AssertionError as e:
         ok = ok and "divide by zero" in str(e)
     return bool(ok)
+
+
+def stark_check(rank, world, dev):
+    """BASELINE configs[4] as a real prover: sharded_stark.ShardedFastStark (sharded LDEs, commitments, quotients, FRI and openings;
+    rank 0's random bytes broadcast) on a synthetic 2-register AIR must produce, on every rank, the byte string that
+    fast_stark.FastStark.prove produces on one GPU from the same random bytes (reference code/fast_stark.py:76-178)."""
+    import random
+    import fast_stark
+    from fast_stark import FastStark
+    from sharded_stark import ShardedFastStark
+    from algebra import Field, FieldElement
+    from multivariate import MPolynomial
+    field = Field.main()
+    ok = True
+    for k, s in ((10, 8), (12, 40)):
+        T = (1 << k) - 4 * s
+        a, b, rows = 3, 5, []
+        for _ in range(T):
+            rows.append((a, b))
+            a, b = b, (a * a + b) % field.p
+        trace = [[FieldElement(x, field), FieldElement(y, field)] for x, y in rows]
+        v = MPolynomial.variables(5, field)                  # X, a, b, a', b'
+        air = [v[3] - v[2], v[4] - v[1] * v[1] - v[2]]
+        boundary = [(0, 0, trace[0][0]), (0, 1, trace[0][1]), (T - 1, 1, trace[T - 1][1])]
+
+        def seeded():
+            rng = random.Random(1000 + k)
+            fast_stark.os.urandom = lambda n: bytes(rng.getrandbits(8) for _ in range(n))
+        seeded()
+        one = FastStark(field, 4, s, 2 * s, 2, T)
+        tz, tzc, tzr = one.preprocess()
+        want = one.prove(trace, air, boundary, tz, tzc)
+        seeded()
+        many = ShardedFastStark(field, 4, s, 2 * s, 2, T, rank, world, dev)
+        tz2, layer, root = many.preprocess()
+        got = many.prove(trace, air, boundary, tz2, layer)
+        good = root == tzr and got == want and one.verify(got, air, boundary, tzr) is True
+        if not good:
+            print("rank", rank, "STARK MISMATCH k", k, root == tzr, len(got), len(want), flush=True)
+        ok &= good
+    return ok
 
 
 def fri_check(rank, world, dev):

@@ -10,6 +10,10 @@ import torch
 from oracle import py_oracle as po
 import synth
 
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -190,6 +194,26 @@ def test_ranks_share_one_gpu(world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == world
+
+
+def test_sharded_fast_stark_one_rank(sc):
+    """sharded_stark.ShardedFastStark at world 1 (no process group): the same proof bytes as fast_stark.FastStark.prove from the
+    same random bytes (worlds of 2 and 4 ranks: test_ranks_share_one_gpu)."""
+    import sharded_gpu_worker
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        assert sharded_gpu_worker.stark_check(0, 1, dev)
+
+
+def test_bench_stark_prove_workload(sc):
+    """`bench.py --workload stark_prove`: BASELINE configs[4] as a prover, on one rank and on two ranks sharing the GPU -- the same
+    proof (randomness is rank 0's; the proofs differ between RUNS, so only the verdicts are compared), accepted by the verifier"""
+    for n in (1, 2):
+        out = _run_bench(["--gpus", str(n), "--workload", "stark_prove", "--log2n", "14", "--steps", "1", "--warmup", "1"])
+        assert out["metric"] == "stark_prove_ms" and out["n_gpus"] == n and out["value"] > 0
+        c = out["config"]
+        assert c["verify_accepts"] is True and c["same_proof_on_every_rank"] is True and c["proof_bytes"] > 10000
 
 
 def test_sharded_fri_hip_engine_matches_reference_proofs(sc):
