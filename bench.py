@@ -83,6 +83,18 @@ def cpu_baseline(sample_log2n):
     return out
 
 
+def emit(out):
+    """the ONE JSON line, as the last line of stdout: RCCL writes a version banner through C stdio, which sits in libc's buffer
+    until the process exits -- flush it first so that it cannot land behind the line"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def _free_port():
     import socket
     with socket.socket() as s_:
@@ -402,7 +414,7 @@ def main():
                 out["extras"] = {"error": repr(e)}
         if not args.no_cpu_baseline and not sharded and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if sharded:
         dist.destroy_process_group()
     elif world > 1:
@@ -554,7 +566,7 @@ def run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gp
                           "collective_backend": collective_label(backend, world, ngpu, shared_gpus),
                           "parallelism": "four-step LDE (1 all-to-all each), slab-local folds, sharded Merkle (1 all-gather per commit)"},
                "stages_best_run": rec}
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.destroy_process_group()
 
 
@@ -620,7 +632,7 @@ def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shar
                           "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace-domain polynomials replicated",
                           "proof_bytes": len(proof), "proof_sha256_16": digest.hex()[:16], "same_proof_on_every_rank": same_everywhere,
                           "verify_accepts": verifies, "verify_s": verify_s, "preprocess_s": preprocess_s, "runs_ms": [round(x * 1e3, 3) for x in t.tolist()]}}
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.destroy_process_group()
     if not same_everywhere:
         sys.exit("ranks disagree on the proof")

@@ -235,6 +235,10 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
  * SHAKE-256 (FIPS 202); Field.sample = big-endian integer of the bytes mod p; pickle.dumps of a list of `count` byte strings
  * (*out_len = bytes needed, copied into out when out_cap suffices) */
 int sc_shake256(const void* in, uint64_t len, void* out, uint64_t out_len);
+/* Field.sample (algebra.py:116-120) of `count` host byte strings of `width` <= 32 bytes each, straight into device memory: the
+ * randomizer polynomial of FastStark.prove (fast_stark.py:117: one os.urandom(17) draw per coefficient) without a Python object
+ * per coefficient.  Synchronous (the bytes are the caller's host memory). */
+int sc_sample_bytes_dev(const void* bytes, uint64_t count, uint32_t width, void* d_out, void* stream);
 int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]);
 int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len);
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */

@@ -102,6 +102,21 @@ SC_HD uint32_t lds_index(uint32_t r, uint32_t c, int logC) {
     return (r << logC) | ((c ^ r) & cm);
 }
 
+// A table entry that is read exactly once per transform (the direct four-step tables): with SC_TWD_NT the load carries the
+// non-temporal hint, so that the table streams past the caches instead of displacing the vector (A/B: profiles/r03).
+#ifndef SC_TWD_NT
+#define SC_TWD_NT 0
+#endif
+SC_HD Fe load_stream(const Fe* p) {
+#if defined(__HIP_DEVICE_COMPILE__) && SC_TWD_NT
+    typedef unsigned long long sc_u64x2 __attribute__((ext_vector_type(2)));
+    const sc_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const sc_u64x2*>(p));
+    return Fe{v.x, v.y};
+#else
+    return *p;
+#endif
+}
+
 // two-level power table lookup: base^e = lo[e & 4095] * hi[e >> 12]   (Montgomery form in, Montgomery form out)
 SC_HD Fe pow2level(const Fe* lo, const Fe* hi, uint64_t e) {
     Fe a = lo[e & 4095u];
@@ -305,7 +320,7 @@ struct Round {
             const uint64_t colidx = ((((uint64_t)t_lo << logC) | cc[i >> S]) >> P.tw_col_shift) + P.tw_col_base;
             // natural output row of element i: k for a column pass of the plain plans (tw_row_k = 1, tw_row_mid = 0), and
             // t_mid + N_1 * k for the last pass of a batched two-pass column transform with a fused outer twiddle table
-            t[i] = P.twd[((uint64_t)k * P.tw_row_k + (uint64_t)t_mid * P.tw_row_mid) * P.twd_stride + colidx];
+            t[i] = load_stream(&P.twd[((uint64_t)k * P.tw_row_k + (uint64_t)t_mid * P.tw_row_mid) * P.twd_stride + colidx]);
         }
     }
     SC_HD void scatter_global(const PassParams& P, const Fe* x) const {

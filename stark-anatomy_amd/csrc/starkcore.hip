@@ -247,6 +247,23 @@ __global__ void __launch_bounds__(256) fri_fold_slab_kernel(const Fe* __restrict
     out[t] = fe_add(fe_half(fe_add(a, b)), mont_mul(fe_sub(a, b), w));
 }
 
+// Field.sample (code/algebra.py:116-120) of `count` byte strings of `width` <= 32 bytes each: the big-endian integer mod p.
+// value = hi * 2^128 + lo with hi, lo < 2^128 < 2p: one conditional subtraction each, hi * 2^128 = to_mont(hi).
+__global__ void __launch_bounds__(256) sample_bytes_kernel(const uint8_t* __restrict__ bytes, uint64_t count, uint32_t width, Fe* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint8_t* b = bytes + i * width;
+    uint64_t w[4] = {0, 0, 0, 0};                      // little-endian 64-bit words of the integer
+    for (uint32_t k = 0; k < width; ++k) {
+        const uint32_t pos = width - 1 - k;            // byte k has weight 256^pos
+        w[pos >> 3] |= (uint64_t)b[k] << (8 * (pos & 7));
+    }
+    Fe lo{w[0], w[1]}, hi{w[2], w[3]};
+    if (fe_ge_p(lo)) lo = fe_sub(lo, Fe{P_LO, P_HI});
+    if (fe_ge_p(hi)) hi = fe_sub(hi, Fe{P_LO, P_HI});
+    out[i] = fe_add(lo, to_mont(hi));
+}
+
 __global__ void __launch_bounds__(256) gather_kernel(const Fe* __restrict__ v, const uint64_t* __restrict__ idx, uint64_t k, Fe* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) out[i] = v[idx[i]];
@@ -1384,6 +1401,20 @@ int sc_vec_download(const sc_vec_t* v, uint64_t offset, void* host, uint64_t cou
     SCCHK(ensure_init());
     if (!v || offset + count > v->n) return fail(SC_ERR_BAD_ARG, "download out of range");
     return download(host, v->d + offset, count * sizeof(Fe), g.stream);
+}
+int sc_sample_bytes_dev(const void* bytes, uint64_t count, uint32_t width, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!count) return SC_OK;
+    if (!bytes || !d_out || width == 0 || width > 32) return fail(SC_ERR_BAD_ARG, "byte strings of 1..32 bytes expected");
+    hipStream_t st = pick_stream(stream);
+    void* buf;
+    SCCHK(scratch(6, count * width + 256, &buf));
+    SCCHK(upload(buf, bytes, count * width, st));
+    hipLaunchKernelGGL(sample_bytes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const uint8_t*)buf, count, width, (Fe*)d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));               // `bytes` is the caller's host memory
+    return SC_OK;
 }
 int sc_memcpy_dev(void* d_dst, const void* d_src, uint64_t count, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -17,6 +17,32 @@ from ntt import *
 from ntt import _View
 
 
+def draw_random_bytes(count, width=17):
+    """`count` draws of os.urandom(width) as one byte string, in draw order.  Long runs are drawn in blocks: os.urandom(n) is
+    the next n bytes of the stream, so the bytes and their order are those of the individual draws."""
+    block = 4096
+    return b"".join(os.urandom(width * min(block, count - i)) for i in range(0, count, block))
+
+
+def sampled_polynomial(raw, field, width=17):
+    """Polynomial([field.sample(raw[17 i : 17 i + 17]) ...]) as a DevicePolynomial: Field.sample on the device (sc_sample_bytes_dev)"""
+    import starkcore as _sc
+    count = len(raw) // width
+    vec = DeviceVector(max(count, 1))
+    _sc._check(_sc.lib().sc_sample_bytes_dev(raw, count, width, vec.ptr, None))
+    return DevicePolynomial(vec, field, count)
+
+
+def device_powers(base, count):
+    """base^i, i < count, as a DeviceVector (Polynomial.scale of the all-ones vector: no host loop)"""
+    import starkcore as _sc
+    ones = DeviceVector.from_bytes((1).to_bytes(16, "little") * count)
+    out = DeviceVector(count)
+    _sc._check(_sc.lib().sc_scale_dev(ones.ptr, out.ptr, count, _sc.fe_bytes(base.value), None))
+    _sc.synchronize()
+    return out
+
+
 class FastStark:
     def __init__(self, field, expansion_factor, num_colinearity_checks, security_level, num_registers, num_cycles, transition_constraints_degree=2):
         assert(len(bin(field.p)) - 2 >= security_level), "p must have at least as many bits as security level"
@@ -104,9 +130,9 @@ class FastStark:
             proof_stream = ProofStream()
         field, registers = self.field, range(self.num_registers)
 
-        # randomizer rows appended to the trace (draw order: row by row, register by register)
-        for _ in range(self.num_randomizers):
-            trace = trace + [[field.sample(os.urandom(17)) for s in registers]]
+        # randomizer rows appended to the trace (draw order: row by row, register by register); one concatenation instead of one
+        # per row -- the caller's list is not touched either way
+        trace = trace + [[field.sample(os.urandom(17)) for s in registers] for _ in range(self.num_randomizers)]
 
         on_device = len(trace) >= FastStark.DEVICE_MIN and field.p == Field.P_MAIN
         interpolants = self.boundary_interpolants(boundary)
@@ -115,11 +141,7 @@ class FastStark:
             # Polynomials live in HBM from here on (DevicePolynomial): interpolation, boundary quotients (exact coset division,
             # exactness decided on the device), the AIR substitution in the value domain, the transition quotients, the LDEs and
             # the combination.  The host keeps what byte parity ties to it: os.urandom draws, Fiat-Shamir, the proof stream.
-            dom, acc = [], 1
-            for _ in range(len(trace)):
-                dom.append(acc)
-                acc = acc * self.omicron.value % field.p
-            trace_domain = DeviceDomain(DeviceVector.from_ints(dom), field)
+            trace_domain = DeviceDomain(device_powers(self.omicron, len(trace)), field)
             trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, DeviceCodeword.from_list([row[s] for row in trace], field)))
                                  for s in registers]
             zerofiers_dev = [DevicePolynomial.from_polynomial(z, field) for z in zerofiers]
@@ -152,9 +174,11 @@ class FastStark:
 
         # randomizer polynomial
         max_degree = self.max_degree(transition_constraints)
-        randomizer_polynomial = Polynomial([field.sample(os.urandom(17)) for i in range(max_degree + 1)])
         if on_device:
-            randomizer_polynomial = DevicePolynomial.from_polynomial(randomizer_polynomial, field)
+            # the same draws (max_degree + 1 times os.urandom(17), fast_stark.py:117), sampled into HBM without a Python object each
+            randomizer_polynomial = sampled_polynomial(draw_random_bytes(max_degree + 1), field)
+        else:
+            randomizer_polynomial = Polynomial([field.sample(os.urandom(17)) for i in range(max_degree + 1)])
         randomizer_codeword = lde(randomizer_polynomial)
         proof_stream.push(Merkle.commit(randomizer_codeword))
 

@@ -86,14 +86,14 @@ class ShardedFastStark(FastStark):
     def _shared_random_bytes(self, count):
         """`count` draws of os.urandom(17) in the reference's order (fast_stark.py:80, :117), made by rank 0 and broadcast: every
         rank must randomise the same trace"""
-        raw = b"".join(_fs.os.urandom(17) for _ in range(count)) if self.rank == 0 else bytes(17 * count)
+        raw = _fs.draw_random_bytes(count) if self.rank == 0 else bytes(17 * count)
         if self.world > 1:
             on_dev = dist.get_backend(self.group) == "nccl"
             t = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
             t = t.to(self.device) if on_dev else t
             dist.broadcast(t, 0, group=self.group)
             raw = bytes(t.cpu().numpy())
-        return [raw[17 * i:17 * i + 17] for i in range(count)]
+        return raw
 
     # -- sharded building blocks ---------------------------------------------------------------------
     def _lde_commit(self, poly):
@@ -142,18 +142,14 @@ class ShardedFastStark(FastStark):
         field, registers = self.field, range(self.num_registers)
 
         # randomizer rows appended to the trace (draw order: row by row, register by register)
-        draws = iter(self._shared_random_bytes(self.num_randomizers * self.num_registers))
-        for _ in range(self.num_randomizers):
-            trace = trace + [[field.sample(next(draws)) for s in registers]]
+        raw = self._shared_random_bytes(self.num_randomizers * self.num_registers)
+        draws = iter([raw[17 * i:17 * i + 17] for i in range(len(raw) // 17)])
+        trace = trace + [[field.sample(next(draws)) for s in registers] for _ in range(self.num_randomizers)]
 
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)
         # replicated: the trace polynomials through {omicron^i} over the subproduct tree (fast_stark.py:84-87)
-        dom, acc = [], 1
-        for _ in range(len(trace)):
-            dom.append(acc)
-            acc = acc * self.omicron.value % field.p
-        trace_domain = DeviceDomain(DeviceVector.from_ints(dom), field)
+        trace_domain = DeviceDomain(_fs.device_powers(self.omicron, len(trace)), field)
         trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, DeviceCodeword.from_list([row[s] for row in trace], field)))
                              for s in registers]
         # sharded: boundary quotients, their LDEs and commitments (fast_stark.py:89-105)
@@ -173,7 +169,7 @@ class ShardedFastStark(FastStark):
 
         # randomizer polynomial (rank 0's draws), its sharded LDE and commitment
         max_degree = self.max_degree(transition_constraints)
-        randomizer_polynomial = DevicePolynomial.from_polynomial(Polynomial([field.sample(b) for b in self._shared_random_bytes(max_degree + 1)]), field)
+        randomizer_polynomial = _fs.sampled_polynomial(self._shared_random_bytes(max_degree + 1), field)
         randomizer_layer = self._lde_commit(randomizer_polynomial)
         proof_stream.push(randomizer_layer["root"])
 

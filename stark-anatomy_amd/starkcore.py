@@ -41,6 +41,7 @@ SIGNATURES = {
     "sc_vec_download": (_int, [_vp, _u64, _vp, _u64]),
     "sc_vec_gather": (_int, [_vp, _vp, _u64, _vp]),
     "sc_memcpy_dev": (_int, [_vp, _vp, _u64, _vp]),
+    "sc_sample_bytes_dev": (_int, [_vp, _u64, ctypes.c_uint32, _vp, _vp]),
     "sc_ntt": (_int, [_vp, _vp, _u64, _vp, _int]),
     "sc_ntt_dev": (_int, [_vp, _vp, _u64, _vp, _int, _vp]),
     "sc_ntt_batch_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp]),

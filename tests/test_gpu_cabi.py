@@ -644,3 +644,24 @@ def test_async_commit_round_and_wide_query(sc):
     assert [len(e) for e, _ in fetched] == [2, 0, 1] and fetched[2][1] == [C.merkle_open(datas[2], sizes[2], 3)]
     with pytest.raises(AssertionError):
         sc.query_codewords([sc.DeviceCodeword(vecs[0], field)], [[-1]])
+
+
+def test_sample_bytes_on_device(sc):
+    """sc_sample_bytes_dev == Field.sample (code/algebra.py:116-120) per byte string, for every width up to 32 bytes, edge values
+    included (all ones, p, p - 1, multiples of 2^128)"""
+    import random
+    from algebra import Field
+    field = Field.main()
+    rng = random.Random(77)
+    lib = sc.lib()
+    for width in (1, 8, 16, 17, 24, 32):
+        rows = [bytes(rng.randrange(256) for _ in range(width)) for _ in range(300)]
+        rows += [bytes([255]) * width, bytes(width), (1).to_bytes(width, "big")]
+        if width >= 16:
+            rows += [P.to_bytes(width, "big"), (P - 1).to_bytes(width, "big")]
+        if width >= 17:
+            rows += [(1 << 128).to_bytes(width, "big"), ((1 << 128) + P).to_bytes(width, "big")]
+        out = sc.DeviceVector(len(rows))
+        sc._check(lib.sc_sample_bytes_dev(b"".join(rows), len(rows), width, out.ptr, None))
+        assert synth.unpack_ints(out.to_bytes()) == [field.sample(r).value for r in rows], width
+    assert lib.sc_sample_bytes_dev(b"x" * 33, 1, 33, sc.DeviceVector(1).ptr, None) == -6
