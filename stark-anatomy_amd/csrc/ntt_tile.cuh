@@ -325,8 +325,13 @@ struct Round {
     }
     SC_HD void scatter_global(const PassParams& P, const Fe* x) const {
         Fe none[E];
-        scatter_global(P, x, none, false);
+        if (P.out_alt != nullptr) scatter_global<true>(P, x, none, false);
+        else scatter_global<false>(P, x, none, false);
     }
+    // ALT: the launch has a second destination (PassParams::out_alt).  A compile-time switch: with the test at run time (inside
+    // the store loop, or two loops behind one branch) the plain transforms paid 1-2 % more VALU instructions for index math
+    // the compiler hoisted above the branch; the geometry-specialised kernels are instantiated for both values.
+    template <bool ALT>
     SC_HD void scatter_global(const PassParams& P, const Fe* x, const Fe (&twd_prefetched)[E], bool have_prefetched) const {
         Fe v[E];
 #pragma unroll
@@ -368,12 +373,14 @@ struct Round {
         for (int i = 0; i < E; ++i) {
             const uint32_t k = bitrev32(row(i, 0), logR), c = cc[i >> S];
             uint64_t j = (uint64_t)t_hi * P.out_hi + (uint64_t)t_mid * P.out_mid + (uint64_t)t_lo * P.out_lo + (uint64_t)k * P.out_rs + (uint64_t)c * P.out_cs;
-            Fe* dst = P.out;
-            if (P.out_alt) {
+            if constexpr (ALT) {
+                // natural rows [alt_lo, alt_lo + alt_n) go to out_alt, the others to out (same element index)
                 const uint32_t nat = k * P.alt_row_k + t_mid * P.alt_row_mid;
-                if (nat - P.alt_lo < P.alt_n) dst = P.out_alt;
+                Fe* dst = (nat - P.alt_lo < P.alt_n) ? P.out_alt : P.out;
+                dst[j] = v[i];
+            } else {
+                P.out[j] = v[i];
             }
-            dst[j] = v[i];
         }
     }
 };
@@ -425,7 +432,7 @@ SC_HD void tile_twiddles_to_lds(const PassParams& P, int logR, uint32_t tid, uin
 //     [SH - LOGE + GLC, SH + GLC) (derivation in DESIGN.md 3.1): once SH + GLC <= 6 every later exchange stays inside
 //     one 64-lane wave, each wave owns a closed set of LDS rows, and the workgroup barrier is replaced by a wave-level
 //     fence -- the waves of a workgroup then drift apart and overlap each other's LDS traffic, arithmetic and stores.
-template <int LOGE, int GLR, int GLC, int ROUND = 0>
+template <int LOGE, int GLR, int GLC, int ROUND = 0, bool ALT = false>
 struct FixedRounds {
     static constexpr int E = 1 << LOGE;
     static constexpr int NR = (GLR + LOGE - 1) / LOGE;
@@ -470,9 +477,9 @@ struct FixedRounds {
             R.scatter_lds(SH, x, lds);
             if (NEXT_WAVE_LOCAL && wave_local) wsync(); else sync();
             stamp(4 + 2 * ROUND);
-            FixedRounds<LOGE, GLR, GLC, ROUND + 1>::run(P, tile, tid, lds, tw, sync, wsync, stamp, wave_local);
+            FixedRounds<LOGE, GLR, GLC, ROUND + 1, ALT>::run(P, tile, tid, lds, tw, sync, wsync, stamp, wave_local);
         } else {
-            R.scatter_global(P, x, tpre, prefetched);
+            R.template scatter_global<ALT>(P, x, tpre, prefetched);
             stamp(4 + 2 * ROUND);
         }
     }

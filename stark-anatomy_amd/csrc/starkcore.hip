@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(PassThreads<LOGE>::value) ntt_pass_kernel(cons
 // it does differently (one memory latency per workgroup, wave-level fences once the exchanges stay inside a wave).
 // TRACE instantiations stamp s_memtime per wave at every phase boundary into P.trace (tools/pass_trace.py).
 constexpr int TRACE_STAMPS = 16;
-template <int LOGE, int GLR, int GLC, bool TRACE>
+template <int LOGE, int GLR, int GLC, bool TRACE, bool ALT = false>
 __global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed(const PassParams P, uint32_t ntiles, int xcd_remap, int wave_local) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fe* lds = reinterpret_cast<Fe*>(smem_raw);
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed
     };
     auto sync = [] { __syncthreads(); };
     auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
-    FixedRounds<LOGE, GLR, GLC>::run(P, tile, threadIdx.x, lds, tw, sync, wsync, stamp, wave_local != 0);
+    FixedRounds<LOGE, GLR, GLC, 0, ALT>::run(P, tile, threadIdx.x, lds, tw, sync, wsync, stamp, wave_local != 0);
     if constexpr (TRACE) {
         if (trow && (threadIdx.x & 63u) == 0) { __builtin_amdgcn_s_waitcnt(0); trow[14] = __builtin_amdgcn_s_memtime(); trow[13] = __builtin_amdgcn_s_memrealtime(); }
     }
@@ -694,13 +694,16 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
         // hot shapes of the default plans get geometry-specialised instantiations
         if (g.fixed_shapes) {
             const int lr = pd.p.logR, lc = pd.p.logC;
-#define SC_LAUNCH_FIXED(LR, LC, TR) \
-    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, TR>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local)
-#define SC_FIXED(LR, LC)                                              \
-            if (lr == LR && lc == LC) {                               \
-                if (pd.p.trace) SC_LAUNCH_FIXED(LR, LC, true);        \
-                else SC_LAUNCH_FIXED(LR, LC, false);                  \
-                return;                                               \
+#define SC_LAUNCH_FIXED(LR, LC, TR, ALT) \
+    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, TR, ALT>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local)
+            // (a launch with a second destination -- the column stage of the sharded transform -- has its own instantiation; it
+            // is never traced: the generic kernel serves that combination)
+#define SC_FIXED(LR, LC)                                                          \
+            if (lr == LR && lc == LC && !(pd.p.trace && pd.p.out_alt)) {          \
+                if (pd.p.trace) SC_LAUNCH_FIXED(LR, LC, true, false);             \
+                else if (pd.p.out_alt) SC_LAUNCH_FIXED(LR, LC, false, true);      \
+                else SC_LAUNCH_FIXED(LR, LC, false, false);                       \
+                return;                                                           \
             }
             SC_FIXED(8, 3) SC_FIXED(7, 4) SC_FIXED(10, 2) SC_FIXED(6, 5) SC_FIXED(9, 3) SC_FIXED(8, 4)
 #undef SC_FIXED
