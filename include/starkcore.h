@@ -66,7 +66,8 @@ int sc_ntt_num_passes(uint64_t n);
 int sc_debug_trace(void* d_buf);
 
 /* diagnostics: out[i] = op(a[i], b[i]) computed by the device field routines the kernels use.
- * op 0: a*b*2^-128 (Montgomery product, b < p), 1: a+b, 2: a-b, 3: a*b, 4: a/2, 5: a^-1, 6: portable Montgomery product */
+ * op 0: a*b*2^-128 (Montgomery product, b < p), 1: a+b, 2: a-b, 3: a*b, 4: a/2, 5: a^-1, 6: portable Montgomery product,
+ * 7: the same product through the two-at-a-time routine of the butterflies (all ones if its two halves disagree) */
 int sc_field_selftest(int op, const void* a, const void* b, void* out, uint64_t n);
 
 /* ---- device vectors ----------------------------------------------------------------------- */

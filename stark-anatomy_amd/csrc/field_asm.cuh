@@ -218,35 +218,41 @@ __device__ __forceinline__ void mont_mul2_asm(Fe xa, Fe wa, Fe xb, Fe wb, Fe& ra
     const uint64_t zero64 = 0;
     const uint32_t zero32 = 0, PHc = PH3;
 #define SC_BOTH(STEP) { MulState& M = A; constexpr int W = 0; STEP } { MulState& M = B; constexpr int W = 1; STEP }
-    // ---- product (the schedule of one product already keeps every counter >= 2 instructions behind its v_mad)
+    // ---- product.  Carry counters travel in PAIRS: the odd accumulator O_k covers columns (2k+1, 2k+2), and the overflow counts
+    // of O_{k-1} (weight: column 2k+1) and of E_k (weight: column 2k+2) are exactly the low and the high word of the 64-bit addend
+    // of O_k's first v_mad -- {nO0, nE1} for O1, {nO1, nE2} for O2 -- so no counter is ever zero-extended into a register pair
+    // of its own (4 v_mov per product before), and the even accumulators start from the shared zero.  That first v_mad cannot
+    // overflow: its product has the twiddle's top limb b3 <= 0xCB800000 as a factor (a * b3 <= 0.8 * 2^64) and the addend is
+    // below 2^34.  The schedule keeps every carry consumer >= 2 instructions behind its producer (4 with the interleave).
     SC_BOTH(SC_V_MADD(M.E0, M.a0, M.b0, zero64);)
     SC_BOTH(SC_V_MADD(M.O0, M.a0, M.b1, zero64);)
     SC_BOTH(SC_V_MADD(M.E1, M.a0, M.b2, zero64);)
     SC_BOTH(SC_V_MAD(M.O0, M.c1, M.a1, M.b0, M.O0);)
     SC_BOTH(SC_V_MAD(M.E1, M.c2, M.a1, M.b1, M.E1);)
+    SC_BOTH(SC_V_MAD(M.E1, M.c3, M.a2, M.b0, M.E1);)
     SC_BOTH(SC_V_INCD(M.nO0, zero32, M.c1);)
     SC_BOTH(SC_V_INCD(M.nE1, zero32, M.c2);)
-    SC_BOTH(SC_V_MAD(M.E1, M.c3, M.a2, M.b0, M.E1);)
-    SC_BOTH(SC_V_MADD(M.O1, M.a0, M.b3, (uint64_t)M.nO0);)
-    SC_BOTH(SC_V_MAD(M.O1, M.c4, M.a1, M.b2, M.O1);)
     SC_BOTH(SC_V_INCD(M.nE1, M.nE1, M.c3);)
+    SC_BOTH(SC_V_MADD(M.O1, M.a0, M.b3, (uint64_t)M.nO0 | ((uint64_t)M.nE1 << 32));)
+    SC_BOTH(SC_V_MAD(M.O1, M.c4, M.a1, M.b2, M.O1);)
     SC_BOTH(SC_V_MAD(M.O1, M.c5, M.a2, M.b1, M.O1);)
     SC_BOTH(SC_V_INCD(M.nO1, zero32, M.c4);)
     SC_BOTH(SC_V_MAD(M.O1, M.c6, M.a3, M.b0, M.O1);)
-    SC_BOTH(SC_V_MADD(M.E2, M.a1, M.b3, (uint64_t)M.nE1);)
+    SC_BOTH(SC_V_MADD(M.E2, M.a1, M.b3, zero64);)
     SC_BOTH(SC_V_INCD(M.nO1, M.nO1, M.c5);)
     SC_BOTH(SC_V_MAD(M.E2, M.c7, M.a2, M.b2, M.E2);)
     SC_BOTH(SC_V_INCD(M.nO1, M.nO1, M.c6);)
     SC_BOTH(SC_V_MAD(M.E2, M.c8, M.a3, M.b1, M.E2);)
     SC_BOTH(SC_V_INCD(M.nE2, zero32, M.c7);)
-    SC_BOTH(SC_V_MADD(M.O2, M.a2, M.b3, (uint64_t)M.nO1);)
-    SC_BOTH(SC_V_MAD(M.O2, M.c9, M.a3, M.b2, M.O2);)
+    SC_BOTH(SC_V_MADD(M.E3, M.a3, M.b3, zero64);)
     SC_BOTH(SC_V_INCD(M.nE2, M.nE2, M.c8);)
-    SC_BOTH(SC_V_MADD(M.E3, M.a3, M.b3, (uint64_t)M.nE2);)
-    SC_BOTH(SC_V_INCD(M.nO2, zero32, M.c9);)
-    // ---- merge T = E + (O << 32), interleaved with the reduction chain s0..s3 (t0 = lo32(E0))
+    SC_BOTH(SC_V_MADD(M.O2, M.a2, M.b3, (uint64_t)M.nO1 | ((uint64_t)M.nE2 << 32));)
+    SC_BOTH(SC_V_MAD(M.O2, M.c9, M.a3, M.b2, M.O2);)
+    // ---- merge T = E + (O << 32), interleaved with the reduction chain s0..s3 (t0 = lo32(E0)); its first two steps stand
+    // between the last v_mad of the product and the counter that reads its carry
     SC_BOTH(SC_V_ADDCO(M.t1, M.ct, hi32(M.E0), lo32(M.O0));)
     SC_BOTH(SC_V_MADD(M.s0, lo32(M.E0), PHc, zero64);)
+    SC_BOTH(SC_V_INCD(M.nO2, zero32, M.c9);)
     SC_BOTH(SC_V_ADDC(M.t2, M.ct, lo32(M.E1), hi32(M.O0), M.ct);)
     SC_BOTH(SC_V_MADD(M.s1, M.t1, PHc, (uint64_t)hi32(M.s0));)
     SC_BOTH(SC_V_ADDC(M.t3, M.ct, hi32(M.E1), lo32(M.O1), M.ct);)

@@ -230,6 +230,12 @@ __global__ void __launch_bounds__(256) field_selftest_kernel(int op, const Fe* _
         case 3: r = fe_mul(x, y); break;
         case 4: r = fe_half(x); break;
         case 5: r = from_mont(mont_inv(to_mont(x))); break;
+        case 7: {                                           // the interleaved pair of products the butterflies use: both halves
+            Fe r0, r1;                                      // must agree with each other (operand pairs swapped between the lanes' roles)
+            mont_mul2(x, y, x, y, r0, r1);
+            r = fe_eq(r0, r1) ? r0 : Fe{~0ull, ~0ull};
+            break;
+        }
         default: r = mont_mul_c(x, y); break;               // portable reference implementation
     }
     out[i] = r;

@@ -406,6 +406,13 @@ def test_device_field_ops(sc):
     assert run(0, a, b) == [x * y * Rinv % P for x, y in zip(a, b)]
     assert run(0, a_lazy, b) == [x * y * Rinv % P for x, y in zip(a_lazy, b)]
     assert run(6, a_lazy, b) == [x * y * Rinv % P for x, y in zip(a_lazy, b)]
+    # the two-at-a-time product of the butterflies (paired carry counters: its first odd-column v_mad relies on the second
+    # operand's top limb being <= p's): any 128-bit first operand, second operand up to p - 1
+    assert run(7, a, b) == [x * y * Rinv % P for x, y in zip(a, b)]
+    assert run(7, a_lazy, b) == [x * y * Rinv % P for x, y in zip(a_lazy, b)]
+    worst_a = ([(1 << 128) - 1, (1 << 128) - 1, 0xFFFFFFFF, (1 << 128) - (1 << 96) + 0xFFFFFFFF] * (n // 4 + 1))[:n]
+    worst_b = ([P - 1, P - (1 << 32), P - 1, P - 2] * (n // 4 + 1))[:n]
+    assert run(7, worst_a, worst_b) == [x * y * Rinv % P for x, y in zip(worst_a, worst_b)]
     assert run(1, a, b) == [(x + y) % P for x, y in zip(a, b)]
     assert run(2, a, b) == [(x - y) % P for x, y in zip(a, b)]
     assert run(3, a, b) == [x * y % P for x, y in zip(a, b)]
