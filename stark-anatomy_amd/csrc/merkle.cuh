@@ -304,8 +304,25 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __res
 //   FOUR_LANE : latency-bound launch (few workgroups): levels of <= 64 nodes run four lanes per hash; throughput-bound
 //               launches keep one lane per hash (the 4-lane form costs ~1.6x the instructions per compression) and the leaner
 //               instantiation (fewer registers, 16 KiB of LDS)
-template <bool LEAVES, bool FOUR_LANE>
-__global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev) {
+// FOLD (with LEAVES): the leaves are not read but COMPUTED -- leaf i is the split-and-fold of fri.py:85 of the previous round's
+// codeword, out[i] = (a + b)/2 + (a - b) * c * w^-i with a = in[i], b = in[i + N] (N = this tree's leaves = half of the previous
+// length) -- written to the folded codeword and hashed in the same thread: one launch less per FRI round, and the folded
+// element never makes a round trip through memory between the two kernels.
+struct FoldIn {
+    const Fe* in;       // previous codeword, 2N elements
+    Fe* out;            // folded codeword, N elements
+    const Fe* lo;       // two-level power table of omega^-1
+    const Fe* hi;
+    Fe c_m;             // alpha / (2 * offset), Montgomery form
+};
+__device__ __forceinline__ Fe fold_element(const FoldIn& f, uint64_t i, uint64_t half) {
+    const Fe a = f.in[i], b = f.in[i + half];
+    const Fe t = mont_mul(mont_mul(f.lo[i & 4095u], f.hi[i >> 12]), f.c_m);          // (c * w^-i) in Montgomery form
+    return fe_add(fe_half(fe_add(a, b)), mont_mul(fe_sub(a, b), t));
+}
+
+template <bool LEAVES, bool FOUR_LANE, bool FOLD = false>
+__global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev, const FoldIn fold = FoldIn()) {
     __shared__ uint4 cur[256 * 4];                    // this level's digests of the subtree (16 KiB)
     constexpr bool four_lane = FOUR_LANE && (SC_MERKLE_4LANE != 0);
     __shared__ uint64_t linA[four_lane ? 64 * 17 : 1], linB[four_lane ? 32 * 17 : 1];   // 4-lane path: 128 resp. 64 digests in the lin layout
@@ -315,7 +332,14 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
     uint64_t h[8];
     if (LEAVES) {
         uint64_t m[16];
-        uint32_t len = leaf_message(elems[wg * 256u + t], m);
+        Fe e;
+        if constexpr (FOLD) {
+            e = fold_element(fold, wg * 256u + t, N);
+            fold.out[wg * 256u + t] = e;
+        } else {
+            e = elems[wg * 256u + t];
+        }
+        uint32_t len = leaf_message(e, m);
         blake2b_single_block(m, len, h);
     } else {
         const ulonglong2* s = reinterpret_cast<const ulonglong2*>(levels + 8 * (level_off(lvl0) + wg * 256u + t));
@@ -377,7 +401,17 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
 // finishes the tree from a level of `width` <= 2048 digests down to the root inside ONE workgroup
 // (levels are written once and read only after the barrier, so L1 cannot hold a stale copy).  Levels of <= 256 parents run
 // four lanes per hash out of LDS.
-__global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint64_t width) {
+// host != nullptr: the root is also written to a pinned, host-coherent slot (8 words, then -- ordered behind them -- the
+// sequence number the waiting host polls): the separate publish launch of an asynchronous build is saved.
+__device__ __forceinline__ void publish_root(const uint64_t* root, volatile uint64_t* host, uint64_t seq) {
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 8) host[threadIdx.x] = root[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) host[8] = seq;
+}
+
+__global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint64_t width, volatile uint64_t* host = nullptr, uint64_t seq = 0) {
     uint64_t* cur = level;
     uint64_t w = width;
 #if SC_MERKLE_4LANE
@@ -393,7 +427,10 @@ __global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint
         cur = nxt;
     }
 #if SC_MERKLE_4LANE
-    if (w <= 1) return;
+    if (w <= 1) {
+        if (host) publish_root(cur, host, seq);
+        return;
+    }
     for (uint32_t q = threadIdx.x; q < (uint32_t)w * 8u; q += 1024u) linA[lin_off(q >> 3) + (q & 7u)] = cur[q];
     __syncthreads();
     uint64_t* src = linA;
@@ -406,6 +443,7 @@ __global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint
         uint64_t* s = src; src = dst; dst = s;
     }
 #endif
+    if (host) publish_root(cur, host, seq);
 }
 
 // authentication paths (merkle.py:16-27): for query q, digest l of the path = level_l[(index >> l) ^ 1]

@@ -828,7 +828,9 @@ int download(void* h, const void* d, size_t bytes, hipStream_t st) {
 // 2.09 ms, 1 level per launch 2.46 ms, 4 levels 2.50 ms, 8 levels 4.5 ms.
 constexpr uint64_t FUSE_MAX_W = 1ull << 17;
 
-int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
+// host / seq: an asynchronous build's pinned root slot; *published is set when the last launch (the tail kernel) wrote the root
+// there itself, so that no separate publish launch is needed
+int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st, volatile uint64_t* host = nullptr, uint64_t seq = 0, bool* published = nullptr) {
     const int logN = ilog2(N);
     uint64_t w = N >> lvl;
     auto off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
@@ -837,7 +839,7 @@ int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
             // whole waves retire as the subtree narrows (256 -> 128 -> 64 nodes: 4, 2, 1 full waves), no lane is wasted and
             // the intermediate levels are never re-read from HBM
             const int nlev = g.merkle_big_nlev;
-            hipLaunchKernelGGL((merkle_subtree_kernel<false, false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
+            hipLaunchKernelGGL((merkle_subtree_kernel<false, false>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev, FoldIn());
             lvl += nlev;
             w >>= nlev;
         } else if (w > FUSE_MAX_W) {
@@ -847,12 +849,15 @@ int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st) {
         } else {
             int nlev = 8;
             if (nlev > logN - lvl) nlev = logN - lvl;
-            hipLaunchKernelGGL((merkle_subtree_kernel<false, true>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev);
+            hipLaunchKernelGGL((merkle_subtree_kernel<false, true>), dim3((unsigned)(w / 256)), dim3(256), 0, st, (const Fe*)nullptr, levels, N, lvl, nlev, FoldIn());
             lvl += nlev;
             w >>= nlev;
         }
     }
-    if (w > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, levels + 8 * off(lvl), w);
+    if (w > 1) {
+        hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(1024), 0, st, levels + 8 * off(lvl), w, host, seq);
+        if (host && published) *published = true;
+    }
     HIPCHK(hipGetLastError());
     return SC_OK;
 }
@@ -879,9 +884,15 @@ int root_slot_get() {
 // sub-root level is copied out on the same stream): no pinned slot is taken and no publish kernel runs, so any number of such
 // trees can be alive at once without degrading the asynchronous builds of Fri.commit to the synchronous path.
 enum BuildMode { BUILD_SYNC = 0, BUILD_ASYNC = 1, BUILD_NOROOT = 2 };
-int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st, BuildMode mode = BUILD_SYNC) {
+// fold != nullptr (with N >= 256): the leaves are the split-and-fold of the previous round's codeword, computed, stored to
+// d_elems (= fold->out) and hashed by the leaf stage itself (merkle_subtree_kernel<true, *, true>)
+int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_merkle** tree, hipStream_t st, BuildMode mode = BUILD_SYNC, const FoldIn* fold = nullptr) {
     if (!is_pow2(N)) return fail(SC_ERR_NOT_POW2, "length must be power of two");
+    if (fold && N < 256) return fail(SC_ERR_BAD_ARG, "the fused fold needs at least 256 leaves");
     const int slot = (mode == BUILD_ASYNC && tree) ? root_slot_get() : -1;
+    const uint64_t seq = slot >= 0 ? ++g.root_seq : 0;
+    volatile uint64_t* host = slot >= 0 ? (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * slot) : nullptr;
+    bool published = false;
     uint8_t root_tmp[64];
     if (!root_out) root_out = root_tmp;
     uint64_t* levels = nullptr;
@@ -889,17 +900,20 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
     HIPCHK(pool_alloc((void**)&levels, tree_bytes));
     if (N >= 256 && N <= FUSE_MAX_W) {
         int nlev = ilog2(N) < 8 ? ilog2(N) : 8;                  // leaves + up to 8 levels of every 256-leaf subtree in one launch
-        hipLaunchKernelGGL((merkle_subtree_kernel<true, true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev);
-        (void)merkle_climb(levels, N, nlev, st);
-    } else if (N > FUSE_MAX_W && g.merkle_big_nlev > 0) {
-        hipLaunchKernelGGL((merkle_subtree_kernel<true, false>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, g.merkle_big_nlev);
-        (void)merkle_climb(levels, N, g.merkle_big_nlev, st);
+        if (fold) hipLaunchKernelGGL((merkle_subtree_kernel<true, true, true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev, *fold);
+        else hipLaunchKernelGGL((merkle_subtree_kernel<true, true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev, FoldIn());
+        (void)merkle_climb(levels, N, nlev, st, host, seq, &published);
+    } else if (N > FUSE_MAX_W && (g.merkle_big_nlev > 0 || fold)) {
+        const int nlev = g.merkle_big_nlev > 0 ? g.merkle_big_nlev : 1;
+        if (fold) hipLaunchKernelGGL((merkle_subtree_kernel<true, false, true>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev, *fold);
+        else hipLaunchKernelGGL((merkle_subtree_kernel<true, false>), dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N, 0, nlev, FoldIn());
+        (void)merkle_climb(levels, N, nlev, st, host, seq, &published);
     } else if (N > FUSE_MAX_W) {
         hipLaunchKernelGGL(merkle_leaf_kernel, dim3((unsigned)(N / 256)), dim3(256), 0, st, d_elems, levels, N);
-        (void)merkle_climb(levels, N, 0, st);
+        (void)merkle_climb(levels, N, 0, st, host, seq, &published);
     } else {
         hipLaunchKernelGGL(merkle_leaf_kernel, dim3(1), dim3(256), 0, st, d_elems, levels, N);
-        (void)merkle_climb(levels, N, 0, st);
+        (void)merkle_climb(levels, N, 0, st, host, seq, &published);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (slot >= 0) g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
@@ -911,11 +925,11 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
         return SC_OK;
     }
     if (slot >= 0) {
-        // the root is WRITTEN to the host slot by a one-wave kernel behind the build (then its sequence number): the waiting
-        // host sees it a microsecond later, without a copy engine, a completion signal or a runtime call in between
-        const uint64_t seq = ++g.root_seq;
-        hipLaunchKernelGGL(root_publish_kernel, dim3(1), dim3(64), 0, st, (const uint64_t*)(levels + 8 * (2 * N - 2)),
-                           (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * slot), seq);
+        // the root is WRITTEN to the host slot by the kernel that computes it (the one-workgroup tail kernel) or, where the tree
+        // ends in another kernel, by a one-wave kernel behind the build -- then its sequence number: the waiting host sees it a
+        // microsecond later, without a copy engine, a completion signal or a runtime call in between
+        if (!published)
+            hipLaunchKernelGGL(root_publish_kernel, dim3(1), dim3(64), 0, st, (const uint64_t*)(levels + 8 * (2 * N - 2)), host, seq);
         e = hipGetLastError();
         if (e != hipSuccess) { g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
         sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
@@ -985,7 +999,8 @@ int merkle_root_wait(sc_merkle* t, bool from_free = false) {
     return SC_OK;
 }
 
-int fold_device(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st) {
+// everything of a fold but its launch: the power tables of omega^-1 and c = alpha / (2 * offset)
+int fold_prepare(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st, FoldIn* f) {
     if (N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
     if (fe_is_zero(offset) || fe_is_zero(omega)) return fail(SC_ERR_DIV_ZERO, "divide by zero");
     // omega^-1 power tables; c = alpha / (2 * offset).  Consecutive rounds of Fri.commit square omega and offset (fri.py:86-87):
@@ -1012,11 +1027,30 @@ int fold_device(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d
     Fe winv = from_mont(winv_m);
     PowTables* pw;
     SCCHK(get_pow(winv, N / 2, st, &pw));
-    Fe c_m = mont_mul(to_mont(alpha), i2o_m);     // alpha~ * (2 offset)^-1~ / R = c~
+    f->in = d_in; f->out = d_out; f->lo = pw->lo; f->hi = pw->hi;
+    f->c_m = mont_mul(to_mont(alpha), i2o_m);     // alpha~ * (2 offset)^-1~ / R = c~
+    return SC_OK;
+}
+
+int fold_device(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st) {
+    FoldIn f;
+    SCCHK(fold_prepare(d_in, N, alpha, offset, omega, d_out, st, &f));
     uint64_t half = N / 2;
-    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, d_in, d_out, half, pw->lo, pw->hi, c_m);
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, d_in, d_out, half, f.lo, f.hi, f.c_m);
     HIPCHK(hipGetLastError());
     return SC_OK;
+}
+
+// one round of Fri.commit (fri.py:73-88) on the device: the fold of the codeword and the tree of the folded codeword, enqueued, the
+// root on its way to a pinned slot.  From 256 folded elements up the leaf stage of the tree computes the fold itself.
+int fold_and_build(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, sc_merkle** tree, hipStream_t st) {
+    if (N / 2 >= 256) {
+        FoldIn f;
+        SCCHK(fold_prepare(d_in, N, alpha, offset, omega, d_out, st, &f));
+        return merkle_build_device(d_out, N / 2, nullptr, tree, st, BUILD_ASYNC, &f);
+    }
+    SCCHK(fold_device(d_in, N, alpha, offset, omega, d_out, st));
+    return merkle_build_device(d_out, N / 2, nullptr, tree, st, BUILD_ASYNC);
 }
 
 int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st) {
@@ -2197,8 +2231,7 @@ int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2]
     SCCHK(ensure_init());
     if (!tree || !d_in || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
     hipStream_t st = pick_stream(stream);
-    SCCHK(fold_device((const Fe*)d_in, N, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)d_out, st));
-    return merkle_build_device((const Fe*)d_out, N / 2, nullptr, tree, st, BUILD_ASYNC);
+    return fold_and_build((const Fe*)d_in, N, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)d_out, tree, st);
 }
 // ---- the Fiat-Shamir step on the host side of the library (csrc/transcript.h); no GPU needed
 static Fe sample_field(const uint8_t* bytes, size_t len) {
@@ -2295,9 +2328,7 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
         shake256(bytes.data(), bytes.size(), digest, 32);
         const Fe alpha = sample_field(digest, 32);
         alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
-        rc = fold_device(cur, n, alpha, off, om, nxt->d, st);
-        if (rc != SC_OK) return undo(rc);
-        rc = merkle_build_device(nxt->d, n / 2, nullptr, &trees_out[r + 1], st, BUILD_ASYNC);
+        rc = fold_and_build(cur, n, alpha, off, om, nxt->d, &trees_out[r + 1], st);
         if (rc != SC_OK) return undo(rc);
         ++made_trees;
         cur = nxt->d;

@@ -238,6 +238,9 @@ class FastStark:
             entries, paths = codeword.query(indices)          # entries and paths in one device round trip
         else:
             entries, paths = [codeword[i] for i in indices], Merkle._tree(codeword).open_batch(indices)
+        if type(proof_stream) is ProofStream:            # push == objects.append: one list extension for the whole codeword
+            proof_stream.objects.extend(x for pair in zip(entries, paths) for x in pair)
+            return
         for entry, path in zip(entries, paths):
             proof_stream.push(entry)
             proof_stream.push(path)

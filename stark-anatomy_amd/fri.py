@@ -178,16 +178,21 @@ class Fri:
             fetched = query_codewords(codewords, requests)          # every round's openings in one device round trip
         else:
             fetched = [cw.query(request) for cw, request in zip(codewords, requests)]
+        # pushes in the reference's order (fri.py:104-113 per round: s triples, then per test the paths of a, b, c); a ProofStream's
+        # `push` is `objects.append`, so a whole round goes in with two list extensions instead of 4 s method calls
+        objects = proof_stream.objects if type(proof_stream) is ProofStream else None
         for i in range(rounds):
             entries, paths = fetched[i]
             next_entries, next_paths = fetched[i + 1]
             c_at = 2 * s if i + 1 < rounds else 0
-            for t in range(s):
-                proof_stream.push((entries[t], entries[s + t], next_entries[c_at + t]))
-            for t in range(s):
-                proof_stream.push(paths[t])
-                proof_stream.push(paths[s + t])
-                proof_stream.push(next_paths[c_at + t])
+            triples = list(zip(entries[:s], entries[s:2 * s], next_entries[c_at:c_at + s]))
+            openings = [p for trio in zip(paths[:s], paths[s:2 * s], next_paths[c_at:c_at + s]) for p in trio]
+            if objects is not None:
+                objects.extend(triples)
+                objects.extend(openings)
+            else:
+                for obj in triples + openings:
+                    proof_stream.push(obj)
 
     def _last_codeword_degree(self, last_codeword, last_omega, last_offset):
         """Degree of the interpolant of the last codeword on its coset: intt + unscale (the route the

@@ -609,8 +609,13 @@ class DeviceCodeword(Sequence):
         """FieldElement objects for freshly fetched residues, created once per index (see __init__)"""
         if self._full is not None:
             return [self._full[i] for i in indices]
-        known, fe, field = self._elems, _field_element(), self.field
+        known, fe, field, new = self._elems, _field_element(), self.field, object.__new__
         for i, v in zip(indices, values):
             if i not in known:
-                known[i] = fe(v, field)
+                # FieldElement(v, field) without the call into __init__ (algebra.py:16-18 sets exactly these two attributes):
+                # half the cost per object, and a query phase creates over a thousand of them
+                e = new(fe)
+                e.value = v
+                e.field = field
+                known[i] = e
         return [known[i] for i in indices]
