@@ -984,13 +984,15 @@ class ColumnReplicas:
             if i % self.world == self.rank:
                 codeword = self.engine.lde(coeffs, offset, generator, order)
                 mine[i] = (codeword, self.engine.tree(codeword))
-        local = {i: t.root for i, (_, t) in mine.items()}
-        if self.world == 1:
-            gathered = [local]
-        else:
-            gathered = [None] * self.world
-            dist.all_gather_object(gathered, local, group=self.group)
-        roots = {}
-        for part in gathered:
-            roots.update(part)
-        return mine, [roots[i] for i in range(len(columns))]
+        # every rank needs all the roots, in column order: a [columns][64] byte table in which each rank fills the rows of its own
+        # columns, summed over the ranks (the rows are disjoint) -- one fixed-shape tensor collective, nothing pickled
+        import numpy as np
+        table = np.zeros((len(columns), 64), dtype=np.int32)
+        for i, (_, t) in mine.items():
+            table[i] = np.frombuffer(t.root, dtype=np.uint8)
+        if self.world > 1:
+            on_dev = self.device.type == "cuda" and dist.get_backend(self.group) != "gloo"
+            tt = torch.from_numpy(table).to(self.device) if on_dev else torch.from_numpy(table)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM, group=self.group)
+            table = tt.cpu().numpy()
+        return mine, [bytes(table[i].astype(np.uint8)) for i in range(len(columns))]
