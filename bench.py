@@ -346,6 +346,20 @@ def main():
 
     # correctness guard inside the bench: the round trip must reproduce the input bit for bit
     ok = bool(torch.equal(z, x))
+    # ... and the forward transform of the timed workload is the REFERENCE's: tests/golden/ntt_big.json holds the SHA-256 of
+    # code/ntt.py's own output for this very input (synth seed 1, n = 2^20, Field.primitive_nth_root), generated by
+    # tests/golden/make_golden.py from the imported reference (BASELINE configs[1]: "bit-exact vs code/ntt.py")
+    reference_sha = None
+    if not sharded and world == 1:
+        try:
+            import hashlib
+            gold = json.load(open(os.path.join(REPO, "tests", "golden", "ntt_big.json")))
+            want = [r["sha256"] for r in gold["ntt"] if r["logn"] == log2n and r["seed"] == 1 and int(r["root"]) == nth_root(n)]
+            if want:
+                reference_sha = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest() == want[0]
+                ok = ok and reference_sha
+        except Exception:       # noqa: BLE001  (no fixture: the round trip stays the guard)
+            reference_sha = None
 
     census = None
     if sharded and world > 1 and not args.no_extras:
@@ -382,7 +396,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": scaling_label, "vs_baseline": None, "dtype": "u128", "data": "synthetic",
             "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
-                       "passes_per_transform": passes, "roundtrip_bit_exact": ok},
+                       "passes_per_transform": passes, "roundtrip_bit_exact": ok, "forward_sha256_equals_reference_output": reference_sha},
             "clock_ramp": {"untimed_steps_between_windows": ramp_steps, "target_ms": CLOCK_RAMP_MS,
                            "steady_state": {"value": 2.0 * total_n * args.steps / steady_elapsed, "ms_per_step": 1e3 * steady_elapsed / args.steps,
                                             "avg_launch_us": steady_ev_ms * 1e3 / (args.steps * launches_per_step),
@@ -416,6 +430,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
         emit(out)
     if sharded:
+        try:
+            from sharded import destroy_native_comm
+            destroy_native_comm()
+        except Exception:      # noqa: BLE001
+            pass
         dist.destroy_process_group()
     elif world > 1:
         try:

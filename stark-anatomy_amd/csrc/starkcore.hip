@@ -2282,7 +2282,7 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!d_codeword || !trees_out || !roots_out || (rounds > 1 && (!vecs_out || !alphas_out)) || rounds < 1) return fail(SC_ERR_BAD_ARG, "null argument");
-    if (N < 2 || !is_pow2(N) || (N >> (rounds - 1)) < 1) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
+    if (N < 2 || !is_pow2(N) || rounds > 60 || (N >> (rounds - 1)) < 1) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
     if (prior_count + rounds > TRANSCRIPT_MAX_ITEMS) return fail(SC_ERR_UNSUPPORTED, "transcript too long for the fixed layout");
     std::vector<uint8_t> items, bytes;
     {

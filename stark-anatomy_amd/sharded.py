@@ -185,6 +185,12 @@ def init_native_comm(rank, world, device, group=None):
     return int(flag.item()) == 1
 
 
+def destroy_native_comm():
+    """tear the library's RCCL communicator down (before the process group goes away); a no-op when there is none"""
+    import starkcore as sc
+    sc.lib().sc_comm_destroy()
+
+
 class ShardedNtt:
     def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False, overlap_chunks=1, native_exchange=False,
                  defer_last_pass=True):

@@ -289,6 +289,21 @@ def _run_bench(args, timeout=900):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
+def test_bench_headline_line_is_the_contract_and_matches_the_reference(sc):
+    """the N = 1 headline exactly as the driver runs it (BASELINE configs[1]): the JSON contract's keys, `roofline` and -- with
+    cpu_baseline switched off here for time -- a forward transform whose SHA-256 equals the one the reference's code/ntt.py produced
+    for the same input (tests/golden/ntt_big.json)"""
+    out = _run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-extras", "--no-cpu-baseline"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["metric"] == "ntt_field_elements_per_sec" and out["n_gpus"] == 1 and out["steps"] == 5 and out["dtype"] == "u128"
+    assert out["config"]["workload"] == "ntt_fwd_inv_2^20_1gpu" and out["config"]["roundtrip_bit_exact"] is True
+    assert out["config"]["forward_sha256_equals_reference_output"] is True
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > r["alg_bytes_per_launch"]
+    assert abs(out["value"] - 2 * (1 << 20) * 5 / (out["ms_per_step"] * 5e-3)) < 1e-3 * out["value"]
+
+
 def test_bench_two_ranks_print_the_north_star_record(sc):
     """`python bench.py --gpus 2` times the north_star's transform -- forward + inverse at 2^24, strong scaling --
     and carries it as extras.ntt_2p24_strong with the roofline fraction, the bytes exchanged, the form of the corner turn and a

@@ -101,6 +101,8 @@ def run(log2n, steps):
     t2 = time.perf_counter()
     out["plain_single_gpu"] = {"ms_per_step": 1e3 * (t2 - t0) / steps, "host_enqueue_ms_per_step": 1e3 * (t1 - t0) / steps}
     print(json.dumps(out), flush=True)
+    from sharded import destroy_native_comm
+    destroy_native_comm()
     dist.destroy_process_group()
 
 
