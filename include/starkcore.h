@@ -254,7 +254,7 @@ int sc_merkle_query_multi_dev(uint64_t n, const sc_merkle_t* const* trees, const
  * a tree whose level 0 is given digests, and the fold of fri.py:85 on a rank's column slab [rows][cols] of the codeword
  * viewed as a rows x R matrix (index i = row*R + col_base + col; the partner i + N/2 is row + rows/2 of the same slab) */
 int sc_merkle_level_copy_dev(const sc_merkle_t* tree, int level, void* d_out, void* stream);
-int sc_merkle_from_digests_dev(const void* d_digests, uint64_t count, uint8_t root_out[64], sc_merkle_t** tree, void* stream);
+int sc_merkle_from_digests_dev(const void* d_digests, uint64_t count, uint8_t root_out[64], sc_merkle_t** tree, void* stream); /* root_out NULL: only enqueued, sc_merkle_root waits */
 int sc_fri_fold_slab_dev(const void* d_in, uint64_t rows, uint64_t cols, uint64_t R, uint64_t col_base, const uint64_t alpha[2], const uint64_t offset[2],
                          const uint64_t omega[2], void* d_out, void* stream);
 uint64_t sc_merkle_leaves(const sc_merkle_t* tree);

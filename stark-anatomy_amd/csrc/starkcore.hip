@@ -2472,7 +2472,28 @@ int sc_merkle_from_digests_dev(const void* d_digests, uint64_t count, uint8_t ro
     const size_t tree_bytes = (2 * count - 1) * 64;
     HIPCHK(pool_alloc((void**)&levels, tree_bytes));
     hipError_t e = hipMemcpyAsync(levels, d_digests, count * 64, hipMemcpyDeviceToDevice, st);
-    int rc = (e == hipSuccess) ? merkle_finish(levels, count, st) : fail(SC_ERR_HIP, hipGetErrorString(e));
+    if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    // root_out == NULL: asynchronous like sc_merkle_build_async_dev -- the root travels to a pinned slot behind the build and
+    // sc_merkle_root polls for it (a blocking stream wait that has gone to sleep costs tens of microseconds to wake up)
+    const int slot = root_out ? -1 : root_slot_get();
+    if (slot >= 0) {
+        const uint64_t seq = ++g.root_seq;
+        volatile uint64_t* host = (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * slot);
+        bool published = false;
+        int rc = merkle_climb(levels, count, 0, st, host, seq, &published);
+        if (rc == SC_OK && !published) {
+            hipLaunchKernelGGL(root_publish_kernel, dim3(1), dim3(64), 0, st, (const uint64_t*)(levels + 8 * (2 * count - 2)), host, seq);
+            if (hipGetLastError() != hipSuccess) rc = fail(SC_ERR_HIP, "root publish launch failed");
+        }
+        if (rc != SC_OK) { (void)hipStreamSynchronize(st); g.free_root_slots.push_back(slot); pool_free(levels, tree_bytes); return rc; }
+        sc_merkle* t = new sc_merkle{levels, count, ilog2(count)};
+        t->slot = slot; t->seq = seq; t->st = st;
+        *tree = t;
+        return SC_OK;
+    }
+    uint8_t root_tmp[64];
+    if (!root_out) root_out = root_tmp;
+    int rc = merkle_finish(levels, count, st);
     if (rc == SC_OK) {
         e = hipMemcpyAsync(root_out, levels + 8 * (2 * count - 2), 64, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);

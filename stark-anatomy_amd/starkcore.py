@@ -446,11 +446,11 @@ class MerkleTree:
 
     @classmethod
     def from_digests_ptr(cls, ptr, count, stream=None):
-        """tree whose level 0 is `count` given 64-byte digests at a raw device pointer"""
-        root = ctypes.create_string_buffer(64)
+        """tree whose level 0 is `count` given 64-byte digests at a raw device pointer; only enqueued: `.root` waits (polling the
+        pinned slot the root is published to)"""
         h = _vp()
-        _check(lib().sc_merkle_from_digests_dev(ptr, count, root, ctypes.byref(h), stream))
-        return cls(h, root.raw, count)
+        _check(lib().sc_merkle_from_digests_dev(ptr, count, None, ctypes.byref(h), stream))
+        return cls(h, None, count)
 
     def copy_level(self, level, dst_ptr, stream=None):
         """copy the (n >> level) digests of one level into caller-owned device memory"""
