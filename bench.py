@@ -475,6 +475,10 @@ def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4):
     if world == 1 and not args.force_diag_exchange:
         forms.append(("one rank: nothing to exchange, the column stage writes the rank's own block in place", {}))
     else:
+        if world > 1 and not args.force_diag_exchange:
+            # the most conservative form first (it is the reference the others are compared with): one plain all_to_all_single
+            # that carries the rank's own block as well
+            forms.append(("torch.distributed all_to_all_single, own block included", dict(always_exchange=True)))
         forms.append(("torch.distributed, one blocking exchange", dict(own)))
         forms.append(("torch.distributed, 4 asynchronous row blocks overlapped with the row stage", dict(own, overlap_chunks=4)))
         native = False

@@ -6,7 +6,7 @@ runs this.  Output: small JSON fixtures next to this file.  Only DATA is written
 regenerated from seeds, outputs stored in full for small sizes and as SHA-256 of the packed
 16-byte-LE output for larger ones).  No reference source is copied.
 
-usage:  python tests/golden/make_golden.py [--big]     (--big adds 2^18 / 2^20 NTT digests, minutes)
+usage:  python tests/golden/make_golden.py [--big] [--fri-big]     (--big adds 2^18 / 2^20 NTT digests, --fri-big 2^14 and 2^16 Fri.prove runs; minutes)
 """
 import hashlib
 import json
@@ -303,7 +303,9 @@ def gen_fri():
     out["test_fri_corrupt"] = {"top_level_indices": top2, "serialized_sha256": hashlib.sha256(ser2).hexdigest(), "serialized_len": len(ser2)}
 
     # synthetic LDE codewords: Fri(generator, omega, N, 4, s)
-    for (logN, s, seed) in [(6, 4, 4000), (10, 10, 4001), (12, 40, 4002)]:
+    # (--fri-big adds 2^14 and 2^16 codewords with the BASELINE number of colinearity checks: a minute of reference time, most of it
+    # Merkle.open rebuilding the tree for each opening)
+    for (logN, s, seed) in [(6, 4, 4000), (10, 10, 4001), (12, 40, 4002)] + ([(14, 40, 4003), (16, 40, 4004)] if "--fri-big" in sys.argv else []):
         N = 1 << logN
         om = field.primitive_nth_root(N)
         coeffs = fes(seed, N // 4)
@@ -383,7 +385,9 @@ def gen_stark():
 
 if __name__ == "__main__":
     big = "--big" in sys.argv
-    if "--stark" in sys.argv:
+    if "--fri-big" in sys.argv:
+        gen_fri()                  # fri.json again, with the 2^14 proof (the other records are reproduced identically)
+    elif "--stark" in sys.argv:
         gen_stark()
     elif "--poly" in sys.argv:
         gen_poly()
