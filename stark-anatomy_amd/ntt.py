@@ -29,12 +29,11 @@ def _require_main_field(field):
 
 
 def _pack(elements):
-    return b"".join(e.value.to_bytes(16, "little") for e in elements)
+    return _sc.pack(list(map(_sc._value_of, elements)))
 
 
 def _unpack(raw, count, field):
-    frm = int.from_bytes
-    return [FieldElement(frm(raw[16 * i:16 * i + 16], "little"), field) for i in range(count)]
+    return [FieldElement(v, field) for v in _sc.unpack(raw, count)]
 
 
 _verified_roots = set()       # (p, root, order) triples that already passed the two assertions below

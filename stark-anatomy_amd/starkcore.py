@@ -192,8 +192,13 @@ def fe_bytes(v):
 
 
 def pack(values):
-    """iterable of ints -> packed bytes."""
-    return b"".join(int(v).to_bytes(16, "little") for v in values)
+    """iterable of ints -> packed bytes (one C-level pass: int.to_bytes mapped over the values; anything that is not an int --
+    numpy scalars, for instance -- goes through int() first)."""
+    values = values if isinstance(values, (list, tuple)) else list(values)
+    try:
+        return b"".join(map(int.to_bytes, values, itertools.repeat(16), itertools.repeat("little")))
+    except TypeError:
+        return b"".join(int(v).to_bytes(16, "little") for v in values)
 
 
 def unpack(buf, count=None):
@@ -483,6 +488,9 @@ class MerkleTree:
             pass
 
 
+import operator as _operator
+
+_value_of = _operator.attrgetter("value")
 _FieldElement = None
 
 
@@ -522,7 +530,7 @@ class DeviceCodeword(Sequence):
     @classmethod
     def from_list(cls, values, field):
         values = list(values)
-        return cls(DeviceVector.from_ints(v.value for v in values), field, elements=values)
+        return cls(DeviceVector.from_ints(list(map(_value_of, values))), field, elements=values)
 
     def __len__(self):
         return self.vec.n
