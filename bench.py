@@ -361,7 +361,7 @@ def main():
         except Exception:       # noqa: BLE001  (no fixture: the round trip stays the guard)
             reference_sha = None
 
-    census = None
+    census = prover = None
     if sharded and world > 1 and not args.no_extras:
         # the whole config-5 pipeline on the same ranks, once warm and once timed (all ranks take part; rank 0 reports)
         try:
@@ -371,6 +371,11 @@ def main():
             census = census_record(times, info, lf, world, dist, backend, dev)
         except Exception as e:       # noqa: BLE001  side measurements never invalidate the headline
             census = {"error": repr(e)[:300]}
+        try:
+            # ... and configs[4] as a prover: ShardedFastStark.prove on the synthetic AIR (FRI domain 2^20; 2^14 on shared GPUs)
+            _, _, prover = stark_prove_measure(14 if shared_gpus else 20, 2, 1, rank, world, dev, dist, backend)
+        except Exception as e:       # noqa: BLE001
+            prover = {"error": repr(e)[:300]}
 
     # what N means for the work: the N > 1 default is the north_star's strong-scaling series (2^24 for every N; its N = 1 member is
     # extras.ntt_2p24_strong of the N = 1 run, whose headline stays BASELINE configs[1] = 2^20); --scaling weak / replicas: work per GPU fixed
@@ -421,6 +426,8 @@ def main():
                 out.setdefault("extras", {})["ntt_2p24_strong"] = strong_record(24, world, elapsed / args.steps, ok, corner_turn, out["config"]["all_to_all_bytes_sent_per_rank_per_step"])
         if census is not None:
             out.setdefault("extras", {})["stark_census_sharded"] = census
+        if prover is not None:
+            out.setdefault("extras", {})["stark_prove_sharded"] = prover
         if not args.no_extras and not sharded and world == 1:
             try:
                 out["extras"] = extras(sc, lib, stream)
@@ -593,18 +600,15 @@ def run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gp
     dist.destroy_process_group()
 
 
-def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shared_gpus):
-    """--workload stark_prove: one step = sharded_stark.ShardedFastStark.prove (reference code/fast_stark.py:76-178) from the
-    trace to the serialized proof, on the synthetic 2-register AIR (a, b) -> (b, a*a + b) with a 2^k-row randomized trace
-    (FRI domain 2^(k+4)); value = ms per proof (max over ranks).  Every rank must end with the same proof; rank 0 verifies it
-    with FastStark.verify outside the timed region."""
+def stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend):
+    """sharded_stark.ShardedFastStark.prove (reference code/fast_stark.py:76-178) on the synthetic 2-register AIR (a, b) -> (b, a*a + b)
+    with a 2^(log_fri - 4)-row randomized trace: (seconds summed over `steps` proofs, max over ranks per proof; record for rank 0).
+    Every rank must end with the same proof; rank 0 verifies it with FastStark.verify outside the timed region."""
     import hashlib
     import torch
     from algebra import Field, FieldElement
     from multivariate import MPolynomial
     from sharded_stark import ShardedFastStark
-    ngpu = torch.cuda.device_count()
-    log_fri = args.log2n or (16 if shared_gpus else 20)
     k, s = log_fri - 4, 40
     field = Field.main()
     T = (1 << k) - 4 * s
@@ -622,7 +626,6 @@ def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shar
     tz, layer, root = stark.preprocess()
     torch.cuda.synchronize()
     preprocess_s = time.perf_counter() - t0
-    steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 1))
     for _ in range(warmup):
         stark.prove(trace, air, boundary, tz, layer)
     dist.barrier()
@@ -643,18 +646,32 @@ def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shar
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     same_everywhere = bool(torch.equal(lo, hi))
+    rec = None
     if rank == 0:
         t0 = time.perf_counter()
         verifies = bool(stark.verify(proof, air, boundary, root))
         verify_s = time.perf_counter() - t0
+        rec = {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_%dgpu" % (k, log_fri, world), "log2n": log_fri, "world_size": world,
+               "registers": 2, "colinearity_checks": s, "expansion_factor": 4, "ms_per_proof": 1e3 * elapsed / steps,
+               "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace-domain polynomials replicated",
+               "proof_bytes": len(proof), "proof_sha256_16": digest.hex()[:16], "same_proof_on_every_rank": same_everywhere,
+               "verify_accepts": verifies, "verify_s": verify_s, "preprocess_s": preprocess_s, "runs_ms": [round(x * 1e3, 3) for x in t.tolist()]}
+    return elapsed, same_everywhere, rec
+
+
+def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shared_gpus):
+    """--workload stark_prove: one step = one ShardedFastStark.prove from the trace to the serialized proof (FRI domain 2^log2n,
+    default 2^20; 2^16 when the ranks share GPUs); value = ms per proof (max over ranks)."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    log_fri = args.log2n or (16 if shared_gpus else 20)
+    steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 1))
+    elapsed, same_everywhere, rec = stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend)
+    if rank == 0:
+        rec["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
         out = {"metric": "stark_prove_ms", "value": 1e3 * elapsed / steps, "unit": "ms", "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "u128", "data": "synthetic",
-               "config": {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_%dgpu" % (k, log_fri, world), "log2n": log_fri, "world_size": world,
-                          "registers": 2, "colinearity_checks": s, "expansion_factor": 4,
-                          "collective_backend": collective_label(backend, world, ngpu, shared_gpus),
-                          "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace-domain polynomials replicated",
-                          "proof_bytes": len(proof), "proof_sha256_16": digest.hex()[:16], "same_proof_on_every_rank": same_everywhere,
-                          "verify_accepts": verifies, "verify_s": verify_s, "preprocess_s": preprocess_s, "runs_ms": [round(x * 1e3, 3) for x in t.tolist()]}}
+               "config": rec}
         emit(out)
     dist.destroy_process_group()
     if not same_everywhere:

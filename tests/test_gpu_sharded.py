@@ -332,6 +332,9 @@ def test_bench_bare_launch_two_ranks_and_census_parity(sc):
     assert out["config"]["all_to_all_bytes_sent_per_rank_per_step"] == 2 * (1 << 15) * 16 // 2
     c2 = out["extras"]["stark_census_sharded"]
     assert "error" not in c2, c2
+    pr = out["extras"]["stark_prove_sharded"]                 # configs[4] as a prover, beside the census
+    assert "error" not in pr, pr
+    assert pr["verify_accepts"] is True and pr["same_proof_on_every_rank"] is True and pr["world_size"] == 2 and pr["ms_per_proof"] > 0
     for k in ("lde_and_commit_ms", "coset_divide_ms", "fri_prove_ms", "openings_ms", "total_ms"):
         assert c2[k] > 0
     assert c2["world_size"] == 2 and c2["all_to_all_bytes_sent_per_rank"] > 0
