@@ -2235,10 +2235,24 @@ int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2]
 }
 // ---- the Fiat-Shamir step on the host side of the library (csrc/transcript.h); no GPU needed
 static Fe sample_field(const uint8_t* bytes, size_t len) {
-    // Field.sample (algebra.py:116-120): the big-endian integer of the bytes, mod p
+    // Field.sample (algebra.py:116-120): the big-endian integer of the bytes, mod p -- 16 bytes at a time: a leading short
+    // chunk, then  acc <- acc * 2^128 + chunk  with acc * 2^128 = to_mont(acc) (one Montgomery product per 16 bytes; the
+    // commit loop samples 32 bytes between a root arriving and the next launch)
     Fe acc{0, 0};
-    const Fe k256{256, 0};
-    for (size_t i = 0; i < len; ++i) acc = fe_add(fe_mul(acc, k256), Fe{bytes[i], 0});
+    size_t i = 0;
+    size_t take = len % 16 ? len % 16 : (len ? 16 : 0);
+    while (i < len) {
+        uint64_t w[2] = {0, 0};
+        for (size_t k = 0; k < take; ++k) {
+            const size_t pos = take - 1 - k;                    // byte k of the chunk has weight 256^pos
+            w[pos >> 3] |= (uint64_t)bytes[i + k] << (8 * (pos & 7));
+        }
+        Fe c{w[0], w[1]};
+        if (fe_ge_p(c)) c = fe_sub(c, Fe{P_LO, P_HI});
+        acc = fe_add(i ? to_mont(acc) : acc, c);
+        i += take;
+        take = 16;
+    }
     return acc;
 }
 int sc_shake256(const void* in, uint64_t len, void* out, uint64_t out_len) {
