@@ -257,6 +257,11 @@ int sc_merkle_level_copy_dev(const sc_merkle_t* tree, int level, void* d_out, vo
 int sc_merkle_from_digests_dev(const void* d_digests, uint64_t count, uint8_t root_out[64], sc_merkle_t** tree, void* stream); /* root_out NULL: only enqueued, sc_merkle_root waits */
 int sc_fri_fold_slab_dev(const void* d_in, uint64_t rows, uint64_t cols, uint64_t R, uint64_t col_base, const uint64_t alpha[2], const uint64_t offset[2],
                          const uint64_t omega[2], void* d_out, void* stream);
+/* that fold AND the local Merkle subtree over the folded slab in one call (a round of the sharded Fri.commit, fri.py:73-88, on one
+ * rank): from 256 folded elements up the tree's leaf stage computes the fold itself; the tree is a *_noroot_dev tree (only
+ * enqueued; its sub-root level is read with sc_merkle_level_copy_dev on the same stream) */
+int sc_fri_fold_slab_build_dev(const void* d_in, uint64_t rows, uint64_t cols, uint64_t R, uint64_t col_base, const uint64_t alpha[2], const uint64_t offset[2],
+                               const uint64_t omega[2], void* d_out, sc_merkle_t** tree, void* stream);
 uint64_t sc_merkle_leaves(const sc_merkle_t* tree);
 int sc_merkle_free(sc_merkle_t* tree);
 

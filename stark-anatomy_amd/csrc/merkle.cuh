@@ -314,10 +314,15 @@ struct FoldIn {
     const Fe* lo;       // two-level power table of omega^-1
     const Fe* hi;
     Fe c_m;             // alpha / (2 * offset), Montgomery form
+    // a rank's column slab [rows][2^logcols] of a codeword that is a [rows][R] matrix (multi-GPU FRI): element i of the slab is
+    // codeword index (i >> logcols) * R + col_base + (i & (2^logcols - 1)); the defaults make that index i itself
+    int logcols = 63;
+    uint64_t R = 0, col_base = 0;
 };
 __device__ __forceinline__ Fe fold_element(const FoldIn& f, uint64_t i, uint64_t half) {
     const Fe a = f.in[i], b = f.in[i + half];
-    const Fe t = mont_mul(mont_mul(f.lo[i & 4095u], f.hi[i >> 12]), f.c_m);          // (c * w^-i) in Montgomery form
+    const uint64_t e = (i >> f.logcols) * f.R + f.col_base + (i & ((1ull << f.logcols) - 1ull));
+    const Fe t = mont_mul(mont_mul(f.lo[e & 4095u], f.hi[e >> 12]), f.c_m);          // (c * w^-e) in Montgomery form
     return fe_add(fe_half(fe_add(a, b)), mont_mul(fe_sub(a, b), t));
 }
 

@@ -2540,6 +2540,26 @@ int sc_fri_fold_slab_dev(const void* d_in, uint64_t rows, uint64_t cols, uint64_
     return SC_OK;
 }
 
+int sc_fri_fold_slab_build_dev(const void* d_in, uint64_t rows, uint64_t cols, uint64_t R, uint64_t col_base, const uint64_t alpha[2], const uint64_t offset[2],
+                               const uint64_t omega[2], void* d_out, sc_merkle_t** tree, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (!tree || !d_in || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (rows < 2 || !is_pow2(rows) || !is_pow2(cols) || !is_pow2(R) || col_base + cols > R) return fail(SC_ERR_BAD_ARG, "bad slab shape");
+    const uint64_t leaves = (rows / 2) * cols;
+    FoldIn f;
+    SCCHK(fold_prepare((const Fe*)d_in, rows * R, fe_from(alpha), fe_from(offset), fe_from(omega), (Fe*)d_out, st, &f));
+    f.logcols = ilog2(cols);
+    f.R = R;
+    f.col_base = col_base;
+    if (leaves >= 256) return merkle_build_device((const Fe*)d_out, leaves, nullptr, tree, st, BUILD_NOROOT, &f);
+    hipLaunchKernelGGL(fri_fold_slab_kernel, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, st, (const Fe*)d_in, (Fe*)d_out, rows / 2, f.logcols, R, col_base,
+                       f.lo, f.hi, f.c_m);
+    HIPCHK(hipGetLastError());
+    return merkle_build_device((const Fe*)d_out, leaves, nullptr, tree, st, BUILD_NOROOT);
+}
+
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out) { return sc_merkle_open_batch(tree, &index, 1, path_out); }
 uint64_t sc_merkle_leaves(const sc_merkle_t* tree) { return tree ? tree->N : 0; }
 int sc_merkle_free(sc_merkle_t* tree) {

@@ -494,6 +494,16 @@ def gather_natural(local, n_rows, n_cols, world, group=None):
 # =====================================================================================================================
 # FRI over the column-slab layout
 # =====================================================================================================================
+def _current_raw_stream(device):
+    """torch's current stream on `device` as a raw hipStream_t value (0 = the null stream); the raw getter costs a tenth of
+    building a torch.cuda.Stream object per engine call"""
+    getter = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if getter is not None:
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        return int(getter(index))
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
 class HipFriEngine:
     """Local FRI primitives on torch-owned slabs through the C-ABI (folds, Merkle trees, openings)."""
 
@@ -517,11 +527,11 @@ class HipFriEngine:
         """The primitives run on torch's CURRENT stream, so they are ordered with the tensor ops and collectives around them and
         need no synchronization of their own.  Only under torch's null stream (which the library cannot share) they run on the
         library stream between two explicit synchronizations."""
-        cur = torch.cuda.current_stream(self.device)
-        if cur.cuda_stream == 0:
-            cur.synchronize()
+        raw = _current_raw_stream(self.device)
+        if raw == 0:
+            torch.cuda.current_stream(self.device).synchronize()
             return None
-        return self.ctypes.c_void_p(cur.cuda_stream)
+        return self.ctypes.c_void_p(raw)
 
     def _done(self, sptr):
         if sptr is None:
@@ -556,6 +566,17 @@ class HipFriEngine:
         self._done(sptr)
         return dst
 
+    def fold_slab_tree(self, src, rows, cols, R, col_base, alpha, offset, omega):
+        """fold_slab AND the enqueue-only local subtree over the folded slab (the next round's `tree(slab, need_root=False)`) in
+        one library call: the tree's leaf stage computes the fold.  Returns (folded slab, tree); tree None under torch's null
+        stream (the caller builds it the plain way)."""
+        sptr = self._stream()
+        if sptr is None:
+            return self.fold_slab(src, rows, cols, R, col_base, alpha, offset, omega), None
+        dst = torch.empty((rows // 2, cols, 2), dtype=torch.int64, device=self.device)
+        tree = self.sc.MerkleTree.from_folded_slab(src.data_ptr(), rows, cols, R, col_base, _fe(alpha), _fe(offset), _fe(omega), dst.data_ptr(), sptr)
+        return dst, HipFriEngine._Tree(tree, dst)
+
     def fold_full(self, src, N, alpha, offset, omega):
         dst = torch.empty((N // 2, 2), dtype=torch.int64, device=self.device)
         sptr = self._stream()
@@ -574,33 +595,46 @@ class HipFriEngine:
         self._done(sptr)
         return out
 
-    def query_many(self, requests):
-        """[(tree, elems tensor or None, indices)] -> [(values as ints or None, authentication paths)]: every opening of every
-        layer in ONE library call and one launch (sc_merkle_query_multi_dev), instead of a device round trip per tree."""
+    def query_many(self, requests, raw_paths=False):
+        """[(tree, elems tensor or None, indices[, keep])] -> [(values as ints or None, authentication paths)]: every opening of
+        every layer in ONE library call and one launch (sc_merkle_query_multi_dev), instead of a device round trip per tree.
+        keep: only the first `keep` digests of each path are wanted (the part below a sharded commitment's sub-roots).
+        raw_paths: the paths of a request come back as ONE uint8 array [openings][64 * digests] instead of lists of bytes
+        objects (the sharded openings join two such parts per path before any object is made)."""
+        import numpy as np
         ct, sc = self.ctypes, self.sc
-        live = [(q, t, e, [int(i) for i in idx]) for q, (t, e, idx) in enumerate(requests) if len(idx)]
-        out = [(None if e is None else [], [[] for _ in idx]) for t, e, idx in requests]
+        requests = [(r[0], r[1], r[2], r[3] if len(r) > 3 else None) for r in requests]
+        live = [(q, t, e, idx if isinstance(idx, list) else list(idx), keep) for q, (t, e, idx, keep) in enumerate(requests) if len(idx)]
+        if raw_paths:
+            out = [(None if e is None else [], np.zeros((0, 0), dtype=np.uint8)) for t, e, idx, _ in requests]
+        else:
+            out = [(None if e is None else [], [[] for _ in idx]) for t, e, idx, _ in requests]
         if not live:
             return out
         torch.cuda.current_stream(self.device).synchronize()        # the library call runs on the library's stream
         n = len(live)
-        flat = [i for _, _, _, idx in live for i in idx]
+        flat = [i for _, _, _, idx, _ in live for i in idx]
         total = len(flat)
-        depths = [t.tree.depth for _, t, _, _ in live]
-        path_bytes = sum(64 * d * len(idx) for d, (_, _, _, idx) in zip(depths, live))
+        depths = [t.tree.depth for _, t, _, _, _ in live]
+        path_bytes = sum(64 * d * len(idx) for d, (_, _, _, idx, _) in zip(depths, live))
         elems_out = ct.create_string_buffer(16 * total)
         paths_out = ct.create_string_buffer(max(path_bytes, 64))
         # a tree over digests has no element vector: any readable pointer will do, the value is not used
-        ptrs = [(e if e is not None else t.keep).data_ptr() for _, t, e, _ in live]
-        sc._check(self.lib.sc_merkle_query_multi_dev(n, (ct.c_void_p * n)(*[t.tree._h for _, t, _, _ in live]), (ct.c_void_p * n)(*ptrs),
-                                                     (ct.c_uint64 * total)(*flat), (ct.c_uint64 * n)(*[len(idx) for _, _, _, idx in live]),
+        ptrs = [(e if e is not None else t.keep).data_ptr() for _, t, e, _, _ in live]
+        sc._check(self.lib.sc_merkle_query_multi_dev(n, (ct.c_void_p * n)(*[t.tree._h for _, t, _, _, _ in live]), (ct.c_void_p * n)(*ptrs),
+                                                     (ct.c_uint64 * total)(*flat), (ct.c_uint64 * n)(*[len(idx) for _, _, _, idx, _ in live]),
                                                      elems_out, paths_out))
         values = sc.unpack(elems_out.raw, total)
         view = memoryview(paths_out)
         vo = po = 0
-        for (q, t, e, idx), d in zip(live, depths):
+        for (q, t, e, idx, keep), d in zip(live, depths):
             k = len(idx)
-            out[q] = (values[vo:vo + k] if e is not None else None, sc._path_lists(view, po, d, k))
+            if raw_paths:
+                whole = np.frombuffer(view[po:po + 64 * k * d], dtype=np.uint8).reshape(k, 64 * d)
+                paths = whole if keep is None or keep >= d else whole[:, :64 * keep]
+            else:
+                paths = sc._path_lists(view, po, d, k, keep)
+            out[q] = (values[vo:vo + k] if e is not None else None, paths)
             vo += k
             po += 64 * k * d
         return out
@@ -652,18 +686,32 @@ class ShardedFri:
         dist.all_gather(parts, t, group=self.group)
         return torch.stack(parts, dim=0)
 
-    def _gather_answers(self, layout, mine):
+    def _gather_answers(self, layout, mine, sizes):
         """The owners' answers to the openings, merged with ONE fixed-shape tensor collective (no pickling, no object store).
         layout[r] = [(q, positions, ndigests)]: the runs rank r answers (one per request it owns something of), in the order it
         packs them -- every rank derives all of it from the public indices; `mine` = this rank's runs [(values, bottoms)] in that
-        order.  Returns {q: {pos: (value, [digests])}}.  Packing and unpacking are per run (numpy / struct), not per opening."""
+        order, bottoms = uint8 array [openings][64 * ndigests]; sizes[q] = number of openings of request q.  Returns
+        {q: (values, bottoms)}: a list and a uint8 array, both indexed by the position in the request.  No object per digest is
+        made here: the caller joins these path bottoms with the path tops first."""
         import numpy as np
         import starkcore as sc
         G, g = self.world, self.rank
         answers = {}
+
+        def place(q, positions, vals, bottoms):
+            if len(positions) == sizes[q]:                       # one owner for the whole request: its run IS the answer
+                answers[q] = (vals, bottoms)
+                return
+            have = answers.get(q)
+            if have is None:
+                have = answers[q] = ([None] * sizes[q], np.zeros((sizes[q], bottoms.shape[1]), dtype=np.uint8))
+            for pos, v in zip(positions, vals):
+                have[0][pos] = v
+            have[1][positions] = bottoms
+
         if G == 1:
             for (q, positions, nd), (vals, bottoms) in zip(layout[0], mine):
-                answers.setdefault(q, {}).update({pos: (v, list(b[:nd])) for pos, v, b in zip(positions, vals, bottoms)})
+                place(q, positions, vals, bottoms)
             return answers
         words = [sum(len(positions) * (2 + 8 * nd) for _, positions, nd in layout[r]) for r in range(G)]
         width = max(max(words), 1)
@@ -672,9 +720,9 @@ class ShardedFri:
         for (q, positions, nd), (vals, bottoms) in zip(layout[g], mine):
             k = len(positions)
             block = np.empty((k, 2 + 8 * nd), dtype=np.int64)
-            block[:, :2] = np.frombuffer(b"".join(int(v).to_bytes(16, "little") for v in vals), dtype=np.int64).reshape(k, 2)
+            block[:, :2] = np.frombuffer(sc.pack(vals), dtype=np.int64).reshape(k, 2)
             if nd:
-                block[:, 2:] = np.frombuffer(b"".join(d for b in bottoms for d in b[:nd]), dtype=np.int64).reshape(k, 8 * nd)
+                block[:, 2:] = np.ascontiguousarray(bottoms).view(np.int64)
             row[at:at + block.size] = block.reshape(-1)
             at += block.size
         assert at == words[g]
@@ -695,14 +743,28 @@ class ShardedFri:
                 block = rows[r, at:at + k * (2 + 8 * nd)].reshape(k, 2 + 8 * nd)
                 at += block.size
                 vals = sc.unpack(np.ascontiguousarray(block[:, :2]).tobytes(), k)
-                bottoms = sc._path_lists(memoryview(np.ascontiguousarray(block[:, 2:]).tobytes()), 0, nd, k)
-                answers.setdefault(q, {}).update({pos: (v, b) for pos, v, b in zip(positions, vals, bottoms)})
+                place(q, positions, vals, np.ascontiguousarray(block[:, 2:]).view(np.uint8))
         return answers
 
+    @staticmethod
+    def _joined_paths(bottoms, tops):
+        """authentication paths (lists of fresh 64-byte objects, merkle.py:16-27) from their two parts, each a uint8 array
+        [openings][64 * digests]: the part below the sub-roots (from the owner's local subtree) and the part above (from the
+        replicated top tree); one pass over one buffer makes all the objects"""
+        import numpy as np
+        import starkcore as sc
+        k = bottoms.shape[0]
+        if tops is not None and tops.shape[0] == k and tops.shape[1]:
+            bottoms = np.concatenate((bottoms, tops), axis=1)
+        depth = bottoms.shape[1] // 64
+        return sc._path_lists(memoryview(np.ascontiguousarray(bottoms)).cast("B"), 0, depth, k)
+
     # -- layers -----------------------------------------------------------------------------------
-    def _commit_sharded(self, slab, C):
+    def _commit_sharded(self, slab, C, local=None):
+        """local: the rank's subtree over `slab` if the fold that produced the slab has built it already (fold_slab_tree)"""
         eng, G, Rw = self.engine, self.world, self.Rw
-        local = eng.tree(slab, need_root=False)
+        if local is None:
+            local = eng.tree(slab, need_root=False)
         sub_level = Rw.bit_length() - 1
         sub = eng.level(local, sub_level)                                   # [C][8]: one sub-root per row
         top_leaves = self._all_gather(sub).permute(1, 0, 2).contiguous()    # natural order: node (row, rank)
@@ -731,14 +793,18 @@ class ShardedFri:
                 where.append(("local", len(asks)))
                 asks.append((layer["tree"], layer["vec"], list(indices)))
                 continue
-            mine = [(pos, i) for pos, i in enumerate(indices) if (i % R) // Rw == g]
-            where.append(("sharded", len(asks), mine))
-            asks.append((layer["local"], layer["slab"], [(i // R) * Rw + (i % R) % Rw for _, i in mine]))
+            mine = [i for i in indices if (i % R) // Rw == g] if G > 1 else indices
+            where.append(("sharded", len(asks)))
+            asks.append((layer["local"], layer["slab"], [(i // R) * Rw + (i % R) % Rw for i in mine], sub_level))
             asks.append((layer["top"], None, [(i // R) * G + (i % R) // Rw for i in indices] if layer["C"] * G > 1 else []))
-        got = eng.query_many(asks)
-        layout, mine = [[] for _ in range(G)], []
+        got = eng.query_many(asks, raw_paths=True)
+        layout, mine, sizes = [[] for _ in range(G)], [], [len(indices) for _, indices in requests]
         for q, ((layer, indices), w) in enumerate(zip(requests, where)):
-            if w[0] == "local":
+            if w[0] == "local" or not indices:
+                continue
+            if G == 1:
+                layout[0].append((q, range(len(indices)), sub_level))
+                mine.append(got[w[1]])
                 continue
             owners = [[] for _ in range(G)]
             for pos, i in enumerate(indices):
@@ -748,29 +814,35 @@ class ShardedFri:
                     layout[r].append((q, owners[r], sub_level))
             if owners[g]:
                 mine.append(got[w[1]])
-        answers = self._gather_answers(layout, mine) if any(layout) else {}
+        answers = self._gather_answers(layout, mine, sizes) if any(layout) else {}
         out = []
         for q, ((layer, indices), w) in enumerate(zip(requests, where)):
             if w[0] == "local":
                 vals, paths = got[w[1]]
-                out.append((vals, paths if layer["length"] > 1 else [[] for _ in indices]))
+                out.append((vals, self._joined_paths(paths, None) if layer["length"] > 1 and len(indices) else [[] for _ in indices]))
                 continue
-            tops = got[w[1] + 1][1] if layer["C"] * G > 1 else [[] for _ in indices]
-            have = answers.get(q, {})
-            out.append(([have[pos][0] for pos in range(len(indices))], [have[pos][1] + list(t) for pos, t in zip(range(len(indices)), tops)]))
+            if q not in answers:
+                out.append(([], []))
+                continue
+            vals, bottoms = answers[q]
+            out.append((vals, self._joined_paths(bottoms, got[w[1] + 1][1] if layer["C"] * G > 1 else None)))     # below the sub-roots + above them
         return out
 
     def _open_many(self, requests):
         """entries as FieldElement objects (one object per index and layer, reused) + fresh path objects per request"""
         from algebra import FieldElement
-        res = []
+        res, field, new = [], self.fri.field, object.__new__
         for (layer, indices), (values, paths) in zip(requests, self._open_many_raw(requests)):
-            cache, ents = layer["cache"], []
+            cache = layer["cache"]
             for i, v in zip(indices, values):
                 if i not in cache:
-                    cache[i] = FieldElement(v, self.fri.field)
-                ents.append(cache[i])
-            res.append((ents, paths))
+                    # FieldElement(v, field) without the call into __init__ (algebra.py:16-18 sets exactly these two attributes),
+                    # as in starkcore.DeviceCodeword._entries
+                    e = new(FieldElement)
+                    e.value = v
+                    e.field = field
+                    cache[i] = e
+            res.append(([cache[i] for i in indices], paths))
         return res
 
     def _open(self, layer, indices):
@@ -784,14 +856,15 @@ class ShardedFri:
         C = N // R
         assert tuple(slab.shape) == (C, Rw, 2), "slab must be this rank's [C][R/G] columns"
         omega, offset, rounds = fr.omega, fr.offset, fr.num_rounds()
-        layers, cur, full = [], slab, None
+        layers, cur, full, local = [], slab, None, None
+        # fri.py:68 in every round: omega_r^(N_r) == 1 with omega_r = omega^(2^r), N_r = N / 2^r -- one condition, checked once
+        assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
         for r in range(rounds):
             Nr = N >> r
-            assert(omega ^ (Nr - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
             if full is None and C == 1:
                 full = self._natural(cur, 1)                # one row left: collect it everywhere, go local
             if full is None:
-                layer = self._commit_sharded(cur, C)
+                layer = self._commit_sharded(cur, C, local)
             else:
                 tree = eng.tree(full)
                 layer = {"kind": "local", "vec": full, "tree": tree, "root": tree.root, "length": Nr, "cache": {}}
@@ -801,7 +874,10 @@ class ShardedFri:
                 break
             alpha = field.sample(proof_stream.prover_fiat_shamir())
             if full is None:
-                cur = eng.fold_slab(cur, C, Rw, R, self.rank * Rw, alpha.value, offset.value, omega.value)
+                if C > 2 and hasattr(eng, "fold_slab_tree"):          # the folded slab is committed to as a slab again: fold + subtree in one call
+                    cur, local = eng.fold_slab_tree(cur, C, Rw, R, self.rank * Rw, alpha.value, offset.value, omega.value)
+                else:
+                    cur, local = eng.fold_slab(cur, C, Rw, R, self.rank * Rw, alpha.value, offset.value, omega.value), None
                 C //= 2
             else:
                 full = eng.fold_full(full, Nr, alpha.value, offset.value, omega.value)
@@ -838,16 +914,22 @@ class ShardedFri:
                 request += per_round[j - 1][:s]
             requests.append((layer, request))
         fetched = self._open_many(requests)                 # one collective for the whole query phase
+        # pushes in the reference's order (fri.py:104-113 per round: s triples, then per test the paths of a, b, c); a ProofStream's
+        # `push` is `objects.append`, so a whole round goes in with two list extensions (as in fri.Fri._query_all)
+        from ip import ProofStream
+        objects = proof_stream.objects if type(proof_stream) is ProofStream else None
         for i in range(nq):
             entries, paths = fetched[i]
             next_entries, next_paths = fetched[i + 1]
             c_at = 2 * s if i + 1 < nq else 0
-            for t in range(s):
-                proof_stream.push((entries[t], entries[s + t], next_entries[c_at + t]))
-            for t in range(s):
-                proof_stream.push(paths[t])
-                proof_stream.push(paths[s + t])
-                proof_stream.push(next_paths[c_at + t])
+            triples = list(zip(entries[:s], entries[s:2 * s], next_entries[c_at:c_at + s]))
+            openings = [p for trio in zip(paths[:s], paths[s:2 * s], next_paths[c_at:c_at + s]) for p in trio]
+            if objects is not None:
+                objects.extend(triples)
+                objects.extend(openings)
+            else:
+                for obj in triples + openings:
+                    proof_stream.push(obj)
         return top_level_indices
 
 
@@ -896,15 +978,14 @@ class ContiguousFri(ShardedFri):
 
     def _open_many_raw(self, requests):
         eng, g = self.engine, self.rank
-        asks, owned = [], []
+        asks = []
         for layer, indices in requests:
             seg = layer["seg"]
-            mine = [(pos, i) for pos, i in enumerate(indices) if i // seg == g]
-            owned.append(mine)
-            asks.append((layer["local"], layer["vec"], [i % seg for _, i in mine]) if mine else (None, None, []))
+            mine = [i % seg for i in indices if i // seg == g]
+            asks.append((layer["local"], layer["vec"], mine, seg.bit_length() - 1) if mine else (None, None, []))
             asks.append((layer["top"], None, [i // seg for i in indices] if layer["active"] > 1 else []))
-        got = eng.query_many(asks)
-        layout, mine = [[] for _ in range(self.world)], []
+        got = eng.query_many(asks, raw_paths=True)
+        layout, mine, sizes = [[] for _ in range(self.world)], [], [len(indices) for _, indices in requests]
         for q, (layer, indices) in enumerate(requests):
             seg = layer["seg"]
             owners = [[] for _ in range(self.world)]
@@ -915,12 +996,14 @@ class ContiguousFri(ShardedFri):
                     layout[r].append((q, owners[r], seg.bit_length() - 1))
             if owners[g]:
                 mine.append(got[2 * q])
-        answers = self._gather_answers(layout, mine)
+        answers = self._gather_answers(layout, mine, sizes)
         out = []
         for q, (layer, indices) in enumerate(requests):
-            tops = got[2 * q + 1][1] if layer["active"] > 1 else [[] for _ in indices]
-            have = answers.get(q, {})
-            out.append(([have[pos][0] for pos in range(len(indices))], [have[pos][1] + list(t) for pos, t in zip(range(len(indices)), tops)]))
+            if q not in answers:
+                out.append(([], []))
+                continue
+            vals, bottoms = answers[q]
+            out.append((vals, self._joined_paths(bottoms, got[2 * q + 1][1] if layer["active"] > 1 else None)))
         return out
 
     def prove(self, slab, proof_stream):
@@ -930,9 +1013,9 @@ class ContiguousFri(ShardedFri):
         assert tuple(slab.shape) == (N // G, 2), "slab must be this rank's N/G consecutive elements"
         omega, offset, rounds = fr.omega, fr.offset, fr.num_rounds()
         layers, cur, active = [], slab, G
+        assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"     # every round's fri.py:68
         for r in range(rounds):
             Nr = N >> r
-            assert(omega ^ (Nr - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
             layer = self._commit_contiguous(cur, Nr, active)
             layers.append(layer)
             proof_stream.push(layer["root"])

@@ -89,6 +89,7 @@ SIGNATURES = {
     "sc_merkle_level_copy_dev": (_int, [_vp, _int, _vp, _vp]),
     "sc_merkle_from_digests_dev": (_int, [_vp, _u64, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_fri_fold_slab_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "sc_fri_fold_slab_build_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_merkle_leaves": (_u64, [_vp]),
     "sc_merkle_free": (_int, [_vp]),
     "sc_mpoly_eval_dev": (_int, [_vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
@@ -368,21 +369,23 @@ class PolyTree:
 _struct_cache = {}
 
 
-def _digest_struct(count):
+def _digest_struct(count, skipped=0):
     import struct
-    st = _struct_cache.get(count)
+    st = _struct_cache.get((count, skipped))
     if st is None:
-        st = _struct_cache[count] = struct.Struct("64s" * count)
+        st = _struct_cache[(count, skipped)] = struct.Struct("64s" * count + ("%dx" % (64 * skipped) if skipped else ""))
     return st
 
 
-def _path_lists(view, offset, depth, k):
+def _path_lists(view, offset, depth, k, keep=None):
     """k authentication paths of `depth` 64-byte digests each, packed back to back in `view` from byte `offset`, as the
     reference's lists of fresh bytes objects (merkle.py:16-27).  One C-level pass per tree: the ~25 000 digest objects of a
-    2^22 Fri.prove are the largest host cost of its query phase."""
-    if depth == 0:
+    2^22 Fri.prove are the largest host cost of its query phase.  keep < depth: only the first `keep` digests of every path
+    become objects (the part of a path below a sharded commitment's sub-roots)."""
+    keep = depth if keep is None else min(keep, depth)
+    if keep == 0:
         return [[] for _ in range(k)]
-    return list(map(list, _digest_struct(depth).iter_unpack(view[offset:offset + 64 * k * depth])))
+    return list(map(list, _digest_struct(keep, depth - keep).iter_unpack(view[offset:offset + 64 * k * depth])))
 
 
 class MerkleTree:
@@ -448,6 +451,14 @@ class MerkleTree:
         h = _vp()
         _check(lib().sc_merkle_build_noroot_dev(ptr, n, ctypes.byref(h), stream))
         return cls(h, None, n)
+
+    @classmethod
+    def from_folded_slab(cls, src_ptr, rows, cols, R, col_base, alpha, offset, omega, dst_ptr, stream=None):
+        """the fold of fri.py:85 on a rank's column slab [rows][cols] (sc_fri_fold_slab_dev) AND the enqueue-only local subtree
+        over the folded slab, in one library call: the tree's leaf stage computes the fold (alpha, offset, omega: packed bytes)"""
+        h = _vp()
+        _check(lib().sc_fri_fold_slab_build_dev(src_ptr, rows, cols, R, col_base, alpha, offset, omega, dst_ptr, ctypes.byref(h), stream))
+        return cls(h, None, (rows // 2) * cols)
 
     @classmethod
     def from_digests_ptr(cls, ptr, count, stream=None):

@@ -248,9 +248,19 @@ class OracleFriEngine:
         raw = po.C.coset_evaluate(coeffs, len(coeffs) // 16, offset, generator, order)
         return torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(order, 2).copy())
 
-    def query_many(self, requests):
-        """[(tree, elems or None, indices)] -> [(values or None, paths)] (the HIP engine answers all of them in one library call)"""
-        return [((self.read(e, idx) if e is not None else None), (t.open(idx) if t is not None else [])) for t, e, idx in requests]
+    def query_many(self, requests, raw_paths=False):
+        """[(tree, elems or None, indices[, keep])] -> [(values or None, paths cut to their first `keep` digests)] (the HIP engine
+        answers all of them in one library call)"""
+        out = []
+        for req in requests:
+            t, e, idx = req[:3]
+            keep = req[3] if len(req) > 3 else None
+            paths = [list(p) if keep is None else list(p[:keep]) for p in t.open(idx)] if t is not None else []
+            if raw_paths:
+                width = 64 * len(paths[0]) if paths else 0
+                paths = np.frombuffer(b"".join(d for p in paths for d in p), dtype=np.uint8).reshape(len(paths), width)
+            out.append(((self.read(e, idx) if e is not None else None), paths))
+        return out
 
     def read(self, elems, flat_indices):
         a = elems.contiguous().numpy().view(np.uint64).reshape(-1, 2)

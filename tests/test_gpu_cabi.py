@@ -467,6 +467,20 @@ def test_sharded_merkle_and_fold_primitives(sc):
     sc.synchronize()
     want = np.frombuffer(C.fold(data, N, alpha, po.GENERATOR, omega), dtype=np.uint64).reshape(rows // 2, R, 2)[:, col_base:col_base + cols, :]
     assert dst.to_bytes() == np.ascontiguousarray(want).tobytes()
+    # the same fold with the local subtree over the folded slab built by the same call (sc_fri_fold_slab_build_dev): the fused
+    # leaf stage (512 leaves here) and, with a narrower slab, the separate fold kernel in front of a small tree (128 leaves)
+    for cols2 in (cols, 4):
+        slab2 = np.ascontiguousarray(full[:, col_base:col_base + cols2, :])
+        want2 = np.ascontiguousarray(np.frombuffer(C.fold(data, N, alpha, po.GENERATOR, omega), dtype=np.uint64).reshape(rows // 2, R, 2)[:, col_base:col_base + cols2, :]).tobytes()
+        src2 = sc.DeviceVector.from_bytes(slab2.tobytes())
+        dst2 = sc.DeviceVector(rows // 2 * cols2)
+        built = sc.MerkleTree.from_folded_slab(src2.ptr, rows, cols2, R, col_base, sc.fe_bytes(alpha), sc.fe_bytes(po.GENERATOR), sc.fe_bytes(omega), dst2.ptr, None)
+        sc.synchronize()
+        assert dst2.to_bytes() == want2, cols2
+        leaves = rows // 2 * cols2
+        assert built.n == leaves
+        assert built.root == C.merkle_tree(want2, leaves)[-64:], cols2
+        assert built.open(3) == C.merkle_open(want2, leaves, 3), cols2
 
 
 def test_query_multi_and_mpoly_eval(sc):

@@ -29,5 +29,21 @@ b2 = 1e9
 for _ in range(4):
     ps2 = ProofStream(); t0 = time.perf_counter(); fr.prove(sc.DeviceCodeword(cw.vec, field), ps2); b2 = min(b2, time.perf_counter() - t0)
 print("plain prove ms", round(b2 * 1e3, 3), "same proof", ps.serialize() == ps2.serialize())
+# commit phase / query phase split of the sharded path (the query phase starts when _query_all is entered)
+marks = {}
+inner = ShardedFri._query_all
+def timed_query(self, layers, last_list, proof_stream):
+    marks["q0"] = time.perf_counter(); out = inner(self, layers, last_list, proof_stream); marks["q1"] = time.perf_counter(); return out
+ShardedFri._query_all = timed_query
+split = []
+for _ in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); ShardedFri(fr, R, 0, 1, dev).prove(slab, ProofStream())
+    split.append((marks["q0"] - t0, marks["q1"] - marks["q0"]))
+c, q = min(split, key=sum)
+print("sharded phases ms: commit (incl. last codeword)", round(c * 1e3, 3), "query", round(q * 1e3, 3))
+ShardedFri._query_all = inner
 pr = cProfile.Profile(); pr.enable(); ShardedFri(fr, R, 0, 1, dev).prove(slab, ProofStream()); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+rows = sorted(pstats.Stats(pr).stats.items(), key=lambda kv: -kv[1][3])[:34]      # by cumulative time, in microseconds
+print("%8s %10s %10s  %s" % ("calls", "own us", "cum us", "function"))
+for (fn, line, name), (cc, nc, tt, ct, _) in rows:
+    print("%8d %10.0f %10.0f  %s:%d(%s)" % (nc, tt * 1e6, ct * 1e6, os.path.basename(fn), line, name))
