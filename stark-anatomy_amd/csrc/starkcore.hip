@@ -1746,13 +1746,16 @@ static int rccl_exchange(const sc_fourstep* p, int dirn, const Fe* send, Fe* rec
     const sc_fourstep::Dir& d = p->dir[dirn];
     const uint64_t G = (uint64_t)p->world, rw = d.R / G, cw = d.C / G;
     RCCLCHK(rccl.GroupStart());
-    for (uint64_t h = 0; h < G; ++h) {
+    int bad = 0;                                       // a failed call still closes the group: nothing is left half-open
+    for (uint64_t h = 0; h < G && !bad; ++h) {
         if ((int)h == p->rank) continue;
         const uint64_t off = (h * rw + row0) * cw;
-        RCCLCHK(rccl.Send(send + off, nrows * cw * sizeof(Fe), 1 /* ncclUint8 */, (int)h, g_comm, st));
-        RCCLCHK(rccl.Recv(recv + off, nrows * cw * sizeof(Fe), 1 /* ncclUint8 */, (int)h, g_comm, st));
+        bad = rccl.Send(send + off, nrows * cw * sizeof(Fe), 1 /* ncclUint8 */, (int)h, g_comm, st);
+        if (!bad) bad = rccl.Recv(recv + off, nrows * cw * sizeof(Fe), 1 /* ncclUint8 */, (int)h, g_comm, st);
     }
-    RCCLCHK(rccl.GroupEnd());
+    const int ended = rccl.GroupEnd();
+    RCCLCHK(bad);
+    RCCLCHK(ended);
     return SC_OK;
 }
 

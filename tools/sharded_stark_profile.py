@@ -26,5 +26,9 @@ tz, layer, root = stark.preprocess()
 for _ in range(2):
     t0 = time.perf_counter(); proof = stark.prove(trace, air, boundary, tz, layer); torch.cuda.synchronize(); print("prove ms", round((time.perf_counter() - t0) * 1e3, 2))
 pr = cProfile.Profile(); pr.enable(); stark.prove(trace, air, boundary, tz, layer); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(12)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
+stats = pstats.Stats(pr).stats
+for title, key in (("by own time", 2), ("by cumulative time", 3)):
+    print(title)
+    print("%8s %10s %10s  %s" % ("calls", "own us", "cum us", "function"))
+    for (fn, line, name), row in sorted(stats.items(), key=lambda kv: -kv[1][key])[:28 if key == 2 else 45]:
+        print("%8d %10.0f %10.0f  %s:%d(%s)" % (row[1], row[2] * 1e6, row[3] * 1e6, os.path.basename(fn), line, name))
