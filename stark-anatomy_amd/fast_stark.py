@@ -45,33 +45,32 @@ def device_powers(base, count):
 
 class FastStark:
     def __init__(self, field, expansion_factor, num_colinearity_checks, security_level, num_registers, num_cycles, transition_constraints_degree=2):
-        assert(len(bin(field.p)) - 2 >= security_level), "p must have at least as many bits as security level"
+        assert(field.p.bit_length() >= security_level), "p must have at least as many bits as security level"
         assert(expansion_factor & (expansion_factor - 1) == 0), "expansion factor must be a power of 2"
         assert(expansion_factor >= 4), "expansion factor must be 4 or greater"
         assert(num_colinearity_checks * 2 >= security_level), "number of colinearity checks must be at least half of security level"
 
-        self.field = field
-        self.expansion_factor = expansion_factor
-        self.num_colinearity_checks = num_colinearity_checks
-        self.security_level = security_level
+        # parameters (names are the reference's, fast_stark.py:14-35: callers read them)
+        self.field, self.security_level = field, security_level
+        self.expansion_factor, self.num_colinearity_checks = expansion_factor, num_colinearity_checks
+        self.num_registers, self.original_trace_length = num_registers, num_cycles
         self.num_randomizers = 4 * num_colinearity_checks
-        self.num_registers = num_registers
-        self.original_trace_length = num_cycles
-        self.randomized_trace_length = self.original_trace_length + self.num_randomizers
-        # smallest power of two strictly above randomized_trace_length * constraint degree (fast_stark.py:27)
-        self.omicron_domain_length = 1 << len(bin(self.randomized_trace_length * transition_constraints_degree)[2:])
+        self.randomized_trace_length = num_cycles + self.num_randomizers
+
+        # domains: the trace lives on <omicron>, the smallest power-of-two subgroup strictly larger than the degree of the AIR
+        # substituted into the trace polynomials; FRI runs on the coset generator * <omega>, expansion_factor times larger
+        self.omicron_domain_length = 1 << max(1, (self.randomized_trace_length * transition_constraints_degree).bit_length())
         self.fri_domain_length = self.omicron_domain_length * expansion_factor
-
-        self.generator = self.field.generator()
-        self.omega = self.field.primitive_nth_root(self.fri_domain_length)
-        self.omicron = self.field.primitive_nth_root(self.omicron_domain_length)
+        self.generator = field.generator()
+        self.omega = field.primitive_nth_root(self.fri_domain_length)
+        self.omicron = field.primitive_nth_root(self.omicron_domain_length)
         # omicron^i for i < omicron_domain_length (fast_stark.py:33), by running product instead of one exponentiation per entry
-        self.omicron_domain, acc = [], self.field.one()
+        self.omicron_domain, power = [], field.one()
         for _ in range(self.omicron_domain_length):
-            self.omicron_domain.append(acc)
-            acc = acc * self.omicron
+            self.omicron_domain.append(power)
+            power = power * self.omicron
 
-        self.fri = Fri(self.generator, self.omega, self.fri_domain_length, self.expansion_factor, self.num_colinearity_checks)
+        self.fri = Fri(self.generator, self.omega, self.fri_domain_length, expansion_factor, num_colinearity_checks)
 
     # -- preprocessing (fast_stark.py:36-40) ------------------------------------------------------
     def preprocess(self):
@@ -96,29 +95,39 @@ class FastStark:
 
     # -- degree bookkeeping (fast_stark.py:42-56) ---------------------------------------------------
     def transition_degree_bounds(self, transition_constraints):
-        point_degrees = [1] + [self.original_trace_length + self.num_randomizers - 1] * 2 * self.num_registers
-        return [max(sum(r * l for r, l in zip(point_degrees, k)) for k, v in a.dictionary.items()) for a in transition_constraints]
+        """degree bound of every AIR polynomial once X (degree 1) and the 2 * num_registers trace polynomials (current and next
+        row, degree randomized_trace_length - 1 each) are substituted for its variables: the worst monomial decides"""
+        trace_degree = self.randomized_trace_length - 1
+        variables = 1 + 2 * self.num_registers
+        bounds = []
+        for constraint in transition_constraints:
+            monomial_degrees = [sum(exponents[:1]) + trace_degree * sum(exponents[1:variables]) for exponents in constraint.dictionary]
+            bounds.append(max(monomial_degrees))
+        return bounds
 
     def transition_quotient_degree_bounds(self, transition_constraints):
-        return [d - (self.original_trace_length - 1) for d in self.transition_degree_bounds(transition_constraints)]
+        # the transition zerofier vanishes on the first original_trace_length - 1 points of <omicron>
+        zerofier_degree = self.original_trace_length - 1
+        return [bound - zerofier_degree for bound in self.transition_degree_bounds(transition_constraints)]
 
     def max_degree(self, transition_constraints):
-        md = max(self.transition_quotient_degree_bounds(transition_constraints))
-        return (1 << (len(bin(md)[2:]))) - 1
+        # one less than the next power of two above the largest quotient bound (fast_stark.py:50-52)
+        largest = max(self.transition_quotient_degree_bounds(transition_constraints))
+        return (1 << max(1, largest.bit_length())) - 1
+
+    def _boundary_points(self, boundary, register):
+        """(domain points, values) of the boundary conditions (cycle, register, value) that concern `register`"""
+        mine = [(cycle, value) for cycle, reg, value in boundary if reg == register]
+        return [self.omicron ^ cycle for cycle, _ in mine], [value for _, value in mine]
 
     def boundary_zerofiers(self, boundary):
-        return [Polynomial.zerofier_domain([self.omicron ^ c for c, r, v in boundary if r == s]) for s in range(self.num_registers)]
+        return [Polynomial.zerofier_domain(self._boundary_points(boundary, s)[0]) for s in range(self.num_registers)]
 
     def boundary_interpolants(self, boundary):
-        interpolants = []
-        for s in range(self.num_registers):
-            points = [(c, v) for c, r, v in boundary if r == s]
-            interpolants.append(Polynomial.interpolate_domain([self.omicron ^ c for c, v in points], [v for c, v in points]))
-        return interpolants
+        return [Polynomial.interpolate_domain(*self._boundary_points(boundary, s)) for s in range(self.num_registers)]
 
     def boundary_quotient_degree_bounds(self, randomized_trace_length, boundary):
-        randomized_trace_degree = randomized_trace_length - 1
-        return [randomized_trace_degree - bz.degree() for bz in self.boundary_zerofiers(boundary)]
+        return [(randomized_trace_length - 1) - zerofier.degree() for zerofier in self.boundary_zerofiers(boundary)]
 
     def sample_weights(self, number, randomness):
         # bytes(i) is i zero bytes (fast_stark.py:74)
@@ -247,75 +256,72 @@ class FastStark:
 
     # -- verifier (fast_stark.py:180-286) -----------------------------------------------------------
     def verify(self, proof, transition_constraints, boundary, transition_zerofier_root, proof_stream=None):
-        original_trace_length = 1 + max(c for c, r, v in boundary)
-        randomized_trace_length = original_trace_length + self.num_randomizers
+        stream = (ProofStream() if proof_stream == None else proof_stream).deserialize(proof)
+        registers = range(self.num_registers)
+        trace_rows = 1 + max(cycle for cycle, _, _ in boundary) + self.num_randomizers
 
-        if proof_stream == None:
-            proof_stream = ProofStream()
-        proof_stream = proof_stream.deserialize(proof)
+        # the commitments, and the combination weights they determine
+        quotient_roots = [stream.pull() for _ in registers]
+        randomizer_root = stream.pull()
+        weights = self.sample_weights(1 + 2 * len(transition_constraints) + 2 * self.num_registers, stream.verifier_fiat_shamir())
 
-        boundary_quotient_roots = [proof_stream.pull() for s in range(self.num_registers)]
-        randomizer_root = proof_stream.pull()
-        interpolants = self.boundary_interpolants(boundary)
-        zerofiers = self.boundary_zerofiers(boundary)
-        weights = self.sample_weights(1 + 2 * len(transition_constraints) + 2 * len(interpolants), proof_stream.verifier_fiat_shamir())
-
-        polynomial_values = []
-        verifier_accepts = self.fri.verify(proof_stream, polynomial_values)
-        polynomial_values.sort(key=lambda iv: iv[0])
-        if not verifier_accepts:
+        # low-degree test of the combination; it reports the combination's values at the points it opened
+        opened = []
+        accepted = self.fri.verify(stream, opened)
+        opened.sort(key=lambda index_value: index_value[0])
+        if not accepted:
             return False
-        indices = [i for i, v in polynomial_values]
-        values = [v for i, v in polynomial_values]
 
-        N = self.fri.domain_length
-        duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
-        duplicated_indices.sort()
-
-        def read_leafs(root):
-            table = dict()
-            for i in duplicated_indices:
-                table[i] = proof_stream.pull()
-                path = proof_stream.pull()
-                if not Merkle.verify(root, i, path, table[i]):
-                    return None
-            return table
-
-        leafs = []
-        for root in boundary_quotient_roots:
-            table = read_leafs(root)
-            if table is None:
+        # every committed codeword opened at those points and at their successors on the trace domain
+        N, step = self.fri.domain_length, self.expansion_factor
+        positions = sorted([i for i, _ in opened] + [(i + step) % N for i, _ in opened])
+        quotient_leaves = []
+        for root in quotient_roots:
+            quotient_leaves.append(self._pull_openings(stream, root, positions))
+            if quotient_leaves[-1] is None:
                 return False
-            leafs.append(table)
-        randomizer = read_leafs(randomizer_root)
+        randomizer = self._pull_openings(stream, randomizer_root, positions)
         if randomizer is None:
             return False
-        transition_zerofier = read_leafs(transition_zerofier_root)
-        if transition_zerofier is None:
+        zerofier_values = self._pull_openings(stream, transition_zerofier_root, positions)
+        if zerofier_values is None:
             return False
 
+        # the combination recomputed from the openings must agree with FRI's view of it at every queried point
+        zerofiers, interpolants = self.boundary_zerofiers(boundary), self.boundary_interpolants(boundary)
         max_degree = self.max_degree(transition_constraints)
-        tq_bounds = self.transition_quotient_degree_bounds(transition_constraints)
-        bq_bounds = self.boundary_quotient_degree_bounds(randomized_trace_length, boundary)
-        constraint_at = [tc.evaluator() for tc in transition_constraints]      # term lists extracted once, not per queried point
-        for position, current_index in enumerate(indices):
-            next_index = (current_index + self.expansion_factor) % N
-            x_current = self.generator * (self.omega ^ current_index)
-            x_next = self.generator * (self.omega ^ next_index)
-            # undo the boundary quotient to recover the trace values at both points
-            current_trace = [leafs[s][current_index] * zerofiers[s].evaluate(x_current) + interpolants[s].evaluate(x_current) for s in range(self.num_registers)]
-            next_trace = [leafs[s][next_index] * zerofiers[s].evaluate(x_next) + interpolants[s].evaluate(x_next) for s in range(self.num_registers)]
-            point = [x_current] + current_trace + next_trace
-            constraint_values = [at(point) for at in constraint_at]
+        transition_shifts = [max_degree - bound for bound in self.transition_quotient_degree_bounds(transition_constraints)]
+        boundary_shifts = [max_degree - bound for bound in self.boundary_quotient_degree_bounds(trace_rows, boundary)]
+        constraint_at = [constraint.evaluator() for constraint in transition_constraints]      # term lists extracted once, not per point
 
-            terms = [randomizer[current_index]]
-            for s, tcv in enumerate(constraint_values):
-                quotient = tcv / transition_zerofier[current_index]
-                terms += [quotient, quotient * (x_current ^ (max_degree - tq_bounds[s]))]
-            for s in range(self.num_registers):
-                bqv = leafs[s][current_index]
-                terms += [bqv, bqv * (x_current ^ (max_degree - bq_bounds[s]))]
-            combination = reduce(lambda a, b: a + b, [terms[j] * weights[j] for j in range(len(terms))], self.field.zero())
-            if not (combination == values[position]):
+        def trace_row(index, x):
+            # undo the boundary quotient: trace = quotient * zerofier + interpolant
+            return [quotient_leaves[s][index] * zerofiers[s].evaluate(x) + interpolants[s].evaluate(x) for s in registers]
+
+        for index, claimed in opened:
+            successor = (index + step) % N
+            x = self.generator * (self.omega ^ index)
+            point = [x] + trace_row(index, x) + trace_row(successor, self.generator * (self.omega ^ successor))
+            weight = iter(weights)
+            total = randomizer[index] * next(weight)
+            for evaluate, shift in zip(constraint_at, transition_shifts):
+                quotient = evaluate(point) / zerofier_values[index]
+                total = total + quotient * next(weight) + quotient * (x ^ shift) * next(weight)
+            for s, shift in zip(registers, boundary_shifts):
+                quotient = quotient_leaves[s][index]
+                total = total + quotient * next(weight) + quotient * (x ^ shift) * next(weight)
+            if not (total == claimed):
                 return False
         return True
+
+    @staticmethod
+    def _pull_openings(stream, root, positions):
+        """{position: leaf} from the (leaf, authentication path) pairs the prover pushed for one commitment, in the order of
+        `positions`; None as soon as a path does not lead to `root`"""
+        leaves = {}
+        for position in positions:
+            leaf, path = stream.pull(), stream.pull()
+            if not Merkle.verify(root, position, path, leaf):
+                return None
+            leaves[position] = leaf
+        return leaves

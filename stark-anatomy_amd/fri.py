@@ -20,20 +20,17 @@ from starkcore import DeviceCodeword, DeviceVector, query_codewords
 
 class Fri:
     def __init__(self, offset, omega, initial_domain_length, expansion_factor, num_colinearity_tests):
-        self.offset = offset
-        self.omega = omega
+        self.offset, self.omega, self.field = offset, omega, omega.field
         self.domain_length = initial_domain_length
-        self.field = omega.field
-        self.expansion_factor = expansion_factor
-        self.num_colinearity_tests = num_colinearity_tests
+        self.expansion_factor, self.num_colinearity_tests = expansion_factor, num_colinearity_tests
         assert(self.num_rounds() >= 1), "cannot do FRI with less than one round"
 
     def num_rounds(self):
-        # halve while the codeword is longer than the expansion factor and 4x the number of tests (fri.py:22-28)
-        length, rounds = self.domain_length, 0
-        while length > self.expansion_factor and 4 * self.num_colinearity_tests < length:
-            length /= 2
-            rounds += 1
+        """commitments made by `commit`: the codeword is halved while it is longer than the expansion factor and than four times
+        the number of colinearity tests (fri.py:22-28)"""
+        rounds, length = 0, self.domain_length
+        while length > self.expansion_factor and length > 4 * self.num_colinearity_tests:
+            rounds, length = rounds + 1, length / 2
         return rounds
 
     def sample_index(byte_array, size):
@@ -47,20 +44,28 @@ class Fri:
         return acc % size
 
     def sample_indices(self, seed, size, reduced_size, number):
+        """`number` indices below `size`, pairwise distinct modulo `reduced_size` (they must not collide in the last codeword),
+        drawn from blake2b(seed + counter zero bytes) for counter = 0, 1, ... (fri.py:36-51)"""
         assert(number <= reduced_size), f"cannot sample more indices than available in last codeword; requested: {number}, available: {reduced_size}"
         assert(number <= 2 * reduced_size), "not enough entropy in indices wrt last codeword"
-        indices, taken, counter = [], set(), 0
-        while len(indices) < number:
+        chosen, residues, counter = [], set(), 0
+        while len(chosen) < number:
             # bytes(counter) is `counter` zero bytes (fri.py:44), not an encoding of the counter
-            index = Fri.sample_index(blake2b(seed + bytes(counter)).digest(), size)
+            candidate = Fri.sample_index(blake2b(seed + bytes(counter)).digest(), size)
             counter += 1
-            if index % reduced_size not in taken:
-                taken.add(index % reduced_size)
-                indices.append(index)
-        return indices
+            if candidate % reduced_size in residues:
+                continue
+            residues.add(candidate % reduced_size)
+            chosen.append(candidate)
+        return chosen
 
     def eval_domain(self):
-        return [self.offset * (self.omega ^ i) for i in range(self.domain_length)]
+        # offset * omega^i, i < domain_length, by running product
+        points, x = [], self.offset
+        for _ in range(self.domain_length):
+            points.append(x)
+            x = x * self.omega
+        return points
 
     def _on_device(self, codeword):
         if isinstance(codeword, DeviceCodeword):
@@ -133,21 +138,21 @@ class Fri:
         return codewords
 
     def query(self, current_codeword, next_codeword, c_indices, proof_stream):
-        current_codeword = self._on_device(current_codeword)
-        next_codeword = self._on_device(next_codeword)
-        s = self.num_colinearity_tests
-        a_indices = [index for index in c_indices]
-        b_indices = [index + len(current_codeword) // 2 for index in c_indices]
+        """one round of the query phase (fri.py:98-113): the s colinear triples (current[c], current[c + half], next[c]), then their
+        authentication paths; returns the opened positions of the current codeword"""
+        current, following = self._on_device(current_codeword), self._on_device(next_codeword)
+        s, half = self.num_colinearity_tests, len(current) // 2
+        lower = list(c_indices)
+        upper = [c + half for c in lower]
         # one round trip per codeword: opened entries and their authentication paths together
-        ab, ab_paths = current_codeword.query(a_indices[:s] + b_indices[:s])
-        cs, c_paths = next_codeword.query(c_indices[:s])
-        for i in range(s):
-            proof_stream.push((ab[i], ab[s + i], cs[i]))
-        for i in range(s):
-            proof_stream.push(ab_paths[i])
-            proof_stream.push(ab_paths[s + i])
-            proof_stream.push(c_paths[i])
-        return a_indices + b_indices
+        entries, paths = current.query(lower[:s] + upper[:s])
+        next_entries, next_paths = following.query(lower[:s])
+        for t in range(s):
+            proof_stream.push((entries[t], entries[s + t], next_entries[t]))
+        for t in range(s):
+            for path in (paths[t], paths[s + t], next_paths[t]):
+                proof_stream.push(path)
+        return lower + upper
 
     def prove(self, codeword, proof_stream):
         assert(self.domain_length == len(codeword)), "initial codeword length does not match length of initial codeword"
@@ -202,56 +207,48 @@ class Fri:
         assert(fast_coset_evaluate(poly, last_offset, last_omega, len(last_codeword)) == last_codeword), "re-evaluated codeword does not match original!"
         return poly.degree()
 
+    @staticmethod
+    def _reject(*lines):
+        for line in lines:
+            print(line)
+        return False
+
     def verify(self, proof_stream, polynomial_values):
-        omega, offset = self.omega, self.offset
-        rounds = self.num_rounds()
+        rounds, s = self.num_rounds(), self.num_colinearity_tests
+        # the commit phase replayed: per round a root and the challenge it determines, then the last codeword in the clear
         roots, alphas = [], []
-        for r in range(rounds):
+        for _ in range(rounds):
             roots.append(proof_stream.pull())
             alphas.append(self.field.sample(proof_stream.verifier_fiat_shamir()))
         last_codeword = proof_stream.pull()
-        if roots[-1] != Merkle.commit(last_codeword):
-            print("last codeword is not well formed")
-            return False
-        degree = (len(last_codeword) // self.expansion_factor) - 1
-        last_omega, last_offset = omega, offset
-        for r in range(rounds - 1):
-            last_omega = last_omega ^ 2
-            last_offset = last_offset ^ 2
+        if Merkle.commit(last_codeword) != roots[-1]:
+            return Fri._reject("last codeword is not well formed")
+        # the last codeword lives on the coset after rounds - 1 squarings; it must be of low degree there
+        squarings = 1 << (rounds - 1)
+        last_omega, last_offset = self.omega ^ squarings, self.offset ^ squarings
         assert(last_omega.inverse() == last_omega ^ (len(last_codeword) - 1)), "omega does not have right order"
+        allowed = len(last_codeword) // self.expansion_factor - 1
         observed = self._last_codeword_degree(last_codeword, last_omega, last_offset)
-        if observed > degree:
-            print("last codeword does not correspond to polynomial of low enough degree")
-            print("observed degree:", observed)
-            print("but should be:", degree)
-            return False
-        top_level_indices = self.sample_indices(proof_stream.verifier_fiat_shamir(), self.domain_length >> 1,
-                                                self.domain_length >> (rounds - 1), self.num_colinearity_tests)
-        s = self.num_colinearity_tests
-        for r in range(0, rounds - 1):
+        if observed > allowed:
+            return Fri._reject("last codeword does not correspond to polynomial of low enough degree", "observed degree: %s" % observed,
+                               "but should be: %s" % allowed)
+        # the query phase: consistency of consecutive codewords at the sampled positions
+        top_level_indices = self.sample_indices(proof_stream.verifier_fiat_shamir(), self.domain_length >> 1, self.domain_length >> (rounds - 1), s)
+        omega, offset = self.omega, self.offset
+        for r in range(rounds - 1):
             half = self.domain_length >> (r + 1)
-            c_indices = [index % half for index in top_level_indices]
-            a_indices = c_indices
-            b_indices = [index + half for index in a_indices]
+            lower = [index % half for index in top_level_indices]
+            upper = [index + half for index in lower]
             triples = [proof_stream.pull() for _ in range(s)]
-            for i, (ay, by, cy) in enumerate(triples):
+            for a, b, (ya, yb, yc) in zip(lower, upper, triples):
                 if r == 0:
-                    polynomial_values += [(a_indices[i], ay), (b_indices[i], by)]
-                ax = offset * (omega ^ a_indices[i])
-                bx = offset * (omega ^ b_indices[i])
-                if test_colinearity([(ax, ay), (bx, by), (alphas[r], cy)]) == False:
-                    print("colinearity check failure")
-                    return False
-            for i, (ay, by, cy) in enumerate(triples):
-                if Merkle.verify(roots[r], a_indices[i], proof_stream.pull(), ay) == False:
-                    print("merkle authentication path verification fails for aa")
-                    return False
-                if Merkle.verify(roots[r], b_indices[i], proof_stream.pull(), by) == False:
-                    print("merkle authentication path verification fails for bb")
-                    return False
-                if Merkle.verify(roots[r + 1], c_indices[i], proof_stream.pull(), cy) == False:
-                    print("merkle authentication path verification fails for cc")
-                    return False
-            omega = omega ^ 2
-            offset = offset ^ 2
+                    polynomial_values += [(a, ya), (b, yb)]
+                # (x_a, y_a), (x_b, y_b) and (alpha, y_c) lie on one line: that is the fold of fri.py:85 read backwards
+                if not test_colinearity([(offset * (omega ^ a), ya), (offset * (omega ^ b), yb), (alphas[r], yc)]):
+                    return Fri._reject("colinearity check failure")
+            for a, b, (ya, yb, yc) in zip(lower, upper, triples):
+                for root, position, leaf, label in ((roots[r], a, ya, "aa"), (roots[r], b, yb, "bb"), (roots[r + 1], a, yc, "cc")):
+                    if not Merkle.verify(root, position, proof_stream.pull(), leaf):
+                        return Fri._reject("merkle authentication path verification fails for " + label)
+            omega, offset = omega ^ 2, offset ^ 2
         return True
