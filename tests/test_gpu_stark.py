@@ -99,3 +99,55 @@ def test_fast_stark(device_min, monkeypatch):      # code/test_fast_stark.py:9-6
     trace[0][1] = trace[0][1] + field.one()
     with pytest.raises(AssertionError):
         stark.prove(trace, air, boundary, transition_zerofier, transition_zerofier_codeword)
+
+
+def test_verifier_rejects_tampered_proofs():
+    """Every rejection branch of FastStark.verify / Fri.verify that a single changed proof object reaches: an opened leaf, a digest of
+    an authentication path, a colinear triple of the low-degree test, the last codeword."""
+    import pickle
+    field = Field.main()
+    _seed_urandom(77)
+    rp = RescuePrime()
+    input_element = field.sample(b"tamper")
+    output_element = rp.hash(input_element)
+    stark = FastStark(field, 4, 2, 2, rp.m, rp.N + 1)
+    tz, tz_codeword, tz_root = stark.preprocess()
+    air, boundary = rp.transition_constraints(stark.omicron), rp.boundary_constraints(output_element)
+    proof = stark.prove(rp.trace(input_element), air, boundary, tz, tz_codeword)
+    assert stark.verify(proof, air, boundary, tz_root) == True
+    objects = pickle.loads(proof)
+
+    def verdict(changed):
+        try:
+            return stark.verify(pickle.dumps(changed), air, boundary, tz_root)
+        except AssertionError:            # a changed transcript may also trip an assertion on the way (e.g. "divide by zero")
+            return False
+
+    def flipped(digest):
+        return bytes([digest[0] ^ 1]) + digest[1:]
+
+    # the last two objects: the leaf and the path of the last opening of the transition zerofier codeword
+    leaf_at, path_at = len(objects) - 2, len(objects) - 1
+    assert isinstance(objects[leaf_at], FieldElement) and isinstance(objects[path_at], list)
+    changed = list(objects); changed[leaf_at] = objects[leaf_at] + field.one()
+    assert verdict(changed) == False, "changed leaf accepted"
+    changed = list(objects); changed[path_at] = [flipped(objects[path_at][0])] + objects[path_at][1:]
+    assert verdict(changed) == False, "changed authentication path accepted"
+    # the low-degree test's part of the stream starts after the registers' roots and the randomizer root
+    first_fri = rp.m + 1
+    rounds = stark.fri.num_rounds()
+    last_codeword_at = first_fri + rounds
+    assert isinstance(objects[last_codeword_at], list) and isinstance(objects[last_codeword_at][0], FieldElement)
+    changed = list(objects); changed[last_codeword_at] = [objects[last_codeword_at][0] + field.one()] + objects[last_codeword_at][1:]
+    assert verdict(changed) == False, "changed last codeword accepted"
+    triple_at = last_codeword_at + 1
+    assert isinstance(objects[triple_at], tuple) and len(objects[triple_at]) == 3
+    a, b, c = objects[triple_at]
+    changed = list(objects); changed[triple_at] = (a, b, c + field.one())
+    assert verdict(changed) == False, "changed colinearity triple accepted"
+    fri_path_at = triple_at + stark.fri.num_colinearity_tests
+    assert isinstance(objects[fri_path_at], list) and isinstance(objects[fri_path_at][0], bytes)
+    changed = list(objects); changed[fri_path_at] = [flipped(objects[fri_path_at][0])] + objects[fri_path_at][1:]
+    assert verdict(changed) == False, "changed FRI authentication path accepted"
+    changed = list(objects); changed[first_fri] = flipped(objects[first_fri])
+    assert verdict(changed) == False, "changed FRI root accepted"
