@@ -194,8 +194,12 @@ class ShardedFastStark(FastStark):
         duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
         quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
         quadrupled_indices.sort()
-        for layer in boundary_layers + [randomizer_layer, transition_zerofier_layer]:
-            entries, paths = self.sfri._open(layer, quadrupled_indices)
+        layers = boundary_layers + [randomizer_layer, transition_zerofier_layer]
+        # ONE library call and ONE collective for all the codewords' openings; pushed leaf, path, leaf, path, ... per codeword
+        for entries, paths in self.sfri._open_many([(layer, quadrupled_indices) for layer in layers]):
+            if type(proof_stream) is ProofStream:            # push == objects.append
+                proof_stream.objects.extend(x for pair in zip(entries, paths) for x in pair)
+                continue
             for entry, path in zip(entries, paths):
                 proof_stream.push(entry)
                 proof_stream.push(path)
