@@ -220,8 +220,14 @@ class FastStark:
         duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
         quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
         quadrupled_indices.sort()
-        for codeword in boundary_quotient_codewords + [randomizer_codeword, transition_zerofier_codeword]:
-            self._open_all(codeword, quadrupled_indices, proof_stream)
+        committed = boundary_quotient_codewords + [randomizer_codeword, transition_zerofier_codeword]
+        if all(isinstance(codeword, DeviceCodeword) for codeword in committed):
+            # every codeword's openings in ONE device round trip; pushed leaf, path, leaf, path, ... codeword by codeword
+            for entries, paths in query_codewords(committed, [quadrupled_indices] * len(committed)):
+                self._push_openings(entries, paths, proof_stream)
+        else:
+            for codeword in committed:
+                self._open_all(codeword, quadrupled_indices, proof_stream)
 
         return proof_stream.serialize()
 
@@ -247,6 +253,10 @@ class FastStark:
             entries, paths = codeword.query(indices)          # entries and paths in one device round trip
         else:
             entries, paths = [codeword[i] for i in indices], Merkle._tree(codeword).open_batch(indices)
+        self._push_openings(entries, paths, proof_stream)
+
+    @staticmethod
+    def _push_openings(entries, paths, proof_stream):
         if type(proof_stream) is ProofStream:            # push == objects.append: one list extension for the whole codeword
             proof_stream.objects.extend(x for pair in zip(entries, paths) for x in pair)
             return
