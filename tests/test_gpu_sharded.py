@@ -240,11 +240,20 @@ def test_sharded_fri_hip_engine_matches_reference_proofs(sc):
         for logR in sorted({1, 3, rec["logN"] // 2, rec["logN"] - 1, rec["logN"]}):
             R = 1 << logR
             fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
-            ps = ProofStream()
-            top = ShardedFri(fr, R, 0, 1, dev).prove(cw.reshape(N // R, R, 2), ps)
-            ser = ps.serialize()
-            assert top == rec["top_level_indices"], (rec["logN"], R)
-            assert hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"], (rec["logN"], R)
+            # under torch's null stream the engine runs on the library's stream and folds with a kernel of its own; on a side
+            # stream (how the sharded prover runs) a round's fold happens in the leaf stage of the next local subtree
+            for side_stream in (False, True):
+                ps = ProofStream()
+                if side_stream:
+                    torch.cuda.synchronize()
+                    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                        top = ShardedFri(fr, R, 0, 1, dev).prove(cw.reshape(N // R, R, 2), ps)
+                    torch.cuda.synchronize()
+                else:
+                    top = ShardedFri(fr, R, 0, 1, dev).prove(cw.reshape(N // R, R, 2), ps)
+                ser = ps.serialize()
+                assert top == rec["top_level_indices"], (rec["logN"], R, side_stream)
+                assert hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"], (rec["logN"], R, side_stream)
 
 
 def test_sharded_lde_then_sharded_fri_one_rank(sc):
