@@ -18,8 +18,6 @@ nonlinear combination -- polynomials of the trace domain's size.  Byte parity ti
 (rank 0 draws, in the reference's order, and broadcasts the bytes), Fiat-Shamir, the proof stream.  Every rank ends with the
 same proof, byte-identical to `FastStark.prove` on one GPU with the same random bytes (tests/test_gpu_sharded.py).
 """
-import ctypes
-
 import torch
 import torch.distributed as dist
 
@@ -30,53 +28,102 @@ from sharded import ShardedNtt, ShardedFri
 import starkcore as _sc
 
 
+class HipReplicatedSteps:
+    """The steps of the prover that are NOT sharded -- polynomials of the trace domain's size, identical on every rank -- on the
+    rank's GPU through the library (DevicePolynomial: the same code fast_stark.FastStark runs).  ShardedFastStark reaches them
+    only through this object, so the multi-rank orchestration around them (what is sharded, what is gathered, which collective
+    carries what) can be run under gloo on CPU with another implementation of these few operations (tests/sharded_worker.py)."""
+
+    def __init__(self, stark):
+        self.stark, self.field, self.device = stark, stark.field, stark.device
+
+    # engines of the sharded parts (None: sharded.ShardedNtt / ShardedFri build their HIP engines)
+    def ntt_engine(self):
+        return None
+
+    def fri_engine(self):
+        return None
+
+    def join(self):
+        """the replicated steps run on the library's stream, the sharded ones on torch's: meet before switching sides"""
+        _sc.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # -- polynomials in, polynomials out
+    def lift(self, polynomial):
+        return DevicePolynomial.from_polynomial(polynomial, self.field)
+
+    def zero(self):
+        return DevicePolynomial(_sc.DeviceVector(1), self.field, 0)
+
+    def subtract(self, lhs, host_polynomial):
+        return lhs.minus(host_polynomial)
+
+    def zerofier(self, domain, root, order):
+        return fast_zerofier(domain, root, order)
+
+    def trace_polynomials(self, omicron, trace, registers):
+        """fast_stark.py:84-87: the interpolants of the trace columns through {omicron^i}, over ONE subproduct tree"""
+        domain = DeviceDomain(_fs.device_powers(omicron, len(trace)), self.field)
+        return [DevicePolynomial.from_codeword(fast_interpolate_device(domain, DeviceCodeword.from_list([row[s] for row in trace], self.field))) for s in registers]
+
+    def coset_divide(self, lhs, rhs, exact):
+        s = self.stark
+        return coset_divide_device(lhs, rhs, s.generator, s.omicron, s.omicron_domain_length, exact=exact)
+
+    def sampled_polynomial(self, raw):
+        return _fs.sampled_polynomial(raw, self.field)
+
+    def combination(self, shifted, weights, max_degree):
+        return self.stark._combination_on_device(shifted, weights, max_degree)
+
+    # -- between a polynomial and the torch tensor the collectives and the sharded transforms work on
+    def coefficients(self, poly, length=None):
+        """coefficients as a torch tensor [length][2] (a copy: torch owns what the collectives touch)"""
+        length = len(poly) if length is None else length
+        t = torch.empty((max(length, 1), 2), dtype=torch.int64, device=self.device)
+        if length:
+            self.join()
+            _sc._check(_sc.lib().sc_memcpy_dev(t.data_ptr(), poly.vec.ptr, length, None))
+            _sc.synchronize()
+        return t[:length]
+
+    def polynomial(self, tensor, length):
+        """the first `length` rows of a [..][2] tensor as a polynomial"""
+        vec = _sc.DeviceVector(max(length, 1))
+        if length:
+            self.join()
+            _sc._check(_sc.lib().sc_memcpy_dev(vec.ptr, tensor.contiguous().data_ptr(), length, None))
+            _sc.synchronize()
+        return DevicePolynomial(vec, self.field, length)
+
+
 class ShardedFastStark(FastStark):
     # divisions whose transform is shorter than this stay on one GPU (replicated): nothing to win from an exchange of a few KiB
     MIN_SHARDED_LOG2 = 10
 
     def __init__(self, field, expansion_factor, num_colinearity_checks, security_level, num_registers, num_cycles, rank, world, device, group=None,
-                 transition_constraints_degree=2):
+                 transition_constraints_degree=2, replicated_steps=None):
         super().__init__(field, expansion_factor, num_colinearity_checks, security_level, num_registers, num_cycles, transition_constraints_degree)
         assert field.p == Field.P_MAIN, "the sharded prover works in the main field"
         self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.steps = HipReplicatedSteps(self) if replicated_steps is None else replicated_steps(self)
         self._ntts = {}
         self.ntt_fri = self._ntt(self.fri_domain_length, self.omega.value)
-        self.sfri = ShardedFri(self.fri, self.ntt_fri.n1, rank, world, device, group=group)
+        self.sfri = ShardedFri(self.fri, self.ntt_fri.n1, rank, world, device, engine=self.steps.fri_engine(), group=group)
 
     # -- plumbing ---------------------------------------------------------------------------------
     def _ntt(self, order, root):
         key = (order, int(root))
         if key not in self._ntts:
-            self._ntts[key] = ShardedNtt(order.bit_length() - 1, int(root), self.rank, self.world, self.device, group=self.group)
+            self._ntts[key] = ShardedNtt(order.bit_length() - 1, int(root), self.rank, self.world, self.device, engine=self.steps.ntt_engine(), group=self.group)
         return self._ntts[key]
 
-    def _stream_ptr(self):
-        cur = torch.cuda.current_stream(self.device)
-        return None if cur.cuda_stream == 0 else ctypes.c_void_p(cur.cuda_stream)
-
-    def _join(self):
-        """the replicated steps run on the library's stream, the sharded ones on torch's: meet before switching sides"""
-        _sc.synchronize()
-        torch.cuda.current_stream(self.device).synchronize()
-
     def _tensor(self, poly, length=None):
-        """coefficients of a DevicePolynomial as a torch tensor [length][2] (a copy: torch owns what the collectives touch)"""
-        length = len(poly) if length is None else length
-        t = torch.empty((max(length, 1), 2), dtype=torch.int64, device=self.device)
-        if length:
-            self._join()
-            _sc._check(_sc.lib().sc_memcpy_dev(t.data_ptr(), poly.vec.ptr, length, None))
-            _sc.synchronize()
-        return t[:length]
+        return self.steps.coefficients(poly, length)
 
     def _polynomial(self, tensor, length):
-        """the first `length` rows of a [..][2] tensor as a DevicePolynomial"""
-        vec = _sc.DeviceVector(max(length, 1))
-        if length:
-            self._join()
-            _sc._check(_sc.lib().sc_memcpy_dev(vec.ptr, tensor.contiguous().data_ptr(), length, None))
-            _sc.synchronize()
-        return DevicePolynomial(vec, self.field, length)
+        return self.steps.polynomial(tensor, length)
 
     def _gather_natural(self, slab, rows, cols):
         """column slabs [rows][cols/G] of every rank -> the whole natural-order vector [rows*cols][2], on every rank"""
@@ -109,13 +156,13 @@ class ShardedFastStark(FastStark):
         the division is not exact.  exact=True: Polynomial.__truediv__'s zero-remainder assertion (univariate.py:99-103)."""
         assert(not rhs.is_zero()), "cannot divide by zero polynomial"
         if lhs.is_zero():
-            return DevicePolynomial(_sc.DeviceVector(1), self.field, 0)
+            return self.steps.zero()
         dl, dr = lhs.degree(), rhs.degree()
         assert(dr <= dl), "cannot divide by polynomial of larger degree"
         root, order = _shrink_order(self.omicron, self.omicron_domain_length, max(dl, dr))
         log2 = order.bit_length() - 1
         if log2 < ShardedFastStark.MIN_SHARDED_LOG2 or (1 << (log2 // 2)) < self.world:
-            return coset_divide_device(lhs, rhs, self.generator, self.omicron, self.omicron_domain_length, exact=exact)
+            return self.steps.coset_divide(lhs, rhs, exact)
         ntt = self._ntt(order, root.value)
         num = ntt.slab_of(self._tensor(lhs, dl + 1), "div_num").clone()
         den = ntt.slab_of(self._tensor(rhs, dr + 1), "div_den").clone()
@@ -131,8 +178,8 @@ class ShardedFastStark(FastStark):
     # -- preprocessing (fast_stark.py:36-40) -----------------------------------------------------------
     def preprocess(self):
         """-> (transition_zerofier, its committed codeword as a sharded layer record, the root)"""
-        transition_zerofier = fast_zerofier(self.omicron_domain[:(self.original_trace_length - 1)], self.omicron, len(self.omicron_domain))
-        layer = self._lde_commit(DevicePolynomial.from_polynomial(transition_zerofier, self.field))
+        transition_zerofier = self.steps.zerofier(self.omicron_domain[:(self.original_trace_length - 1)], self.omicron, len(self.omicron_domain))
+        layer = self._lde_commit(self.steps.lift(transition_zerofier))
         return transition_zerofier, layer, layer["root"]
 
     # -- prover (fast_stark.py:76-178) -------------------------------------------------------------------
@@ -149,12 +196,11 @@ class ShardedFastStark(FastStark):
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)
         # replicated: the trace polynomials through {omicron^i} over the subproduct tree (fast_stark.py:84-87)
-        trace_domain = DeviceDomain(_fs.device_powers(self.omicron, len(trace)), field)
-        trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, DeviceCodeword.from_list([row[s] for row in trace], field)))
-                             for s in registers]
+        steps = self.steps
+        trace_polynomials = steps.trace_polynomials(self.omicron, trace, registers)
         # sharded: boundary quotients, their LDEs and commitments (fast_stark.py:89-105)
-        zerofiers_dev = [DevicePolynomial.from_polynomial(z, field) for z in zerofiers]
-        boundary_quotients = [self._coset_divide(trace_polynomials[s].minus(interpolants[s]), zerofiers_dev[s], exact=True) for s in registers]
+        zerofiers_dev = [steps.lift(z) for z in zerofiers]
+        boundary_quotients = [self._coset_divide(steps.subtract(trace_polynomials[s], interpolants[s]), zerofiers_dev[s], exact=True) for s in registers]
         boundary_layers = []
         for s in registers:
             boundary_layers.append(self._lde_commit(boundary_quotients[s]))
@@ -162,14 +208,14 @@ class ShardedFastStark(FastStark):
 
         # replicated: the AIR substituted in (X, trace(X), trace(omicron X)) in the value domain; sharded: the quotients
         x = Polynomial([field.zero(), field.one()])
-        point = [DevicePolynomial.from_polynomial(x, field)] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
+        point = [steps.lift(x)] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
         transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
-        tz_dev = DevicePolynomial.from_polynomial(transition_zerofier, field)
+        tz_dev = steps.lift(transition_zerofier)
         transition_quotients = [self._coset_divide(tp, tz_dev) for tp in transition_polynomials]
 
         # randomizer polynomial (rank 0's draws), its sharded LDE and commitment
         max_degree = self.max_degree(transition_constraints)
-        randomizer_polynomial = _fs.sampled_polynomial(self._shared_random_bytes(max_degree + 1), field)
+        randomizer_polynomial = steps.sampled_polynomial(self._shared_random_bytes(max_degree + 1))
         randomizer_layer = self._lde_commit(randomizer_polynomial)
         proof_stream.push(randomizer_layer["root"])
 
@@ -184,7 +230,7 @@ class ShardedFastStark(FastStark):
             shifted.append((tq, max_degree - tq_bounds[i]))
         for i in registers:
             shifted.append((boundary_quotients[i], max_degree - bq_bounds[i]))
-        combination = self._combination_on_device(shifted, weights, max_degree)
+        combination = steps.combination(shifted, weights, max_degree)
         slab = torch.empty(self.ntt_fri.local_shape(False), dtype=torch.int64, device=self.device)
         self.ntt_fri.coset_evaluate(self._tensor(combination), self.generator.value, slab)
         indices = self.sfri.prove(slab, proof_stream)

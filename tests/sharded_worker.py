@@ -203,7 +203,7 @@ def poly_checks(eng, rank, world, n, root):
     return bool(ok)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "fri"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("fri", "stark")):
     main()
 
 
@@ -357,3 +357,125 @@ def fri_main():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "fri":
     fri_main()
+
+
+# =====================================================================================================================
+# ShardedFastStark under gloo: the orchestration of the sharded prover with every local computation served by the oracle
+# =====================================================================================================================
+def stark_main():
+    """sharded_stark.ShardedFastStark on the reference's Rescue-Prime workload (code/test_fast_stark.py) with the reference's seeded
+    random bytes: every rank must end with the proof the REFERENCE produced (tests/golden/fast_stark.json: SHA-256 of the proof,
+    the first roots, the zerofier commitment).  The replicated steps (trace-domain polynomials) are host Polynomial arithmetic
+    and the oracle's fast_* restatements; the sharded ones run sharded.py's real data movement over the oracle engines."""
+    import hashlib
+    import json
+    import random
+    import fast_stark
+    import sharded_stark
+    from algebra import Field, FieldElement
+    from univariate import Polynomial
+    from ip import ProofStream
+    from workload_rescue_prime import RescuePrime
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    field = Field.main()
+    from multivariate import MPolynomial
+    Polynomial.FAST_MUL_MIN_LEN = 10 ** 9            # host products stay schoolbook: no GPU in this process
+    MPolynomial.VALUE_DOMAIN_MIN_DEGREE = 10 ** 9    # and the AIR substitution stays the reference's sums of products
+    sharded_stark.ShardedFastStark.MIN_SHARDED_LOG2 = 4   # the quotients of this small workload (order 64 / 128) take the sharded route too
+
+    def ints(polynomial):
+        return [c.value for c in polynomial.coefficients]
+
+    def poly(values):
+        return Polynomial([FieldElement(int(v), field) for v in values])
+
+    class OracleReplicatedSteps:
+        def __init__(self, stark):
+            self.stark = stark
+
+        def ntt_engine(self):
+            return StagesOracleEngine()
+
+        def fri_engine(self):
+            return OracleFriEngine()
+
+        def join(self):
+            pass
+
+        def lift(self, polynomial):
+            return polynomial
+
+        def zero(self):
+            return Polynomial([])
+
+        def subtract(self, lhs, rhs):
+            return lhs - rhs
+
+        def zerofier(self, domain, root, order):
+            return poly(po.fast_zerofier([d.value for d in domain], root.value, order))
+
+        def trace_polynomials(self, omicron, trace, registers):
+            s = self.stark
+            domain = [pow(omicron.value, i, P) for i in range(len(trace))]
+            return [poly(po.fast_interpolate(domain, [row[r].value for row in trace], s.omicron.value, s.omicron_domain_length)) for r in registers]
+
+        def coset_divide(self, lhs, rhs, exact):
+            if exact:
+                return lhs / rhs                       # univariate.py's division: asserts a zero remainder
+            s = self.stark
+            return poly(po.fast_coset_divide(ints(lhs), ints(rhs), s.generator.value, s.omicron.value, s.omicron_domain_length))
+
+        def sampled_polynomial(self, raw):
+            return Polynomial([field.sample(raw[17 * i:17 * i + 17]) for i in range(len(raw) // 17)])
+
+        def combination(self, shifted, weights, max_degree):
+            x = Polynomial([field.zero(), field.one()])
+            terms = []
+            for polynomial, shift in shifted:
+                terms += [polynomial] if shift is None else [polynomial, (x ^ shift) * polynomial]
+            total = Polynomial([])
+            for weight, term in zip(weights, terms):
+                total = total + Polynomial([weight]) * term
+            return total
+
+        def coefficients(self, polynomial, length=None):
+            values = ints(polynomial)
+            length = len(values) if length is None else length
+            values = (values + [0] * length)[:length]
+            raw = b"".join(v.to_bytes(16, "little") for v in values)
+            return torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(length, 2).copy()) if length else torch.empty((0, 2), dtype=torch.int64)
+
+        def polynomial(self, tensor, length):
+            a = tensor.contiguous().numpy().view(np.uint64).reshape(-1, 2)
+            return poly(int(a[i, 0]) | (int(a[i, 1]) << 64) for i in range(length))
+
+    golden = json.load(open(os.path.join(REPO, "tests", "golden", "fast_stark.json")))
+    rp = RescuePrime()
+    ok = True
+    for rec in golden["runs"]:
+        rng = random.Random(rec["urandom_seed"])
+        fast_stark.os.urandom = lambda k, rng=rng: bytes(rng.getrandbits(8) for _ in range(k))
+        input_element = FieldElement(int(rec["input"]), field)
+        output_element = rp.hash(input_element)
+        stark = sharded_stark.ShardedFastStark(field, rec["expansion_factor"], rec["num_colinearity_checks"], rec["security_level"], rp.m, rp.N + 1,
+                                               rank, world, torch.device("cpu"), replicated_steps=OracleReplicatedSteps)
+        transition_zerofier, layer, root = stark.preprocess()
+        proof = stark.prove(rp.trace(input_element), rp.transition_constraints(stark.omicron), rp.boundary_constraints(output_element), transition_zerofier, layer)
+        objects = ProofStream().deserialize(proof).objects
+        good = (root.hex() == rec["zerofier_root"] and [o.hex() for o in objects[:rp.m + 1]] == rec["first_roots"] and len(objects) == rec["num_objects"]
+                and len(proof) == rec["proof_len"] and hashlib.sha256(proof).hexdigest() == rec["proof_sha256"])
+        # the quotients really took the sharded route: transforms of other orders than the FRI domain's were planned
+        good = good and len(stark._ntts) >= 2
+        if not good:
+            print("rank", rank, "STARK MISMATCH seed", rec["urandom_seed"], root.hex() == rec["zerofier_root"], len(proof), rec["proof_len"], flush=True)
+        ok &= good
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+    print("rank", rank, "ok")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stark":
+    stark_main()

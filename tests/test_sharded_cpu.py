@@ -38,3 +38,17 @@ def test_sharded_fri_gloo_matches_reference_proofs(world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == world
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_sharded_stark_prover_gloo_matches_reference_proofs(world):
+    """sharded_stark.ShardedFastStark (BASELINE configs[4] as a prover: sharded LDEs, commitments, quotients, FRI, openings; rank 0's
+    random bytes broadcast) on the reference's Rescue-Prime workload: every rank ends with the REFERENCE's proof (golden SHA-256 from
+    code/fast_stark.py run with the same seeded random bytes).  Local computations come from the oracle; what runs for real is the
+    orchestration: what is sharded, what is gathered, which collective carries what."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(REPO, "tests", "sharded_worker.py"), "stark"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == world
