@@ -13,7 +13,7 @@ def nth_root(n):
     return r
 sc.init(0); lib = sc.lib(); dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream); sptr = ctypes.c_void_p(stream.cuda_stream)
-DEFAULTS = dict(fixed_shapes=1, wave_local=1, tw_on_load=0, prio_balance=-1, prune=1, max_tile_log=-1, max_col_log=-1, max_digit_log=-1)
+DEFAULTS = dict(fixed_shapes=1, wave_local=1, tw_on_load=0, prio_balance=-1, prune=1, max_tile_log=-1, max_col_log=-1, max_digit_log=-1, direct_tw_max_log=22)
 cfgs = [dict()] + [json.loads(a) for a in sys.argv[1:]] + [dict()]
 def timed(f, reps):
     for _ in range(3): f()
