@@ -45,6 +45,7 @@ extern "C" {
 typedef struct sc_vec sc_vec_t;        /* device-resident vector of field elements */
 typedef struct sc_merkle sc_merkle_t;  /* device-resident BLAKE2b Merkle tree (all levels kept) */
 typedef struct sc_polytree sc_polytree_t; /* device-resident subproduct tree over a list of points (all levels kept) */
+typedef struct sc_geodomain sc_geodomain_t; /* tables of a domain that is a geometric progression first * ratio^i */
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 int sc_device_count(void);
@@ -190,6 +191,22 @@ int sc_polytree_zerofier_dev(const sc_polytree_t* tree, void* d_out, void* strea
 int sc_polytree_evaluate_dev(sc_polytree_t* tree, const void* d_coeffs, uint64_t m, const void* d_points, void* d_out, void* stream);
 int sc_polytree_interpolate_dev(sc_polytree_t* tree, const void* d_values, void* d_out, void* stream);
 int sc_polytree_free(sc_polytree_t* tree);
+
+/* ---- the same three functions on a GEOMETRIC PROGRESSION  x_i = first * ratio^i, i < n : code/ntt.py:66-130 as called by
+ * code/fast_stark.py:84-90 (the trace domain {omicron^i}) and :37 (the transition zerofier's domain) -----------------------
+ * Zerofier, values and interpolant are unique, so on such a domain they are computed with O(1) transforms of length
+ * M = pow2 >= 2n - 1 (Bluestein / Bostan-Schost) instead of a tree: same outputs as sc_polytree_* / the reference's recursion.
+ * create: n >= 2, distinct points required (SC_ERR_UNSUPPORTED otherwise: use the tree, which reproduces the reference's
+ * behaviour for repeated points).  The *_dev calls only ENQUEUE on `stream` (NULL: the library stream): results are valid in
+ * stream order; nothing waits, temporaries are returned behind the stream.
+ * detect: is d_points[i+1] == d_points[i] * ratio for all i (ratio = points[1] / points[0])?  one small kernel + one sync. */
+int sc_geodomain_create(const uint64_t first[2], const uint64_t ratio[2], uint64_t n, sc_geodomain_t** domain, void* stream);
+uint64_t sc_geodomain_points(const sc_geodomain_t* domain);
+int sc_geodomain_detect_dev(const void* d_points, uint64_t n, uint64_t first[2], uint64_t ratio[2], int* is_geometric, void* stream);
+int sc_geodomain_zerofier_dev(const sc_geodomain_t* domain, void* d_out, void* stream);          /* n + 1 coefficients */
+int sc_geodomain_evaluate_dev(const sc_geodomain_t* domain, const void* d_coeffs, uint64_t m, void* d_out, void* stream);   /* n values, any m */
+int sc_geodomain_interpolate_dev(const sc_geodomain_t* domain, const void* d_values, void* d_out, void* stream);            /* n coefficients */
+int sc_geodomain_free(sc_geodomain_t* domain);
 
 /* ---- MPolynomial.evaluate_symbolic in the value domain : code/multivariate.py:83-90 (call site fast_stark.py:109-110) ---- */
 /* d_vals: [nvars][n] values of the point polynomials on an n-point domain (CONSUMED: converted in place to the library's

@@ -31,7 +31,13 @@ def xgcd(x, y):
 def _inverse_residue(value, p):
     """value^-1 mod p, with the reference's convention inverse(0) == 0 (xgcd(0, p) gives the cofactor 0, algebra.py:87-89)"""
     value %= p
-    return pow(value, -1, p) if value else 0
+    if not value:
+        return 0
+    try:
+        return pow(value, -1, p)
+    except ValueError:
+        # not invertible (composite modulus): the reference returns the Bezout cofactor of its xgcd without complaint (algebra.py:87-89)
+        return xgcd(value, p)[0] % p
 
 
 class FieldElement:

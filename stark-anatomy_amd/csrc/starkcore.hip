@@ -16,6 +16,7 @@
 #include "../../include/starkcore.h"
 #include "merkle.cuh"
 #include "polytree.cuh"
+#include "geoseq.cuh"
 #include "ntt_plan.h"
 #include "transcript.h"
 
@@ -999,6 +1000,20 @@ int merkle_root_wait(sc_merkle* t, bool from_free = false) {
     return SC_OK;
 }
 
+// The commit loop of sc_fri_commit_dev spends most of its time waiting for roots.  That wait does not need the library lock:
+// the tree, its slot and its sequence number belong to the calling thread until the call returns.  Poll with the lock released
+// (other threads' sc_vec_free / sc_merkle_root / a second prover get through), then take it again; merkle_root_wait finds the
+// root landed (or, after a failed launch, finds out why under the lock).
+void root_poll_unlocked(std::unique_lock<std::mutex>& lk, const sc_merkle* t) {
+    if (t->have_root || t->lazy || t->slot < 0) return;
+    volatile uint64_t* slot = (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * t->slot);
+    const uint64_t seq = t->seq;
+    lk.unlock();
+    for (long spin = 0; spin < SPIN_POLLS; ++spin)
+        if (__atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == seq) break;
+    lk.lock();
+}
+
 // everything of a fold but its launch: the power tables of omega^-1 and c = alpha / (2 * offset)
 int fold_prepare(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st, FoldIn* f) {
     if (N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
@@ -1322,6 +1337,239 @@ int polytree_interpolate(sc_polytree* t, const Fe* d_values, Fe* d_out, hipStrea
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(d_out, cur + pad, k * sizeof(Fe), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
+    return SC_OK;
+}
+
+}  // namespace
+
+// ============================================================================ geometric progressions (geoseq.cuh)
+
+struct sc_geodomain {
+    uint64_t n, M;
+    int logM;
+    Fe c, q, c_inv;        // first point, ratio, 1 / first point (canonical)
+    bool unit;             // c == 1: no scaling by powers of c anywhere
+    Fe* tinv_m;            // n:  q^-(j(j-1)/2)
+    Fe* wden_m;            // n:  1 / (Z'(q^i) t_i)
+    Fe* Bf;                // M:  transform of t_0 .. t_(M-1)
+    Fe* ZRf;               // M:  transform of the reversed zerofier's first n coefficients
+    Fe* zr;                // n + 1: reversed zerofier of {q^i}, canonical
+};
+
+namespace {
+
+// pool temporary whose memory goes back once the streams that may still read it have passed this point (nothing here waits)
+struct PoolTmpAsync {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~PoolTmpAsync() { if (p) release_after_streams(p, bytes); }
+    int get(size_t b) {
+        bytes = b ? b : sizeof(Fe);
+        HIPCHK(pool_alloc(&p, bytes));
+        return SC_OK;
+    }
+    Fe* fe() const { return (Fe*)p; }
+};
+
+// inclusive prefix products of n Montgomery forms, in place (reduce per workgroup, scan the totals, apply)
+int scan_products(Fe* a, uint64_t n, hipStream_t st) {
+    if (n == 0) return SC_OK;
+    const uint64_t nb = (n + GS_BLOCK - 1) / GS_BLOCK;
+    if (nb == 1) {
+        hipLaunchKernelGGL(gs_apply_kernel, dim3(1), dim3(GS_T), 0, st, a, n, (const Fe*)nullptr);
+        HIPCHK(hipGetLastError());
+        return SC_OK;
+    }
+    PoolTmpAsync tot;
+    SCCHK(tot.get(nb * sizeof(Fe)));
+    hipLaunchKernelGGL(gs_totals_kernel, dim3((unsigned)nb), dim3(GS_T), 0, st, (const Fe*)a, n, tot.fe());
+    SCCHK(scan_products(tot.fe(), nb, st));
+    hipLaunchKernelGGL(gs_apply_kernel, dim3((unsigned)nb), dim3(GS_T), 0, st, a, n, (const Fe*)tot.fe());
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+void geodomain_release(sc_geodomain* d) {
+    if (!d) return;
+    if (d->tinv_m) release_after_streams(d->tinv_m, d->n * sizeof(Fe));
+    if (d->wden_m) release_after_streams(d->wden_m, d->n * sizeof(Fe));
+    if (d->Bf) release_after_streams(d->Bf, d->M * sizeof(Fe));
+    if (d->ZRf) release_after_streams(d->ZRf, d->M * sizeof(Fe));
+    if (d->zr) release_after_streams(d->zr, (d->n + 1) * sizeof(Fe));
+    delete d;
+}
+
+int geodomain_create(Fe c, Fe q, uint64_t n, sc_geodomain** out, hipStream_t st) {
+    if (n < 2) return fail(SC_ERR_UNSUPPORTED, "a progression of fewer than two points");
+    if (fe_ge_p(c) || fe_ge_p(q) || fe_is_zero(c) || fe_is_zero(q)) return fail(SC_ERR_UNSUPPORTED, "first point and ratio must be non-zero residues");
+    const int logM = ilog2(2 * n - 1);
+    if (logM > 28) return fail(SC_ERR_UNSUPPORTED, "progression too long");
+    const uint64_t M = 1ull << logM;
+    sc_geodomain* d = new sc_geodomain{n, M, logM, c, q, Fe{0, 0}, fe_eq(c, fe_one()), nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto bail = [&](int rc) { geodomain_release(d); return rc; };
+    auto alloc = [&](Fe** p, uint64_t count) -> int {
+        hipError_t e = pool_alloc((void**)p, count * sizeof(Fe));
+        return e == hipSuccess ? SC_OK : fail(SC_ERR_HIP, hipGetErrorString(e));
+    };
+    int rc = alloc(&d->tinv_m, n);
+    if (rc == SC_OK) rc = alloc(&d->wden_m, n);
+    if (rc == SC_OK) rc = alloc(&d->Bf, M);
+    if (rc == SC_OK) rc = alloc(&d->ZRf, M);
+    if (rc == SC_OK) rc = alloc(&d->zr, n + 1);
+    if (rc != SC_OK) return bail(rc);
+    const Fe q_m = to_mont(q);
+    const Fe qinv = from_mont(mont_inv(q_m));
+    d->c_inv = from_mont(mont_inv(to_mont(c)));
+    PoolTmpAsync tt, A, rev;
+    if ((rc = tt.get(M * sizeof(Fe))) != SC_OK || (rc = A.get(n * sizeof(Fe))) != SC_OK || (rc = rev.get(n * sizeof(Fe))) != SC_OK) return bail(rc);
+    PowTables *pq, *pqi, *pg;
+    if ((rc = get_pow(q, M, st, &pq)) != SC_OK) return bail(rc);
+    if ((rc = get_pow(qinv, n, st, &pqi)) != SC_OK) return bail(rc);
+    // t_j (M of them), 1 / t_j (n), A_(j+1) (n), S_(n-2-j) (n - 1): one fill and one scan each
+    hipLaunchKernelGGL(geo_fill_kernel, dim3(pt_blocks(M)), dim3(256), 0, st, tt.fe(), M, 0, n, (const Fe*)pq->lo, (const Fe*)pq->hi);
+    if ((rc = scan_products(tt.fe(), M, st)) != SC_OK) return bail(rc);
+    hipLaunchKernelGGL(geo_fill_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, d->tinv_m, n, 0, n, (const Fe*)pqi->lo, (const Fe*)pqi->hi);
+    if ((rc = scan_products(d->tinv_m, n, st)) != SC_OK) return bail(rc);
+    hipLaunchKernelGGL(geo_fill_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, A.fe(), n, 1, n, (const Fe*)pq->lo, (const Fe*)pq->hi);
+    if ((rc = scan_products(A.fe(), n, st)) != SC_OK) return bail(rc);
+    hipLaunchKernelGGL(geo_fill_kernel, dim3(pt_blocks(n - 1)), dim3(256), 0, st, rev.fe(), n - 1, 2, n, (const Fe*)pq->lo, (const Fe*)pq->hi);
+    if ((rc = scan_products(rev.fe(), n - 1, st)) != SC_OK) return bail(rc);
+    // scan[j] = A_(j+1).  A_(n-1) and A_n decide: a zero A_(n-1) means q^m = 1 for some m < n, i.e. the points repeat
+    Fe tail[2];
+    if (hipMemcpyAsync(tail, A.fe() + (n - 2), 2 * sizeof(Fe), hipMemcpyDeviceToHost, st) != hipSuccess) return bail(fail(SC_ERR_HIP, "copy of the scan's tail failed"));
+    if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(SC_ERR_HIP, "progression tables failed"));
+    const Fe an1_m = tail[0], an_m = tail[1];
+    if (fe_is_zero(an1_m)) return bail(fail(SC_ERR_UNSUPPORTED, "the points of the progression are not distinct"));
+    const Fe ia_m = mont_inv(an1_m);
+    const Fe k1_m = mont_mul(ia_m, ia_m);
+    const Fe k2_m = mont_mul(an_m, k1_m);
+    const Fe g = from_mont(mont_pow(to_mont(qinv), n - 2));
+    if ((rc = get_pow(g, n, st, &pg)) != SC_OK) return bail(rc);
+    hipLaunchKernelGGL(geo_wden_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, d->wden_m, n, (const Fe*)rev.fe(), k1_m, (const Fe*)pg->lo, (const Fe*)pg->hi);
+    hipLaunchKernelGGL(geo_zr_kernel, dim3(pt_blocks(n + 1)), dim3(256), 0, st, d->zr, n, (const Fe*)rev.fe(), (const Fe*)tt.fe(), k2_m);
+    hipLaunchKernelGGL(geo_from_mont_kernel, dim3(pt_blocks(M)), dim3(256), 0, st, tt.fe(), M);
+    if (hipGetLastError() != hipSuccess) return bail(fail(SC_ERR_HIP, "progression table launch failed"));
+    const Fe rt = canonical_root(logM);
+    if ((rc = ntt_device(tt.fe(), d->Bf, logM, rt, false, NttOpts(), st)) != SC_OK) return bail(rc);
+    NttOpts o;
+    o.in_limit = n;
+    if ((rc = ntt_device(d->zr, d->ZRf, logM, rt, false, o, st)) != SC_OK) return bail(rc);
+    *out = d;
+    return SC_OK;
+}
+
+const PowTables* geo_cpow(const sc_geodomain* d, Fe base, uint64_t count, hipStream_t st, int* rc) {
+    if (d->unit) { *rc = SC_OK; return nullptr; }
+    PowTables* pw = nullptr;
+    *rc = get_pow(base, count, st, &pw);
+    return pw;
+}
+
+// values at all n points of the polynomial p[0..len), len <= n; bx, by: M entries each
+int geodomain_evaluate_chunk(const sc_geodomain* d, const Fe* p, uint64_t len, Fe* dst, Fe* bx, Fe* by, hipStream_t st) {
+    const uint64_t n = d->n, M = d->M;
+    if (len == 0) { HIPCHK(hipMemsetAsync(dst, 0, n * sizeof(Fe), st)); return SC_OK; }
+    int rc;
+    const PowTables* pc = geo_cpow(d, d->c, n, st, &rc);
+    SCCHK(rc);
+    hipLaunchKernelGGL(geo_eval_in_kernel, dim3(pt_blocks(len)), dim3(256), 0, st, p, len, pc ? (const Fe*)pc->lo : nullptr, pc ? (const Fe*)pc->hi : nullptr, (const Fe*)d->tinv_m, bx);
+    const Fe rt = canonical_root(d->logM);
+    NttOpts o;
+    o.in_limit = len;
+    SCCHK(ntt_device(bx, by, d->logM, rt, false, o, st));
+    hipLaunchKernelGGL(geo_corr_kernel, dim3(pt_blocks(M)), dim3(256), 0, st, (const Fe*)by, (const Fe*)d->Bf, bx, M, ninv_scaled(d->logM, 2));
+    SCCHK(ntt_device(bx, by, d->logM, root_inverse(rt, M), false, NttOpts(), st));
+    hipLaunchKernelGGL(geo_mul_tab_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, (const Fe*)by, (const Fe*)d->tinv_m, dst, n);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+int geodomain_evaluate(const sc_geodomain* d, const Fe* coeffs, uint64_t m, Fe* out, hipStream_t st) {
+    const uint64_t n = d->n, M = d->M;
+    PoolTmpAsync bx, by;
+    SCCHK(bx.get(M * sizeof(Fe)));
+    SCCHK(by.get(M * sizeof(Fe)));
+    if (m <= n) return geodomain_evaluate_chunk(d, coeffs, m, out, bx.fe(), by.fe(), st);
+    // longer polynomials: Horner over chunks of n coefficients, y_i = x_i^n = c^n (q^n)^i
+    PoolTmpAsync y, vals;
+    SCCHK(y.get(n * sizeof(Fe)));
+    SCCHK(vals.get(n * sizeof(Fe)));
+    const Fe cn_m = mont_pow(to_mont(d->c), n);
+    const Fe qn = from_mont(mont_pow(to_mont(d->q), n));
+    PowTables* py;
+    SCCHK(get_pow(qn, n, st, &py));
+    hipLaunchKernelGGL(geo_chunk_power_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, y.fe(), n, cn_m, (const Fe*)py->lo, (const Fe*)py->hi);
+    const uint64_t chunks = (m + n - 1) / n;
+    for (uint64_t j = chunks; j-- > 0;) {
+        const uint64_t len = (j == chunks - 1) ? m - j * n : n;
+        if (j == chunks - 1) { SCCHK(geodomain_evaluate_chunk(d, coeffs + j * n, len, out, bx.fe(), by.fe(), st)); continue; }
+        SCCHK(geodomain_evaluate_chunk(d, coeffs + j * n, len, vals.fe(), bx.fe(), by.fe(), st));
+        hipLaunchKernelGGL(pt_horner_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, out, (const Fe*)y.fe(), (const Fe*)vals.fe(), n);
+    }
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
+// is d_points[i + 1] == d_points[i] * ratio for all i < n - 1, with ratio = points[1] / points[0]?  (one small kernel, one sync)
+int geodomain_detect(const Fe* d_points, uint64_t n, Fe* first, Fe* ratio, bool* is_geometric, hipStream_t st) {
+    *is_geometric = false;
+    if (n < 2) return SC_OK;
+    Fe head[2];
+    HIPCHK(hipMemcpyAsync(head, d_points, 2 * sizeof(Fe), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (fe_is_zero(head[0]) || fe_is_zero(head[1]) || fe_ge_p(head[0]) || fe_ge_p(head[1])) return SC_OK;
+    const Fe r_m = mont_mul(to_mont(head[1]), mont_inv(to_mont(head[0])));
+    void* fl;
+    SCCHK(scratch(7, 64, &fl));
+    HIPCHK(hipMemsetAsync(fl, 0, 4, st));
+    hipLaunchKernelGGL(geo_detect_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, d_points, n, r_m, (uint32_t*)fl);
+    HIPCHK(hipGetLastError());
+    uint32_t bad = 1;
+    HIPCHK(hipMemcpyAsync(&bad, fl, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (bad) return SC_OK;
+    *first = head[0];
+    *ratio = from_mont(r_m);
+    *is_geometric = true;
+    return SC_OK;
+}
+
+// the progression tables of device points if they are a progression of at least two distinct points, else *out = nullptr
+int geodomain_of_points(const Fe* d_points, uint64_t n, sc_geodomain** out, hipStream_t st) {
+    *out = nullptr;
+    Fe first, ratio;
+    bool is = false;
+    SCCHK(geodomain_detect(d_points, n, &first, &ratio, &is, st));
+    if (!is) return SC_OK;
+    int rc = geodomain_create(first, ratio, n, out, st);
+    if (rc == SC_ERR_UNSUPPORTED) { *out = nullptr; return SC_OK; }
+    return rc;
+}
+
+int geodomain_interpolate(const sc_geodomain* d, const Fe* values, Fe* out, hipStream_t st) {
+    const uint64_t n = d->n, M = d->M;
+    PoolTmpAsync bx, by;
+    SCCHK(bx.get(M * sizeof(Fe)));
+    SCCHK(by.get(M * sizeof(Fe)));
+    int rc;
+    const PowTables* pi = geo_cpow(d, d->c_inv, n, st, &rc);
+    SCCHK(rc);
+    const Fe rt = canonical_root(d->logM), rti = root_inverse(rt, M);
+    const Fe c_m2 = ninv_scaled(d->logM, 2);
+    NttOpts o;
+    o.in_limit = n;
+    // s_m = sum_i (v_i / Z'(q^i)) q^(i m): weights, correlation with t, division by t_m
+    hipLaunchKernelGGL(geo_mul_tab_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, values, (const Fe*)d->wden_m, bx.fe(), n);
+    SCCHK(ntt_device(bx.fe(), by.fe(), d->logM, rt, false, o, st));
+    hipLaunchKernelGGL(geo_corr_kernel, dim3(pt_blocks(M)), dim3(256), 0, st, (const Fe*)by.fe(), (const Fe*)d->Bf, bx.fe(), M, c_m2);
+    SCCHK(ntt_device(bx.fe(), by.fe(), d->logM, rti, false, NttOpts(), st));
+    hipLaunchKernelGGL(geo_mul_tab_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, (const Fe*)by.fe(), (const Fe*)d->tinv_m, bx.fe(), n);
+    // rev(P) = rev(Z) * S mod y^n
+    SCCHK(ntt_device(bx.fe(), by.fe(), d->logM, rt, false, o, st));
+    hipLaunchKernelGGL(pt_mul_scaled_kernel, dim3(pt_blocks(M)), dim3(256), 0, st, (const Fe*)by.fe(), (const Fe*)d->ZRf, bx.fe(), M, c_m2);
+    SCCHK(ntt_device(bx.fe(), by.fe(), d->logM, rti, false, NttOpts(), st));
+    hipLaunchKernelGGL(geo_rev_scale_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, (const Fe*)by.fe(), n, pi ? (const Fe*)pi->lo : nullptr, pi ? (const Fe*)pi->hi : nullptr, out);
+    HIPCHK(hipGetLastError());
     return SC_OK;
 }
 
@@ -2296,7 +2544,7 @@ int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, 
 int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
                       const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
                       sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!d_codeword || !trees_out || !roots_out || (rounds > 1 && (!vecs_out || !alphas_out)) || rounds < 1) return fail(SC_ERR_BAD_ARG, "null argument");
     if (N < 2 || !is_pow2(N) || rounds > 60 || (N >> (rounds - 1)) < 1) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
@@ -2335,6 +2583,7 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
             vecs_out[r] = nxt;
             ++made_vecs;
         }
+        root_poll_unlocked(lk, trees_out[r]);
         rc = merkle_root_wait(trees_out[r]);
         if (rc != SC_OK) return undo(rc);
         memcpy(roots_out + 64 * r, trees_out[r]->root, 64);
@@ -2625,8 +2874,40 @@ int sc_polytree_free(sc_polytree_t* tree) {
 }
 
 // host-buffer forms of ntt.py:66-80, :82-100, :102-130
+// host points -> their progression tables (nullptr when they are not a progression of >= 2 distinct points: the tree serves those)
+static int host_points_progression(const void* points, uint64_t k, sc_geodomain** gd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    *gd = nullptr;
+    if (!points) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (k < 2) return SC_OK;
+    PoolTmp dp;
+    SCCHK(dp.get(k * sizeof(Fe)));
+    SCCHK(upload(dp.p, points, k * sizeof(Fe), g.stream));
+    int rc = geodomain_of_points(dp.fe(), k, gd, g.stream);
+    if (hipStreamSynchronize(g.stream) != hipSuccess && rc == SC_OK) rc = fail(SC_ERR_HIP, "progression tables failed");   // dp goes back to the pool
+    return rc;
+}
+
 int sc_zerofier(const void* points, uint64_t k, void* out) {
     if (k == 0) return SC_OK;
+    sc_geodomain* gd = nullptr;
+    SCCHK(host_points_progression(points, k, &gd));
+    if (gd) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PoolTmp d;
+        int rc = d.get((k + 1) * sizeof(Fe));
+        if (rc == SC_OK) {
+            const PowTables* pc = geo_cpow(gd, gd->c, k + 1, g.stream, &rc);
+            if (rc == SC_OK) {
+                hipLaunchKernelGGL(geo_zerofier_out_kernel, dim3(pt_blocks(k + 1)), dim3(256), 0, g.stream, (const Fe*)gd->zr, k, pc ? (const Fe*)pc->lo : nullptr,
+                                   pc ? (const Fe*)pc->hi : nullptr, d.fe());
+                rc = download(out, d.p, (k + 1) * sizeof(Fe), g.stream);
+            }
+        }
+        geodomain_release(gd);
+        return rc;
+    }
     sc_polytree_t* t = nullptr;
     SCCHK(sc_polytree_build(points, k, &t));
     int rc;
@@ -2644,6 +2925,20 @@ int sc_zerofier(const void* points, uint64_t k, void* out) {
 }
 int sc_evaluate(const void* coeffs, uint64_t m, const void* points, uint64_t k, void* out) {
     if (k == 0) return SC_OK;
+    sc_geodomain* gd = nullptr;
+    SCCHK(host_points_progression(points, k, &gd));
+    if (gd) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PoolTmp dc, dv;
+        int rc = dc.get((m ? m : 1) * sizeof(Fe));
+        if (rc == SC_OK) rc = dv.get(k * sizeof(Fe));
+        if (rc == SC_OK) rc = upload(dc.p, coeffs, m * sizeof(Fe), g.stream);
+        if (rc == SC_OK) rc = geodomain_evaluate(gd, dc.fe(), m, dv.fe(), g.stream);
+        if (rc == SC_OK) rc = download(out, dv.p, k * sizeof(Fe), g.stream);
+        else (void)hipStreamSynchronize(g.stream);
+        geodomain_release(gd);
+        return rc;
+    }
     sc_polytree_t* t = nullptr;
     SCCHK(sc_polytree_build(points, k, &t));
     int rc;
@@ -2663,6 +2958,20 @@ int sc_evaluate(const void* coeffs, uint64_t m, const void* points, uint64_t k, 
 }
 int sc_interpolate(const void* points, const void* values, uint64_t k, void* out) {
     if (k == 0) return SC_OK;
+    sc_geodomain* gd = nullptr;
+    SCCHK(host_points_progression(points, k, &gd));
+    if (gd) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PoolTmp dv, dout;
+        int rc = dv.get(k * sizeof(Fe));
+        if (rc == SC_OK) rc = dout.get(k * sizeof(Fe));
+        if (rc == SC_OK) rc = upload(dv.p, values, k * sizeof(Fe), g.stream);
+        if (rc == SC_OK) rc = geodomain_interpolate(gd, dv.fe(), dout.fe(), g.stream);
+        if (rc == SC_OK) rc = download(out, dout.p, k * sizeof(Fe), g.stream);
+        else (void)hipStreamSynchronize(g.stream);
+        geodomain_release(gd);
+        return rc;
+    }
     sc_polytree_t* t = nullptr;
     SCCHK(sc_polytree_build(points, k, &t));
     int rc;
@@ -2678,6 +2987,57 @@ int sc_interpolate(const void* points, const void* values, uint64_t k, void* out
     sc_polytree_free(t);
     return rc;
 }
+
+// ---- geometric progressions: fast_zerofier / fast_evaluate / fast_interpolate (ntt.py:66-130) on {first * ratio^i} ------------
+int sc_geodomain_create(const uint64_t first[2], const uint64_t ratio[2], uint64_t n, sc_geodomain_t** domain, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!first || !ratio || !domain) return fail(SC_ERR_BAD_ARG, "null argument");
+    return geodomain_create(fe_from(first), fe_from(ratio), n, domain, pick_stream(stream));
+}
+uint64_t sc_geodomain_points(const sc_geodomain_t* domain) { return domain ? domain->n : 0; }
+int sc_geodomain_detect_dev(const void* d_points, uint64_t n, uint64_t first[2], uint64_t ratio[2], int* is_geometric, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!d_points || !first || !ratio || !is_geometric) return fail(SC_ERR_BAD_ARG, "null argument");
+    Fe f{0, 0}, r{0, 0};
+    bool is = false;
+    SCCHK(geodomain_detect((const Fe*)d_points, n, &f, &r, &is, pick_stream(stream)));
+    *is_geometric = is ? 1 : 0;
+    if (is) { first[0] = f.lo; first[1] = f.hi; ratio[0] = r.lo; ratio[1] = r.hi; }
+    return SC_OK;
+}
+int sc_geodomain_zerofier_dev(const sc_geodomain_t* domain, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!domain || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    hipStream_t st = pick_stream(stream);
+    int rc;
+    const PowTables* pc = geo_cpow(domain, domain->c, domain->n + 1, st, &rc);
+    SCCHK(rc);
+    hipLaunchKernelGGL(geo_zerofier_out_kernel, dim3(pt_blocks(domain->n + 1)), dim3(256), 0, st, (const Fe*)domain->zr, domain->n, pc ? (const Fe*)pc->lo : nullptr,
+                       pc ? (const Fe*)pc->hi : nullptr, (Fe*)d_out);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+int sc_geodomain_evaluate_dev(const sc_geodomain_t* domain, const void* d_coeffs, uint64_t m, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!domain || !d_out || (m && !d_coeffs)) return fail(SC_ERR_BAD_ARG, "null argument");
+    return geodomain_evaluate(domain, (const Fe*)d_coeffs, m, (Fe*)d_out, pick_stream(stream));
+}
+int sc_geodomain_interpolate_dev(const sc_geodomain_t* domain, const void* d_values, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!domain || !d_values || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    return geodomain_interpolate(domain, (const Fe*)d_values, (Fe*)d_out, pick_stream(stream));
+}
+int sc_geodomain_free(sc_geodomain_t* domain) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    geodomain_release(domain);
+    return SC_OK;
+}
+
 
 // ---- MPolynomial.evaluate_symbolic in the value domain
 int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, void* stream) {

@@ -84,10 +84,16 @@ class Fri:
         # N_r = N / 2^r, so every round's condition is omega^N == 1: checked once, before anything is enqueued
         assert(self.omega ^ (len(codeword) - 1) == self.omega.inverse()), "error in commit: omega does not have the right order!"
         prior = proof_stream.objects
-        if (len(codeword) >= 2 and codeword._tree is None and len(prior) + rounds < 999 and all(type(o) is bytes and len(o) < 256 for o in prior)
-                and len(set(map(id, prior))) == len(prior) and sum(map(len, prior)) + 67 * rounds < 60000):
+        # only a plain ProofStream: a subclass may derive its challenges differently (the reference's SignatureProofStream prefixes
+        # the document), and the library computes SHAKE-256(pickle(objects)) itself.  The size test counts what the C side counts
+        # (3 bytes of pickle opcodes per prior item, 67 per root of this commit); the library still answers "unsupported" for
+        # anything else it does not take, and then the Python loop runs.
+        codewords = None
+        if (type(proof_stream) is ProofStream and len(codeword) >= 2 and codeword._tree is None and len(prior) + rounds < 999
+                and all(type(o) is bytes and len(o) < 256 for o in prior) and len(set(map(id, prior))) == len(prior)
+                and sum(len(o) + 3 for o in prior) + 67 * rounds < 60000):
             codewords = self._commit_in_library(codeword, proof_stream, rounds)
-        else:
+        if codewords is None:
             codewords = self._commit_rounds(codeword, proof_stream, rounds)
         # the last codeword goes out in the clear, as a plain list (it is pickled into the transcript)
         proof_stream.push(codewords[-1].tolist())
@@ -101,8 +107,11 @@ class Fri:
         trees = (ctypes.c_void_p * rounds)()
         roots = ctypes.create_string_buffer(64 * rounds)
         alphas = (ctypes.c_uint64 * max(2, 2 * (rounds - 1)))()
-        _sc._check(_sc.lib().sc_fri_commit_dev(codeword.vec.ptr, len(codeword), _sc.fe_bytes(self.offset.value), _sc.fe_bytes(self.omega.value), rounds,
-                                               b"".join(prior), (ctypes.c_uint32 * max(1, k))(*map(len, prior)), k, vecs, trees, roots, alphas, None))
+        rc = _sc.lib().sc_fri_commit_dev(codeword.vec.ptr, len(codeword), _sc.fe_bytes(self.offset.value), _sc.fe_bytes(self.omega.value), rounds,
+                                         b"".join(prior), (ctypes.c_uint32 * max(1, k))(*map(len, prior)), k, vecs, trees, roots, alphas, None)
+        if rc == _sc.SC_ERR_UNSUPPORTED:
+            return None                                  # a transcript shape the library does not write: the caller runs _commit_rounds
+        _sc._check(rc)
         codewords, cur, raw = [], codeword, roots.raw
         for r in range(rounds):
             n = len(codeword) >> r

@@ -108,8 +108,9 @@ def fast_multiply(lhs, rhs, primitive_root, root_order):
     return Polynomial(_unpack(out.raw, degree + 1, field))
 
 
-# Domains of at least this many points go to the device's level-batched subproduct tree (csrc/polytree.cuh); smaller ones
-# follow the reference's recursion below.  Zerofier, values and interpolant are unique, so both give the same lists.
+# Domains of at least this many points go to the device -- the level-batched subproduct tree (csrc/polytree.cuh), or, when the
+# points are a geometric progression, a handful of convolutions (csrc/geoseq.cuh); smaller ones follow the reference's
+# recursion below.  Zerofier, values and interpolant are unique, so all three give the same lists.
 DEVICE_TREE_MIN_POINTS = 16
 
 _tree_memo = {}           # points (as packed bytes) -> PolyTree; fast_interpolate / fast_evaluate revisit the same domains
@@ -125,7 +126,9 @@ def _device_tree(domain):
             for t in _tree_memo.values():
                 t.free()
             _tree_memo.clear()
-        tree = _tree_memo[key] = _sc.PolyTree(key)
+        # a geometric progression (the trace domain {omicron^i}, fast_stark.py:84-90) gets the progression tables, anything
+        # else the subproduct tree: same zerofier, values and interpolant either way
+        tree = _tree_memo[key] = _sc.domain_tables(key)
     return tree
 
 
@@ -213,7 +216,23 @@ class DeviceDomain:
         assert(vec.n > 0), "empty domain"
         _require_main_field(field)
         self.field = field
-        self.tree = _sc.PolyTree(vec)
+        self.tree = _sc.domain_tables(vec)
+
+    @classmethod
+    def geometric(cls, first, ratio, count):
+        """the domain first * ratio^i, i < count (FieldElements), without materialising or inspecting the points: the trace
+        domain of fast_stark.py:84-90 is {omicron^i}.  Falls back to the general tree where the progression tables do not apply."""
+        field = ratio.field
+        _require_main_field(field)
+        tables = _sc.GeoDomain.create(first.value, ratio.value, count) if count >= 2 else None
+        if tables is None:
+            ones = DeviceVector.from_bytes((first.value).to_bytes(16, "little") * count)
+            points = DeviceVector(count)
+            _sc._check(_sc.lib().sc_scale_dev(ones.ptr, points.ptr, count, _sc.fe_bytes(ratio.value), None))
+            return cls(points, field)
+        domain = cls.__new__(cls)
+        domain.field, domain.tree = field, tables
+        return domain
 
     def __len__(self):
         return self.tree.k

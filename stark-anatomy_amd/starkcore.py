@@ -20,6 +20,7 @@ SC_ERR_NOT_POW2 = -2
 SC_ERR_ROOT_ORDER = -3
 SC_ERR_ROOT_NOT_PRIMITIVE = -4
 SC_ERR_DIV_ZERO = -5
+SC_ERR_UNSUPPORTED = -7
 
 # every symbol include/starkcore.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -103,6 +104,13 @@ SIGNATURES = {
     "sc_polytree_evaluate_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "sc_polytree_interpolate_dev": (_int, [_vp, _vp, _vp, _vp]),
     "sc_polytree_free": (_int, [_vp]),
+    "sc_geodomain_create": (_int, [_vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "sc_geodomain_points": (_u64, [_vp]),
+    "sc_geodomain_detect_dev": (_int, [_vp, _u64, _vp, _vp, ctypes.POINTER(_int), _vp]),
+    "sc_geodomain_zerofier_dev": (_int, [_vp, _vp, _vp]),
+    "sc_geodomain_evaluate_dev": (_int, [_vp, _vp, _u64, _vp, _vp]),
+    "sc_geodomain_interpolate_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "sc_geodomain_free": (_int, [_vp]),
 }
 
 _lib = None
@@ -364,6 +372,77 @@ class PolyTree:
             self.free()
         except Exception:
             pass
+
+
+class GeoDomain:
+    """Owner of an sc_geodomain_t: the tables of a domain that is a geometric progression first * ratio^i, i < n (the trace
+    domain {omicron^i} of code/fast_stark.py:84-90).  Same three operations as PolyTree, same results (zerofier, values and
+    interpolant are unique), a handful of transforms instead of a tree.  The operations are enqueued on the library stream."""
+
+    def __init__(self, first, ratio, n):
+        """first, ratio: int residues; n >= 2 distinct points -- StarkCoreError(unsupported) otherwise (see `create`)"""
+        self.first, self.ratio, self.k = int(first), int(ratio), int(n)
+        h = _vp()
+        _check(lib().sc_geodomain_create(fe_bytes(first), fe_bytes(ratio), self.k, ctypes.byref(h), None))
+        self._h = h
+
+    @classmethod
+    def create(cls, first, ratio, n):
+        """the domain, or None where the progression path does not apply (fewer than two points, repeated points)"""
+        dom = cls.__new__(cls)
+        dom.first, dom.ratio, dom.k, dom._h = int(first), int(ratio), int(n), None
+        h = _vp()
+        rc = lib().sc_geodomain_create(fe_bytes(first), fe_bytes(ratio), dom.k, ctypes.byref(h), None)
+        if rc == SC_ERR_UNSUPPORTED:
+            return None
+        _check(rc)
+        dom._h = h
+        return dom
+
+    @classmethod
+    def detect(cls, points):
+        """points: DeviceVector.  The GeoDomain of these points if they form a progression of distinct points, else None."""
+        if points.n < 2:
+            return None
+        first, ratio, flag = (ctypes.c_uint64 * 2)(), (ctypes.c_uint64 * 2)(), _int(0)
+        _check(lib().sc_geodomain_detect_dev(points.ptr, points.n, first, ratio, ctypes.byref(flag), None))
+        if not flag.value:
+            return None
+        return cls.create(first[0] | (first[1] << 64), ratio[0] | (ratio[1] << 64), points.n)
+
+    def zerofier(self):
+        out = DeviceVector(self.k + 1)
+        _check(lib().sc_geodomain_zerofier_dev(self._h, out.ptr, None))
+        return out
+
+    def evaluate(self, coeffs):
+        out = DeviceVector(self.k)
+        _check(lib().sc_geodomain_evaluate_dev(self._h, coeffs.ptr, coeffs.n, out.ptr, None))
+        return out
+
+    def interpolate(self, values):
+        assert values.n == self.k
+        out = DeviceVector(self.k)
+        _check(lib().sc_geodomain_interpolate_dev(self._h, values.ptr, out.ptr, None))
+        return out
+
+    def free(self):
+        if self._h is not None and _lib is not None:
+            _lib.sc_geodomain_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def domain_tables(points):
+    """the device structure that serves fast_zerofier / fast_evaluate / fast_interpolate over `points` (DeviceVector or packed
+    bytes): the progression tables where the points are a geometric progression of distinct points, the subproduct tree otherwise"""
+    points = points if isinstance(points, DeviceVector) else DeviceVector.from_bytes(points)
+    return GeoDomain.detect(points) or PolyTree(points)
 
 
 _struct_cache = {}
