@@ -23,6 +23,7 @@ CLOCK_RAMP_MS of untimed steps and reported beside it as `clock_ramp.steady_stat
 start-up runs at the board's idle clock).  `cpu_baseline` and `extras` (Fri.prove, LDE, census, Merkle, ...) follow, rank 0, N = 1.
 """
 import argparse
+import itertools
 import json
 import math
 import os
@@ -600,30 +601,46 @@ def run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gp
     dist.destroy_process_group()
 
 
-def stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend):
-    """sharded_stark.ShardedFastStark.prove (reference code/fast_stark.py:76-178) on the synthetic 2-register AIR (a, b) -> (b, a*a + b)
-    with a 2^(log_fri - 4)-row randomized trace: (seconds summed over `steps` proofs, max over ranks per proof; record for rank 0).
-    Every rank must end with the same proof; rank 0 verifies it with FastStark.verify outside the timed region."""
-    import hashlib
-    import torch
+def synthetic_stark_instance(log_fri, s=40):
+    """The synthetic configs[4] workload: the 2-register AIR (a, b) -> (b, a*a + b) over a trace of T = 2^(log_fri - 4) - 4 s rows,
+    so that the randomized trace has 2^(log_fri - 4) rows and the FRI domain 2^log_fri points (expansion factor 4).  Returns
+    (field, T, packed columns (bytes per register), air, boundary): the columns are handed to the prover as a device-resident
+    fast_stark.DeviceTrace -- a trace of 2^20 rows as the reference's list of lists is two million Python objects."""
     from algebra import Field, FieldElement
     from multivariate import MPolynomial
-    from sharded_stark import ShardedFastStark
-    k, s = log_fri - 4, 40
+    k = log_fri - 4
     field = Field.main()
+    p = field.p
     T = (1 << k) - 4 * s
-    a, b, rows = 3, 5, []
+    a, b = 3, 5
+    col_a, col_b = [], []
     for _ in range(T):
-        rows.append((a, b))
-        a, b = b, (a * a + b) % field.p
-    trace = [[FieldElement(x, field), FieldElement(y, field)] for x, y in rows]
+        col_a.append(a)
+        col_b.append(b)
+        a, b = b, (a * a + b) % p
+    pack = lambda col: b"".join(map(int.to_bytes, col, itertools.repeat(16), itertools.repeat("little")))
     v = MPolynomial.variables(5, field)                  # X, a, b, a', b'
     air = [v[3] - v[2], v[4] - v[1] * v[1] - v[2]]
-    boundary = [(0, 0, trace[0][0]), (0, 1, trace[0][1]), (T - 1, 1, trace[T - 1][1])]
+    boundary = [(0, 0, FieldElement(col_a[0], field)), (0, 1, FieldElement(col_b[0], field)), (T - 1, 1, FieldElement(col_b[T - 1], field))]
+    return field, T, [pack(col_a), pack(col_b)], air, boundary
+
+
+def stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend, phases=False):
+    """sharded_stark.ShardedFastStark.prove (reference code/fast_stark.py:76-178) on the synthetic 2-register AIR (a, b) -> (b, a*a + b)
+    with a 2^(log_fri - 4)-row randomized trace that is RESIDENT IN HBM as columns when the timed region starts: (seconds summed
+    over `steps` proofs, max over ranks per proof; record for rank 0).  Every rank must end with the same proof; rank 0 verifies
+    it with FastStark.verify outside the timed region.  phases: one more (untimed) proof with the per-phase breakdown."""
+    import hashlib
+    import torch
+    from fast_stark import DeviceTrace
+    from sharded_stark import ShardedFastStark
+    s = 40
+    field, T, packed, air, boundary = synthetic_stark_instance(log_fri, s)
     stark = ShardedFastStark(field, 4, s, 2 * s, 2, T, rank, world, dev)
     assert stark.fri_domain_length == 1 << log_fri
+    trace = DeviceTrace.from_packed(packed, field)
     t0 = time.perf_counter()
-    tz, layer, root = stark.preprocess()
+    tz, layer, root = stark.preprocess(device_resident=True)
     torch.cuda.synchronize()
     preprocess_s = time.perf_counter() - t0
     for _ in range(warmup):
@@ -646,16 +663,25 @@ def stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     same_everywhere = bool(torch.equal(lo, hi))
+    phase_ms = None
+    if phases:
+        stark.phase_log = []
+        stark.prove(trace, air, boundary, tz, layer)
+        phase_ms = [[name, round(1e3 * sec, 3)] for name, sec in stark.phase_log]
+        stark.phase_log = None
     rec = None
     if rank == 0:
         t0 = time.perf_counter()
         verifies = bool(stark.verify(proof, air, boundary, root))
         verify_s = time.perf_counter() - t0
-        rec = {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_%dgpu" % (k, log_fri, world), "log2n": log_fri, "world_size": world,
+        rec = {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_%dgpu" % (log_fri - 4, log_fri, world), "log2n": log_fri, "world_size": world,
                "registers": 2, "colinearity_checks": s, "expansion_factor": 4, "ms_per_proof": 1e3 * elapsed / steps,
+               "trace": "device-resident columns (fast_stark.DeviceTrace), generated on the host outside the timed region",
                "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace-domain polynomials replicated",
                "proof_bytes": len(proof), "proof_sha256_16": digest.hex()[:16], "same_proof_on_every_rank": same_everywhere,
                "verify_accepts": verifies, "verify_s": verify_s, "preprocess_s": preprocess_s, "runs_ms": [round(x * 1e3, 3) for x in t.tolist()]}
+        if phase_ms is not None:
+            rec["phases_ms_synchronised_after_each"] = phase_ms
     return elapsed, same_everywhere, rec
 
 
@@ -666,7 +692,7 @@ def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shar
     ngpu = torch.cuda.device_count()
     log_fri = args.log2n or (16 if shared_gpus else 20)
     steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 1))
-    elapsed, same_everywhere, rec = stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend)
+    elapsed, same_everywhere, rec = stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend, phases=True)
     if rank == 0:
         rec["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
         out = {"metric": "stark_prove_ms", "value": 1e3 * elapsed / steps, "unit": "ms", "n_gpus": world, "steps": steps, "warmup": warmup,

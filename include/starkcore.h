@@ -53,6 +53,10 @@ int sc_init(int device);               /* idempotent; selects the device and cre
 int sc_shutdown(void);                 /* frees plans, scratch and the stream */
 const char* sc_last_error(void);
 int sc_synchronize(void);              /* wait for the library stream */
+/* The library stream as a raw hipStream_t, for callers that put their other device work on the same stream (no ordering needed
+ * then), and a two-way, event-based ordering of the library stream with another stream that never blocks the host. */
+int sc_stream(void** stream_out);
+int sc_stream_join(void* other_stream);
 /* tuning knobs for experiments (defaults are the measured optimum; -1 = choose by size where applicable): key in
  * {"max_tile_log","loge","max_col_log","min_tiles_log","single_pass_max_log","max_digit_log","direct_tw_max_log",
  *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune"}.  Plans are re-derived on the next call; results
@@ -257,6 +261,11 @@ int sc_shake256(const void* in, uint64_t len, void* out, uint64_t out_len);
  * randomizer polynomial of FastStark.prove (fast_stark.py:117: one os.urandom(17) draw per coefficient) without a Python object
  * per coefficient.  Synchronous (the bytes are the caller's host memory). */
 int sc_sample_bytes_dev(const void* bytes, uint64_t count, uint32_t width, void* d_out, void* stream);
+/* The same with the draws made by the library: `count` times getrandom(width bytes) -- what os.urandom(width) is -- split over
+ * host threads into a pinned staging buffer, one asynchronous copy, Field.sample on the device.  Enqueued on `stream`.  For
+ * callers whose os.urandom is the operating system's (a patched, seeded os.urandom must go through sc_sample_bytes_dev, whose
+ * bytes and order are the caller's). */
+int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* stream);
 int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]);
 int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len);
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */

@@ -6,6 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <thread>
+#include <sys/random.h>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -1620,6 +1624,36 @@ int sc_synchronize(void) {
     return SC_OK;
 }
 
+// The library's own stream as a raw hipStream_t: a caller that runs its other device work (torch tensors, collectives) on THIS
+// stream -- torch.cuda.ExternalStream(sc_stream()) -- needs no ordering with the library at all.
+int sc_stream(void** stream_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!stream_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    *stream_out = (void*)g.stream;
+    return SC_OK;
+}
+
+// Order the library stream and another stream with each other WITHOUT blocking the host: everything enqueued so far on either
+// is finished before anything enqueued later on the other starts (two events, two stream waits).
+int sc_stream_join(void* other) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t o = (hipStream_t)other;
+    if (o == g.stream) return SC_OK;
+    (void)pick_stream(other);                              // frees must respect this stream from now on
+    hipEvent_t a = event_get(), b = event_get();
+    if (!a || !b) { if (a) g_event_pool.push_back(a); if (b) g_event_pool.push_back(b); HIPCHK(hipStreamSynchronize(o)); HIPCHK(hipStreamSynchronize(g.stream)); return SC_OK; }
+    hipError_t e = hipEventRecord(a, o);
+    if (e == hipSuccess) e = hipStreamWaitEvent(g.stream, a, 0);
+    if (e == hipSuccess) e = hipEventRecord(b, g.stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(o, b, 0);
+    g_event_pool.push_back(a);                             // a recorded event may be re-recorded once the waits are enqueued
+    g_event_pool.push_back(b);
+    if (e != hipSuccess) return fail(SC_ERR_HIP, hipGetErrorString(e));
+    return SC_OK;
+}
+
 int sc_set_tuning(const char* key, int value) {
     std::lock_guard<std::mutex> lk(g_mu);
     std::string k(key ? key : "");
@@ -1707,6 +1741,65 @@ int sc_sample_bytes_dev(const void* bytes, uint64_t count, uint32_t width, void*
     HIPCHK(hipStreamSynchronize(st));               // `bytes` is the caller's host memory
     return SC_OK;
 }
+// `count` draws of os.urandom(width) (code/fast_stark.py:116-117: one per coefficient of the randomizer polynomial) made by the
+// library itself -- getrandom(2), which is what os.urandom calls -- and sampled into HBM (Field.sample, algebra.py:116-120).
+// At a 2^24 FRI domain that is 36 MB of kernel randomness: 40-50 ms from one thread, the whole proof's budget; the kernel's
+// generator is per-CPU, so the draw is split over threads writing into one pinned staging buffer (16 threads: 3 ms), which then
+// goes to the device with one asynchronous copy.  Enqueued on `stream`; the staging buffer is reused by the next call, which
+// first waits for this call's copy.
+namespace {
+uint8_t* g_rand_host = nullptr;
+size_t g_rand_host_bytes = 0;
+hipEvent_t g_rand_copied = nullptr;
+}
+int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!count) return SC_OK;
+    if (!d_out || width == 0 || width > 32) return fail(SC_ERR_BAD_ARG, "byte strings of 1..32 bytes expected");
+    hipStream_t st = pick_stream(stream);
+    const size_t bytes = (size_t)count * width;
+    if (g_rand_copied) HIPCHK(hipEventSynchronize(g_rand_copied));            // the previous call's copy has left the buffer
+    if (g_rand_host_bytes < bytes) {
+        if (g_rand_host) { (void)hipHostFree(g_rand_host); g_rand_host = nullptr; g_rand_host_bytes = 0; }
+        HIPCHK(hipHostMalloc((void**)&g_rand_host, bytes, hipHostMallocDefault));
+        g_rand_host_bytes = bytes;
+    }
+    if (!g_rand_copied) HIPCHK(hipEventCreateWithFlags(&g_rand_copied, hipEventDisableTiming));
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthreads = bytes / (256u << 10);                                    // at least 256 KiB per thread
+    if (nthreads > 32) nthreads = 32;
+    if (hw && nthreads > hw) nthreads = hw;
+    if (nthreads < 1) nthreads = 1;
+    std::atomic<int> failed{0};
+    auto fill = [&](size_t a, size_t b) {
+        while (a < b) {
+            size_t want = b - a < (1u << 20) ? b - a : (1u << 20);
+            ssize_t r = getrandom(g_rand_host + a, want, 0);
+            if (r < 0) { if (errno == EINTR) continue; failed = 1; return; }
+            a += (size_t)r;
+        }
+    };
+    if (nthreads == 1) fill(0, bytes);
+    else {
+        std::vector<std::thread> pool;
+        const size_t per = (bytes + nthreads - 1) / nthreads;
+        for (size_t i = 0; i < nthreads; ++i) {
+            const size_t a = i * per, b = a + per < bytes ? a + per : bytes;
+            if (a < b) pool.emplace_back(fill, a, b);
+        }
+        for (auto& t : pool) t.join();
+    }
+    if (failed) return fail(SC_ERR_HIP, "getrandom failed");
+    void* buf;
+    SCCHK(scratch(6, bytes + 256, &buf));
+    HIPCHK(hipMemcpyAsync(buf, g_rand_host, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(g_rand_copied, st));
+    hipLaunchKernelGGL(sample_bytes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const uint8_t*)buf, count, width, (Fe*)d_out);
+    HIPCHK(hipGetLastError());
+    return SC_OK;
+}
+
 int sc_memcpy_dev(void* d_dst, const void* d_src, uint64_t count, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());

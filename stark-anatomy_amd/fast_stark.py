@@ -15,6 +15,7 @@ from univariate import *
 from multivariate import *
 from ntt import *
 from ntt import _View
+import starkcore as _sc
 
 
 def draw_random_bytes(count, width=17):
@@ -24,18 +25,63 @@ def draw_random_bytes(count, width=17):
     return b"".join(os.urandom(width * min(block, count - i)) for i in range(0, count, block))
 
 
+class DeviceTrace:
+    """The execution trace as device-resident COLUMNS: one DeviceVector of `rows` field elements per register -- what the
+    `trace` argument of FastStark.prove (a list of rows of FieldElements, fast_stark.py:76) is to a caller whose trace never
+    was a Python list.  A 2^20-row trace of two registers is two million Python objects and seconds of marshalling as lists
+    (SURVEY.md App. C); as columns it is 32 MiB in HBM."""
+
+    def __init__(self, columns, field):
+        assert len(columns) >= 1 and all(c.n == columns[0].n for c in columns), "columns of one length, one per register"
+        self.columns, self.field = list(columns), field
+
+    @classmethod
+    def from_rows(cls, rows, field):
+        """rows: the reference's list of rows (lists of FieldElement or ints)"""
+        width = len(rows[0])
+        cols = [DeviceVector.from_bytes(b"".join(int(getattr(row[s], "value", row[s])).to_bytes(16, "little") for row in rows)) for s in range(width)]
+        return cls(cols, field)
+
+    @classmethod
+    def from_packed(cls, packed_columns, field):
+        """packed_columns: per register, the column as packed bytes (16 little-endian bytes per element)"""
+        return cls([DeviceVector.from_bytes(c) for c in packed_columns], field)
+
+    def __len__(self):
+        return self.columns[0].n
+
+    def entry(self, cycle, register):
+        """one cell as a FieldElement (boundary conditions are read from the trace: 16 bytes from HBM)"""
+        return FieldElement(int.from_bytes(self.columns[register].to_bytes(cycle, 1), "little"), self.field)
+
+
 def sampled_polynomial(raw, field, width=17):
     """Polynomial([field.sample(raw[17 i : 17 i + 17]) ...]) as a DevicePolynomial: Field.sample on the device (sc_sample_bytes_dev)"""
-    import starkcore as _sc
     count = len(raw) // width
     vec = DeviceVector(max(count, 1))
     _sc._check(_sc.lib().sc_sample_bytes_dev(raw, count, width, vec.ptr, None))
     return DevicePolynomial(vec, field, count)
 
 
+def os_urandom_is_genuine():
+    """is os.urandom the interpreter's own (the operating system's generator), not a seeded stand-in a test has put in its place?
+    Only then may the draws be made anywhere but through os.urandom itself, in any order."""
+    return type(os.urandom).__name__ == "builtin_function_or_method"
+
+
+def random_polynomial(count, field, width=17):
+    """Polynomial([field.sample(os.urandom(17)) for i in range(count)]) (fast_stark.py:116-117) as a DevicePolynomial.  With the
+    operating system's os.urandom the library makes the draws itself -- getrandom(2), several host threads, straight into a
+    pinned buffer (sc_sample_urandom_dev); a patched os.urandom is called draw by draw in the reference's order."""
+    if not os_urandom_is_genuine():
+        return sampled_polynomial(draw_random_bytes(count, width), field, width)
+    vec = DeviceVector(max(count, 1))
+    _sc._check(_sc.lib().sc_sample_urandom_dev(count, width, vec.ptr, None))
+    return DevicePolynomial(vec, field, count)
+
+
 def device_powers(base, count):
     """base^i, i < count, as a DeviceVector (Polynomial.scale of the all-ones vector: no host loop)"""
-    import starkcore as _sc
     ones = DeviceVector.from_bytes((1).to_bytes(16, "little") * count)
     out = DeviceVector(count)
     _sc._check(_sc.lib().sc_scale_dev(ones.ptr, out.ptr, count, _sc.fe_bytes(base.value), None))
@@ -64,16 +110,61 @@ class FastStark:
         self.generator = field.generator()
         self.omega = field.primitive_nth_root(self.fri_domain_length)
         self.omicron = field.primitive_nth_root(self.omicron_domain_length)
-        # omicron^i for i < omicron_domain_length (fast_stark.py:33), by running product instead of one exponentiation per entry
-        self.omicron_domain, power = [], field.one()
-        for _ in range(self.omicron_domain_length):
-            self.omicron_domain.append(power)
-            power = power * self.omicron
+        self._omicron_domain = None
+        self._trace_domains = {}          # rows -> DeviceDomain of {omicron^i, i < rows} (progression tables, built once)
+        self._lifted = {}                 # id(host Polynomial) -> (the Polynomial, its DevicePolynomial): lifted once, not per proof
 
         self.fri = Fri(self.generator, self.omega, self.fri_domain_length, expansion_factor, num_colinearity_checks)
 
+    @property
+    def omicron_domain(self):
+        """omicron^i for i < omicron_domain_length (fast_stark.py:33), by running product instead of one exponentiation per
+        entry; built when first read (a 2^22-entry list of objects is seconds of host time the device-resident prover never needs)"""
+        if self._omicron_domain is None:
+            domain, power = [], self.field.one()
+            for _ in range(self.omicron_domain_length):
+                domain.append(power)
+                power = power * self.omicron
+            self._omicron_domain = domain
+        return self._omicron_domain
+
+    def _trace_domain(self, rows):
+        """{omicron^i, i < rows} as a DeviceDomain: a geometric progression, so interpolation through it is a handful of
+        convolutions (csrc/geoseq.cuh) instead of a subproduct tree"""
+        domain = self._trace_domains.get(rows)
+        if domain is None:
+            if len(self._trace_domains) >= 4:
+                self._trace_domains.clear()
+            domain = self._trace_domains[rows] = DeviceDomain.geometric(self.field.one(), self.omicron, rows)
+        return domain
+
+    def _lift(self, polynomial):
+        """a host Polynomial (or an already device-resident one) as a DevicePolynomial; the same object is lifted once"""
+        if isinstance(polynomial, DevicePolynomial):
+            return polynomial
+        hit = self._lifted.get(id(polynomial))
+        if hit is not None and hit[0] is polynomial:
+            return hit[1]
+        if len(self._lifted) >= 16:
+            self._lifted.clear()
+        dev = DevicePolynomial.from_polynomial(polynomial, self.field)
+        self._lifted[id(polynomial)] = (polynomial, dev)
+        return dev
+
     # -- preprocessing (fast_stark.py:36-40) ------------------------------------------------------
-    def preprocess(self):
+    def preprocess(self, device_resident=False):
+        """device_resident=True: the transition zerofier comes back as a DevicePolynomial (prove() takes either form) and no
+        host list of the omicron domain is ever built -- the zerofier of {omicron^i, i < T - 1} has a closed form on the device"""
+        if device_resident:
+            assert(self.field.p == Field.P_MAIN), "the device-resident prover works in the main field"
+            count = self.original_trace_length - 1
+            if count >= 2:
+                zerofier_domain = DeviceDomain.geometric(self.field.one(), self.omicron, count)
+                transition_zerofier = DevicePolynomial.from_codeword(fast_zerofier_device(zerofier_domain))
+            else:
+                transition_zerofier = DevicePolynomial.from_polynomial(fast_zerofier(self.omicron_domain[:count], self.omicron, self.omicron_domain_length), self.field)
+            transition_zerofier_codeword = transition_zerofier.coset_evaluate(self.generator, self.omega, self.fri_domain_length)
+            return transition_zerofier, transition_zerofier_codeword, Merkle.commit(transition_zerofier_codeword)
         transition_zerofier = fast_zerofier(self.omicron_domain[:(self.original_trace_length - 1)], self.omicron, len(self.omicron_domain))
         if self.randomized_trace_length >= FastStark.DEVICE_MIN and self.field.p == Field.P_MAIN:
             # long traces: the codeword is committed here and opened in prove() where it lies, in HBM (a DeviceCodeword is list-like)
@@ -141,25 +232,31 @@ class FastStark:
 
         # randomizer rows appended to the trace (draw order: row by row, register by register); one concatenation instead of one
         # per row -- the caller's list is not touched either way
-        trace = trace + [[field.sample(os.urandom(17)) for s in registers] for _ in range(self.num_randomizers)]
-
-        on_device = len(trace) >= FastStark.DEVICE_MIN and field.p == Field.P_MAIN
+        if isinstance(trace, DeviceTrace):
+            assert(field.p == Field.P_MAIN), "a device-resident trace lives in the main field"
+            columns = self._randomized_columns(trace, draw_random_bytes(self.num_randomizers * self.num_registers))
+            trace_rows, on_device = len(trace) + self.num_randomizers, True
+        else:
+            trace = trace + [[field.sample(os.urandom(17)) for s in registers] for _ in range(self.num_randomizers)]
+            trace_rows = len(trace)
+            on_device = trace_rows >= FastStark.DEVICE_MIN and field.p == Field.P_MAIN
+            if on_device:
+                columns = [DeviceCodeword.from_list([row[s] for row in trace], field) for s in registers]
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)
         if on_device:
             # Polynomials live in HBM from here on (DevicePolynomial): interpolation, boundary quotients (exact coset division,
             # exactness decided on the device), the AIR substitution in the value domain, the transition quotients, the LDEs and
             # the combination.  The host keeps what byte parity ties to it: os.urandom draws, Fiat-Shamir, the proof stream.
-            trace_domain = DeviceDomain(device_powers(self.omicron, len(trace)), field)
-            trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, DeviceCodeword.from_list([row[s] for row in trace], field)))
-                                 for s in registers]
+            trace_domain = self._trace_domain(trace_rows)
+            trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, column)) for column in columns]
             zerofiers_dev = [DevicePolynomial.from_polynomial(z, field) for z in zerofiers]
             boundary_quotients = [coset_divide_device(trace_polynomials[s].minus(interpolants[s]), zerofiers_dev[s], self.generator, self.omicron,
                                                       self.omicron_domain_length, exact=True) for s in registers]
             lde = lambda poly: poly.coset_evaluate(self.generator, self.omega, self.fri_domain_length)
         else:
             # trace polynomials through {omicron^i}
-            trace_domain = [self.omicron ^ i for i in range(len(trace))]
+            trace_domain = [self.omicron ^ i for i in range(trace_rows)]
             trace_polynomials = [fast_interpolate(trace_domain, [row[s] for row in trace], self.omicron, self.omicron_domain_length) for s in registers]
             # boundary quotients (exact schoolbook division by the small boundary zerofiers)
             boundary_quotients = [(trace_polynomials[s] - interpolants[s]) / zerofiers[s] for s in registers]
@@ -176,7 +273,7 @@ class FastStark:
         point = [DevicePolynomial.from_polynomial(x, field) if on_device else x] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
         transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
         if on_device:
-            tz_dev = DevicePolynomial.from_polynomial(transition_zerofier, field)
+            tz_dev = self._lift(transition_zerofier)
             transition_quotients = [coset_divide_device(tp, tz_dev, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
         else:
             transition_quotients = [fast_coset_divide(tp, transition_zerofier, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
@@ -185,7 +282,7 @@ class FastStark:
         max_degree = self.max_degree(transition_constraints)
         if on_device:
             # the same draws (max_degree + 1 times os.urandom(17), fast_stark.py:117), sampled into HBM without a Python object each
-            randomizer_polynomial = sampled_polynomial(draw_random_bytes(max_degree + 1), field)
+            randomizer_polynomial = random_polynomial(max_degree + 1, field)
         else:
             randomizer_polynomial = Polynomial([field.sample(os.urandom(17)) for i in range(max_degree + 1)])
         randomizer_codeword = lde(randomizer_polynomial)
@@ -197,7 +294,7 @@ class FastStark:
         assert([tq.degree() for tq in transition_quotients] == tq_bounds), "transition quotient degrees do not match with expectation"
 
         # nonlinear combination: each quotient and its degree-shifted copy
-        bq_bounds = self.boundary_quotient_degree_bounds(len(trace), boundary)
+        bq_bounds = self.boundary_quotient_degree_bounds(trace_rows, boundary)
         shifted = [(randomizer_polynomial, None)]
         for i, tq in enumerate(transition_quotients):
             shifted.append((tq, max_degree - tq_bounds[i]))
@@ -230,6 +327,23 @@ class FastStark:
                 self._open_all(codeword, quadrupled_indices, proof_stream)
 
         return proof_stream.serialize()
+
+    def _randomized_columns(self, trace, raw):
+        """the columns of a DeviceTrace with the randomizer rows appended (fast_stark.py:79-81): `raw` holds the draws of
+        os.urandom(17) in the reference's order -- row by row, register by register; 4 * num_colinearity_checks rows, sampled on
+        the host and written behind each column's copy"""
+        assert(len(trace.columns) == self.num_registers), "one column per register"
+        width, rows, extra = self.num_registers, len(trace), self.num_randomizers
+        sample = self.field.sample
+        columns = []
+        for s in range(width):
+            tail = b"".join(sample(raw[17 * (r * width + s):17 * (r * width + s) + 17]).value.to_bytes(16, "little") for r in range(extra))
+            column = DeviceVector(rows + extra)
+            _sc._check(_sc.lib().sc_memcpy_dev(column.ptr, trace.columns[s].ptr, rows, None))
+            if extra:
+                _sc._check(_sc.lib().sc_vec_upload(column._h, rows, tail, extra))
+            columns.append(DeviceCodeword(column, self.field))
+        return columns
 
     def _combine_on_device(self, shifted, weights, max_degree):
         """sum_i weights[i] * terms[i] (fast_stark.py:130-145) as axpys over coefficient vectors in HBM, then the LDE straight from

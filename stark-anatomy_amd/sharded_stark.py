@@ -23,8 +23,8 @@ import torch.distributed as dist
 
 import fast_stark as _fs
 from fast_stark import *                      # noqa: F401,F403  (FastStark and the reference's star-imported names)
-from ntt import DevicePolynomial, DeviceDomain, _shrink_order, coset_divide_device, fast_interpolate_device
-from sharded import ShardedNtt, ShardedFri
+from ntt import DevicePolynomial, DeviceDomain, _shrink_order, coset_divide_device, fast_interpolate_device, fast_zerofier_device
+from sharded import ShardedNtt, ShardedFri, _current_raw_stream
 import starkcore as _sc
 
 
@@ -45,13 +45,20 @@ class HipReplicatedSteps:
         return None
 
     def join(self):
-        """the replicated steps run on the library's stream, the sharded ones on torch's: meet before switching sides"""
-        _sc.synchronize()
-        torch.cuda.current_stream(self.device).synchronize()
+        """The replicated steps run on the library's stream, the sharded ones on torch's current stream.  ShardedFastStark makes
+        them the SAME stream (torch.cuda.ExternalStream over sc_stream()), and then there is nothing to do here; under any other
+        current stream the two are ordered with each other on the device (sc_stream_join: two events).  The host never waits."""
+        raw = _current_raw_stream(self.device)
+        if raw != _sc.library_stream():
+            if raw == 0:                                  # torch's null stream cannot be waited on from another stream's side
+                torch.cuda.current_stream(self.device).synchronize()
+                _sc.synchronize()
+            else:
+                _sc.stream_join(raw)
 
     # -- polynomials in, polynomials out
     def lift(self, polynomial):
-        return DevicePolynomial.from_polynomial(polynomial, self.field)
+        return self.stark._lift(polynomial)                # the same host Polynomial is packed and uploaded once, not per proof
 
     def zero(self):
         return DevicePolynomial(_sc.DeviceVector(1), self.field, 0)
@@ -62,10 +69,25 @@ class HipReplicatedSteps:
     def zerofier(self, domain, root, order):
         return fast_zerofier(domain, root, order)
 
-    def trace_polynomials(self, omicron, trace, registers):
-        """fast_stark.py:84-87: the interpolants of the trace columns through {omicron^i}, over ONE subproduct tree"""
-        domain = DeviceDomain(_fs.device_powers(omicron, len(trace)), self.field)
-        return [DevicePolynomial.from_codeword(fast_interpolate_device(domain, DeviceCodeword.from_list([row[s] for row in trace], self.field))) for s in registers]
+    def zerofier_device(self, count):
+        """fast_zerofier of {omicron^i, i < count} (fast_stark.py:37) as a DevicePolynomial: closed form on a progression"""
+        domain = DeviceDomain.geometric(self.field.one(), self.stark.omicron, count)
+        return DevicePolynomial.from_codeword(fast_zerofier_device(domain))
+
+    def trace_polynomials(self, trace, rows, registers, raw):
+        """fast_stark.py:79-87: the trace with its randomizer rows (`raw`: the os.urandom draws, in the reference's order)
+        interpolated column by column through {omicron^i, i < rows} -- a geometric progression: a handful of convolutions per
+        column over tables built once (csrc/geoseq.cuh).  trace: the reference's list of rows, or a fast_stark.DeviceTrace."""
+        stark, field = self.stark, self.field
+        if isinstance(trace, _fs.DeviceTrace):
+            columns = stark._randomized_columns(trace, raw)
+        else:
+            width = stark.num_registers
+            draws = [field.sample(raw[17 * i:17 * i + 17]) for i in range(len(raw) // 17)]
+            full = trace + [draws[r * width:(r + 1) * width] for r in range(stark.num_randomizers)]
+            columns = [DeviceCodeword.from_list([row[s] for row in full], field) for s in registers]
+        domain = stark._trace_domain(rows)
+        return [DevicePolynomial.from_codeword(fast_interpolate_device(domain, column)) for column in columns]
 
     def coset_divide(self, lhs, rhs, exact):
         s = self.stark
@@ -73,6 +95,9 @@ class HipReplicatedSteps:
 
     def sampled_polynomial(self, raw):
         return _fs.sampled_polynomial(raw, self.field)
+
+    def random_polynomial(self, count):
+        return _fs.random_polynomial(count, self.field)
 
     def combination(self, shifted, weights, max_degree):
         return self.stark._combination_on_device(shifted, weights, max_degree)
@@ -85,16 +110,17 @@ class HipReplicatedSteps:
         if length:
             self.join()
             _sc._check(_sc.lib().sc_memcpy_dev(t.data_ptr(), poly.vec.ptr, length, None))
-            _sc.synchronize()
+            self.join()
         return t[:length]
 
     def polynomial(self, tensor, length):
         """the first `length` rows of a [..][2] tensor as a polynomial"""
         vec = _sc.DeviceVector(max(length, 1))
         if length:
+            tensor = tensor.contiguous()
             self.join()
-            _sc._check(_sc.lib().sc_memcpy_dev(vec.ptr, tensor.contiguous().data_ptr(), length, None))
-            _sc.synchronize()
+            _sc._check(_sc.lib().sc_memcpy_dev(vec.ptr, tensor.data_ptr(), length, None))
+            self.join()                                   # `tensor` may go back to torch's allocator once this returns
         return DevicePolynomial(vec, self.field, length)
 
 
@@ -107,10 +133,35 @@ class ShardedFastStark(FastStark):
         super().__init__(field, expansion_factor, num_colinearity_checks, security_level, num_registers, num_cycles, transition_constraints_degree)
         assert field.p == Field.P_MAIN, "the sharded prover works in the main field"
         self.rank, self.world, self.device, self.group = rank, world, device, group
-        self.steps = HipReplicatedSteps(self) if replicated_steps is None else replicated_steps(self)
-        self._ntts = {}
-        self.ntt_fri = self._ntt(self.fri_domain_length, self.omega.value)
-        self.sfri = ShardedFri(self.fri, self.ntt_fri.n1, rank, world, device, engine=self.steps.fri_engine(), group=group)
+        # ONE stream for everything: torch's tensor ops and collectives are put on the library's own stream, so the replicated
+        # steps (library stream) and the sharded ones (torch's current stream) are ordered by construction and nothing waits
+        self._stream = None
+        if replicated_steps is None and getattr(device, "type", None) == "cuda":
+            self._stream = torch.cuda.ExternalStream(_sc.library_stream(), device=device)
+        with self._on_stream():
+            self.steps = HipReplicatedSteps(self) if replicated_steps is None else replicated_steps(self)
+            self._ntts = {}
+            self.ntt_fri = self._ntt(self.fri_domain_length, self.omega.value)
+            self.sfri = ShardedFri(self.fri, self.ntt_fri.n1, rank, world, device, engine=self.steps.fri_engine(), group=group)
+
+    # a list here turns on the per-phase breakdown: after each phase of prove() the device is waited for and
+    # (phase, seconds since the previous mark) is appended -- measurement only (tools/sharded_stark_profile.py, bench.py)
+    phase_log = None
+
+    def _mark(self, phase):
+        if self.phase_log is None:
+            return
+        import time
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        now = time.perf_counter()
+        if phase is not None:
+            self.phase_log.append((phase, now - self._phase_t0))
+        self._phase_t0 = now
+
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
 
     # -- plumbing ---------------------------------------------------------------------------------
     def _ntt(self, order, root):
@@ -141,6 +192,24 @@ class ShardedFastStark(FastStark):
             dist.broadcast(t, 0, group=self.group)
             raw = bytes(t.cpu().numpy())
         return raw
+
+    def _shared_random_polynomial(self, count):
+        """Polynomial([field.sample(os.urandom(17)) ...]) of `count` coefficients (fast_stark.py:116-117), the same on every rank.
+        A patched (seeded) os.urandom: rank 0's draws in the reference's order, broadcast as bytes.  The operating system's:
+        rank 0 has the library draw and sample them on the device (fast_stark.random_polynomial) and the ELEMENTS are broadcast."""
+        steps = self.steps
+        if not (_fs.os_urandom_is_genuine() and hasattr(steps, "random_polynomial")):
+            return steps.sampled_polynomial(self._shared_random_bytes(count))
+        if self.world == 1:
+            return steps.random_polynomial(count)
+        on_dev = dist.get_backend(self.group) == "nccl"
+        if self.rank == 0:
+            t = steps.coefficients(steps.random_polynomial(count), count)
+            t = t if on_dev else t.cpu()
+        else:
+            t = torch.empty((count, 2), dtype=torch.int64, device=self.device if on_dev else "cpu")
+        dist.broadcast(t, 0, group=self.group)
+        return steps.polynomial(t.to(self.device), count)
 
     # -- sharded building blocks ---------------------------------------------------------------------
     def _lde_commit(self, poly):
@@ -176,64 +245,84 @@ class ShardedFastStark(FastStark):
         return self._polynomial(full, n_out)
 
     # -- preprocessing (fast_stark.py:36-40) -----------------------------------------------------------
-    def preprocess(self):
-        """-> (transition_zerofier, its committed codeword as a sharded layer record, the root)"""
-        transition_zerofier = self.steps.zerofier(self.omicron_domain[:(self.original_trace_length - 1)], self.omicron, len(self.omicron_domain))
-        layer = self._lde_commit(self.steps.lift(transition_zerofier))
-        return transition_zerofier, layer, layer["root"]
+    def preprocess(self, device_resident=False):
+        """-> (transition_zerofier, its committed codeword as a sharded layer record, the root).  device_resident=True: the
+        zerofier of {omicron^i, i < T - 1} is made on the device from its closed form (no host list of the domain)"""
+        with self._on_stream():
+            if device_resident and self.original_trace_length - 1 >= 2 and hasattr(self.steps, "zerofier_device"):
+                transition_zerofier = self.steps.zerofier_device(self.original_trace_length - 1)
+            else:
+                transition_zerofier = self.steps.zerofier(self.omicron_domain[:(self.original_trace_length - 1)], self.omicron, len(self.omicron_domain))
+            layer = self._lde_commit(self.steps.lift(transition_zerofier))
+            return transition_zerofier, layer, layer["root"]
 
     # -- prover (fast_stark.py:76-178) -------------------------------------------------------------------
     def prove(self, trace, transition_constraints, boundary, transition_zerofier, transition_zerofier_layer, proof_stream=None):
+        """trace: the reference's list of rows, or a fast_stark.DeviceTrace (columns resident in HBM)"""
+        with self._on_stream():
+            return self._prove(trace, transition_constraints, boundary, transition_zerofier, transition_zerofier_layer, proof_stream)
+
+    def _prove(self, trace, transition_constraints, boundary, transition_zerofier, transition_zerofier_layer, proof_stream):
         if proof_stream == None:
             proof_stream = ProofStream()
         field, registers = self.field, range(self.num_registers)
+        self._mark(None)
 
         # randomizer rows appended to the trace (draw order: row by row, register by register)
         raw = self._shared_random_bytes(self.num_randomizers * self.num_registers)
-        draws = iter([raw[17 * i:17 * i + 17] for i in range(len(raw) // 17)])
-        trace = trace + [[field.sample(next(draws)) for s in registers] for _ in range(self.num_randomizers)]
+        trace_rows = len(trace) + self.num_randomizers
 
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)
-        # replicated: the trace polynomials through {omicron^i} over the subproduct tree (fast_stark.py:84-87)
+        # replicated: the trace polynomials through {omicron^i} (fast_stark.py:84-87)
         steps = self.steps
-        trace_polynomials = steps.trace_polynomials(self.omicron, trace, registers)
+        trace_polynomials = steps.trace_polynomials(trace, trace_rows, registers, raw)
+        self._mark("trace interpolation (replicated)")
         # sharded: boundary quotients, their LDEs and commitments (fast_stark.py:89-105)
         zerofiers_dev = [steps.lift(z) for z in zerofiers]
         boundary_quotients = [self._coset_divide(steps.subtract(trace_polynomials[s], interpolants[s]), zerofiers_dev[s], exact=True) for s in registers]
+        self._mark("boundary quotients (sharded division)")
         boundary_layers = []
         for s in registers:
             boundary_layers.append(self._lde_commit(boundary_quotients[s]))
             proof_stream.push(boundary_layers[s]["root"])
+        self._mark("boundary quotient LDEs + commitments (sharded)")
 
         # replicated: the AIR substituted in (X, trace(X), trace(omicron X)) in the value domain; sharded: the quotients
         x = Polynomial([field.zero(), field.one()])
         point = [steps.lift(x)] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
         transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
+        self._mark("AIR substitution in the value domain (replicated)")
         tz_dev = steps.lift(transition_zerofier)
         transition_quotients = [self._coset_divide(tp, tz_dev) for tp in transition_polynomials]
+        self._mark("transition quotients (sharded division)")
 
         # randomizer polynomial (rank 0's draws), its sharded LDE and commitment
         max_degree = self.max_degree(transition_constraints)
-        randomizer_polynomial = steps.sampled_polynomial(self._shared_random_bytes(max_degree + 1))
+        randomizer_polynomial = self._shared_random_polynomial(max_degree + 1)
+        self._mark("randomizer polynomial: os.urandom / getrandom draws and Field.sample")
         randomizer_layer = self._lde_commit(randomizer_polynomial)
         proof_stream.push(randomizer_layer["root"])
+        self._mark("randomizer polynomial: LDE, commitment (sharded)")
 
         weights = self.sample_weights(1 + 2 * len(transition_quotients) + 2 * len(boundary_quotients), proof_stream.prover_fiat_shamir())
         tq_bounds = self.transition_quotient_degree_bounds(transition_constraints)
         assert([tq.degree() for tq in transition_quotients] == tq_bounds), "transition quotient degrees do not match with expectation"
 
         # nonlinear combination (replicated axpys over coefficient vectors), its sharded LDE, the sharded low-degree test
-        bq_bounds = self.boundary_quotient_degree_bounds(len(trace), boundary)
+        bq_bounds = self.boundary_quotient_degree_bounds(trace_rows, boundary)
         shifted = [(randomizer_polynomial, None)]
         for i, tq in enumerate(transition_quotients):
             shifted.append((tq, max_degree - tq_bounds[i]))
         for i in registers:
             shifted.append((boundary_quotients[i], max_degree - bq_bounds[i]))
         combination = steps.combination(shifted, weights, max_degree)
+        self._mark("weights, degree checks, nonlinear combination (replicated)")
         slab = torch.empty(self.ntt_fri.local_shape(False), dtype=torch.int64, device=self.device)
         self.ntt_fri.coset_evaluate(self._tensor(combination), self.generator.value, slab)
+        self._mark("LDE of the combination (sharded)")
         indices = self.sfri.prove(slab, proof_stream)
+        self._mark("FRI: commit + query phases (sharded)")
 
         # open the queried positions (and their expansion_factor / half-domain companions) on every committed codeword
         N = self.fri.domain_length
@@ -249,4 +338,7 @@ class ShardedFastStark(FastStark):
             for entry, path in zip(entries, paths):
                 proof_stream.push(entry)
                 proof_stream.push(path)
-        return proof_stream.serialize()
+        self._mark("openings of the committed codewords (sharded)")
+        proof = proof_stream.serialize()
+        self._mark("proof serialization (host pickle)")
+        return proof

@@ -29,6 +29,8 @@ SIGNATURES = {
     "sc_shutdown": (_int, []),
     "sc_last_error": (ctypes.c_char_p, []),
     "sc_synchronize": (_int, []),
+    "sc_stream": (_int, [ctypes.POINTER(_vp)]),
+    "sc_stream_join": (_int, [_vp]),
     "sc_set_tuning": (_int, [ctypes.c_char_p, _int]),
     "sc_ntt_num_passes": (_int, [_u64]),
     "sc_debug_trace": (_int, [_vp]),
@@ -43,6 +45,7 @@ SIGNATURES = {
     "sc_vec_gather": (_int, [_vp, _vp, _u64, _vp]),
     "sc_memcpy_dev": (_int, [_vp, _vp, _u64, _vp]),
     "sc_sample_bytes_dev": (_int, [_vp, _u64, ctypes.c_uint32, _vp, _vp]),
+    "sc_sample_urandom_dev": (_int, [_u64, ctypes.c_uint32, _vp, _vp]),
     "sc_ntt": (_int, [_vp, _vp, _u64, _vp, _int]),
     "sc_ntt_dev": (_int, [_vp, _vp, _u64, _vp, _int, _vp]),
     "sc_ntt_batch_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp]),
@@ -193,6 +196,19 @@ def set_tuning(key, value):
 
 def synchronize():
     _check(lib().sc_synchronize())
+
+
+def library_stream():
+    """the library's own HIP stream as an integer handle (for torch.cuda.ExternalStream: work put on it needs no ordering with
+    the library's)"""
+    h = _vp()
+    _check(lib().sc_stream(ctypes.byref(h)))
+    return int(h.value or 0)
+
+
+def stream_join(other):
+    """order the library stream and the raw stream handle `other` with each other on the device; the host does not wait"""
+    _check(lib().sc_stream_join(_vp(int(other))))
 
 
 def fe_bytes(v):

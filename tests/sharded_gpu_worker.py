@@ -138,6 +138,11 @@ def stark_check(rank, world, dev):
         tz2, layer, root = many.preprocess()
         got = many.prove(trace, air, boundary, tz2, layer)
         good = root == tzr and got == want and one.verify(got, air, boundary, tzr) is True
+        # the same proof from a device-resident trace (columns in HBM) and a zerofier made on the device from its closed form
+        seeded()
+        columns = fast_stark.DeviceTrace.from_rows(trace, field)
+        tz3, layer3, root3 = many.preprocess(device_resident=True)
+        good = good and root3 == tzr and many.prove(columns, air, boundary, tz3, layer3) == want
         if not good:
             print("rank", rank, "STARK MISMATCH k", k, root == tzr, len(got), len(want), flush=True)
         ok &= good

@@ -415,9 +415,13 @@ def stark_main():
         def zerofier(self, domain, root, order):
             return poly(po.fast_zerofier([d.value for d in domain], root.value, order))
 
-        def trace_polynomials(self, omicron, trace, registers):
+        def trace_polynomials(self, trace, rows, registers, raw):
             s = self.stark
-            domain = [pow(omicron.value, i, P) for i in range(len(trace))]
+            width = s.num_registers
+            draws = [field.sample(raw[17 * i:17 * i + 17]) for i in range(len(raw) // 17)]
+            trace = trace + [draws[r * width:(r + 1) * width] for r in range(s.num_randomizers)]
+            assert len(trace) == rows
+            domain = [pow(s.omicron.value, i, P) for i in range(rows)]
             return [poly(po.fast_interpolate(domain, [row[r].value for row in trace], s.omicron.value, s.omicron_domain_length)) for r in registers]
 
         def coset_divide(self, lhs, rhs, exact):

@@ -151,3 +151,59 @@ def test_verifier_rejects_tampered_proofs():
     assert verdict(changed) == False, "changed FRI authentication path accepted"
     changed = list(objects); changed[first_fri] = flipped(objects[first_fri])
     assert verdict(changed) == False, "changed FRI root accepted"
+
+
+def test_device_resident_trace_reproduces_the_reference_proofs():
+    """fast_stark.DeviceTrace (the trace as columns in HBM) and preprocess(device_resident=True) (the transition zerofier from
+    its closed form on the progression {omicron^i}) against the REFERENCE's golden proofs: byte-identical."""
+    from fast_stark import DeviceTrace
+    g = load_golden("fast_stark.json")
+    field = Field.main()
+    rp = RescuePrime()
+    for rec in g["runs"]:
+        input_element = FieldElement(int(rec["input"]), field)
+        output_element = rp.hash(input_element)
+        stark = FastStark(field, rec["expansion_factor"], rec["num_colinearity_checks"], rec["security_level"], rp.m, rp.N + 1)
+        for resident in (False, True):
+            _seed_urandom(rec["urandom_seed"])
+            tz, tz_codeword, tz_root = stark.preprocess(device_resident=resident)
+            assert tz_root.hex() == rec["zerofier_root"]
+            rows = rp.trace(input_element)
+            trace = DeviceTrace.from_rows(rows, field)
+            assert len(trace) == len(rows) and trace.entry(3, 1) == rows[3][1]
+            air, boundary = rp.transition_constraints(stark.omicron), rp.boundary_constraints(output_element)
+            proof = stark.prove(trace, air, boundary, tz, tz_codeword)
+            assert hashlib.sha256(proof).hexdigest() == rec["proof_sha256"], resident
+            assert stark.verify(proof, air, boundary, tz_root) == True
+
+
+def test_library_draws_of_the_randomizer_polynomial(monkeypatch):
+    """sc_sample_urandom_dev: the library's own getrandom draws (what os.urandom is), threaded, sampled on the device.  The bytes
+    are the operating system's, so only properties can be checked: canonical residues, no repeats, a fresh draw every call; and a
+    proof made with them verifies.  Field.sample itself is pinned through sc_sample_bytes_dev (seeded goldens above)."""
+    import os as real_os
+    import importlib
+    import starkcore as sc
+    from starkcore import DeviceVector
+    count = (1 << 16) + 3                         # > 1 MiB of draws: several threads
+    a, b = DeviceVector(count), DeviceVector(count)
+    sc._check(sc.lib().sc_sample_urandom_dev(count, 17, a.ptr, None))
+    sc._check(sc.lib().sc_sample_urandom_dev(count, 17, b.ptr, None))
+    va, vb = sc.unpack(a.to_bytes()), sc.unpack(b.to_bytes())
+    p = Field.main().p
+    assert all(0 <= v < p for v in va) and len(set(va)) == count and len(set(va) & set(vb)) == 0
+    assert max(va) > p // 2 and min(va) < p // 2 and sum(v >> 120 != 0 for v in va) > count // 4
+    # a whole proof with the operating system's randomness: os.urandom as the interpreter provides it
+    genuine = importlib.import_module("posix").urandom
+    monkeypatch.setattr(real_os, "urandom", genuine)
+    assert fast_stark.os_urandom_is_genuine()
+    field = Field.main()
+    rp = RescuePrime()
+    input_element = field.sample(b"library draws")
+    output_element = rp.hash(input_element)
+    stark = FastStark(field, 4, 2, 2, rp.m, rp.N + 1)
+    tz, tz_codeword, tz_root = stark.preprocess(device_resident=True)
+    air, boundary = rp.transition_constraints(stark.omicron), rp.boundary_constraints(output_element)
+    proofs = [stark.prove(fast_stark.DeviceTrace.from_rows(rp.trace(input_element), field), air, boundary, tz, tz_codeword) for _ in range(2)]
+    assert proofs[0] != proofs[1]                 # zero knowledge needs fresh randomizers every time
+    assert all(stark.verify(proof, air, boundary, tz_root) == True for proof in proofs)
