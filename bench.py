@@ -847,9 +847,55 @@ def extras(sc, lib, stream=None):
         res["polytree_2p20_points"] = {"build_ms": tb * 1e3, "evaluate_ms": te * 1e3, "interpolate_ms": ti * 1e3,
                                        "round_trip_ok": back.to_bytes() == f.to_bytes()}
         tree.free()
+        # the same three functions on a geometric progression (the trace domain {omicron^i} of fast_stark.py:84-90: 2^20 - 160
+        # points, omicron of order 2^22): convolutions instead of a tree (csrc/geoseq.cuh)
+        kg = (1 << 20) - 160
+        omicron = field.primitive_nth_root(1 << 22).value
+        tg, dom = timed(lambda: sc.GeoDomain(1, omicron, kg), 2)
+        vals = sc.DeviceVector.from_bytes(synth.synth_packed(13, kg).tobytes())
+        ti, poly = timed(lambda: dom.interpolate(vals), 5)
+        te, back = timed(lambda: dom.evaluate(poly), 5)
+        res["progression_2p20_points"] = {"tables_ms": tg * 1e3, "evaluate_ms": te * 1e3, "interpolate_ms": ti * 1e3, "points": kg,
+                                          "round_trip_ok": back.to_bytes() == vals.to_bytes()}
+        dom.free()
     except Exception as e:
         res["merkle_polytree"] = {"error": repr(e)}
+    # configs[4] as a real prover on ONE GPU: fast_stark.FastStark.prove (reference code/fast_stark.py:76-178) on the synthetic
+    # 2-register AIR, 2^20-row randomized trace resident in HBM, FRI domain 2^24; verified outside the timed region
+    try:
+        res["stark_prove_2p24_1gpu"] = plain_stark_prove_measure(24, 3)
+    except Exception as e:
+        res["stark_prove_2p24_1gpu"] = {"error": repr(e)}
     return res
+
+
+def plain_stark_prove_measure(log_fri, steps):
+    """fast_stark.FastStark.prove on one GPU (no process group): ms per proof from a device-resident trace to the serialized proof"""
+    from fast_stark import DeviceTrace, FastStark
+    s = 40
+    field, T, packed, air, boundary = synthetic_stark_instance(log_fri, s)
+    stark = FastStark(field, 4, s, 2 * s, 2, T)
+    trace = DeviceTrace.from_packed(packed, field)
+    sc = sys.modules["starkcore"]
+    t0 = time.perf_counter()
+    tz, tz_codeword, root = stark.preprocess(device_resident=True)
+    sc.synchronize()
+    preprocess_s = time.perf_counter() - t0
+    stark.prove(trace, air, boundary, tz, tz_codeword)
+    runs, proof = [], None
+    for _ in range(steps):
+        sc.synchronize()
+        t0 = time.perf_counter()
+        proof = stark.prove(trace, air, boundary, tz, tz_codeword)
+        sc.synchronize()
+        runs.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    verifies = bool(stark.verify(proof, air, boundary, root))
+    return {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_1gpu" % (log_fri - 4, log_fri), "ms_per_proof": 1e3 * min(runs),
+            "runs_ms": [round(1e3 * r, 3) for r in runs], "registers": 2, "colinearity_checks": s, "expansion_factor": 4,
+            "trace": "device-resident columns (fast_stark.DeviceTrace)", "proof_bytes": len(proof), "verify_accepts": verifies,
+            "verify_s": time.perf_counter() - t0, "preprocess_s": preprocess_s,
+            "randomness": "the operating system's (getrandom, drawn by the library)" if sys.modules["fast_stark"].os_urandom_is_genuine() else "patched os.urandom"}
 
 
 def stark_census(sc, lib, field, log_fri):

@@ -686,3 +686,18 @@ def test_sample_bytes_on_device(sc):
         sc._check(lib.sc_sample_bytes_dev(b"".join(rows), len(rows), width, out.ptr, None))
         assert synth.unpack_ints(out.to_bytes()) == [field.sample(r).value for r in rows], width
     assert lib.sc_sample_bytes_dev(b"x" * 33, 1, 33, sc.DeviceVector(1).ptr, None) == -6
+
+
+def test_vec_degree_looks_at_the_top_first_and_then_at_the_rest(sc):
+    """sc_vec_degree_dev (Polynomial.degree, code/univariate.py:7-17): the top 2^16 entries first, the rest only if those are zero"""
+    lib = sc.lib()
+    n = (1 << 17) + 77
+    deg = ctypes.c_int64(0)
+    for want in (-1, 0, 5, 63, 64, n - (1 << 16) - 1, n - (1 << 16), n - (1 << 16) + 1, n - 2, n - 1):
+        v = sc.DeviceVector.zeros(n)
+        if want >= 0:
+            sc._check(lib.sc_vec_upload(v._h, want, (12345).to_bytes(16, "little"), 1))
+            if want >= 3:
+                sc._check(lib.sc_vec_upload(v._h, want // 2, (1).to_bytes(16, "little"), 1))     # a lower non-zero entry must not win
+        sc._check(lib.sc_vec_degree_dev(v.ptr, n, ctypes.byref(deg), None))
+        assert deg.value == want

@@ -86,3 +86,43 @@ def test_stark_census_2p24_two_paths_and_oracle(sc):
     coeffs = synth.synth_packed(60, No // 2).tobytes()
     lde = C.coset_evaluate(coeffs, No // 2, po.GENERATOR, po.primitive_nth_root(Nf), Nf)
     assert C.merkle_commit(lde, Nf).hex()[:16] == info["roots"][0]
+
+
+@pytest.mark.parametrize("log_fri", [22, 24])
+def test_stark_prover_full_size_two_provers_one_proof(sc, log_fri):
+    """BASELINE configs[4] as a real prover at its stated size (reference code/fast_stark.py:76-178): the synthetic 2-register AIR
+    with a 2^(log_fri - 4)-row randomized trace resident in HBM, FRI domain 2^log_fri.  The single-GPU prover
+    (fast_stark.FastStark, plain transforms) and the sharded prover at world 1 (sharded_stark.ShardedFastStark: four-step slabs,
+    slab-local FRI) must produce the SAME proof bytes from the same seeded os.urandom stream, and FastStark.verify -- host
+    arithmetic only: hashlib, Python ints -- accepts it and rejects it for a false boundary claim."""
+    import random
+    import torch
+    import bench
+    import fast_stark
+    from algebra import FieldElement
+    from fast_stark import DeviceTrace, FastStark
+    from sharded_stark import ShardedFastStark
+    s = 40
+    field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+    trace = DeviceTrace.from_packed(packed, field)
+    genuine = fast_stark.os.urandom
+
+    def seeded():
+        rng = random.Random(4242 + log_fri)
+        fast_stark.os.urandom = rng.randbytes
+    try:
+        seeded()
+        one = FastStark(field, 4, s, 2 * s, 2, T)
+        tz, tz_codeword, root = one.preprocess(device_resident=True)
+        want = one.prove(trace, air, boundary, tz, tz_codeword)
+        seeded()
+        many = ShardedFastStark(field, 4, s, 2 * s, 2, T, 0, 1, torch.device("cuda", 0))
+        tz2, layer, root2 = many.preprocess(device_resident=True)
+        got = many.prove(trace, air, boundary, tz2, layer)
+    finally:
+        fast_stark.os.urandom = genuine
+    assert root2 == root
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest() and len(got) > 2_000_000
+    assert one.verify(want, air, boundary, root) is True
+    wrong = [(0, 0, boundary[0][2] + FieldElement(1, field))] + boundary[1:]
+    assert one.verify(want, air, wrong, root) is False
