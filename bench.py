@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--force-diag-exchange", action="store_true",
                     help="send the block a rank keeps for itself through the collective as well (a one-rank world then exercises the whole RCCL path)")
     ap.add_argument("--no-native-exchange", action="store_true", help="do not probe the library's own RCCL communicator, only torch.distributed")
+    ap.add_argument("--no-direct-store", action="store_true", help="do not probe the direct-store corner turn (HIP IPC, no collective)")
+    ap.add_argument("--allow-replicas", action="store_true",
+                    help="N > 1: if the sharded path cannot be set up, time N independent single-GPU transforms instead of exiting non-zero")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -272,15 +275,19 @@ def main():
                 else:
                     log2n = 20 + (world.bit_length() - 1) + 1                   # 2^21 per GPU: 8 GPUs -> 2^24
                 n = 1 << log2n
-                step, eng, (x, y, z), corner_turn = sharded_setup(args, log2n, rank, world, dev, dist, backend)
+                step, eng, (x, y, z), corner_turn, corner_probes = sharded_setup(args, log2n, rank, world, dev, dist, backend)
                 launches_per_step = 2      # N > 1: roofline is reported per whole transform (local passes + corner turn)
                 workload = "ntt_fwd_inv_2^%d_fourstep_%dgpu" % (log2n, world)
                 total_n = n
                 parallelism = "four-step, column-sharded, 1 corner turn per transform"
         except Exception as e:       # noqa: BLE001
             replicas_reason = repr(e)[:300]
+            if not args.allow_replicas:
+                # a scaling run that silently measured N independent transforms would report a meaningless number with rc 0
+                sys.stderr.write("bench.py: the sharded path could not be set up (%s); --allow-replicas would time independent replicas instead\n" % replicas_reason)
+                sys.exit(4)
             sharded = False
-            sys.stderr.write("bench.py: sharded path failed (%s); falling back to independent replicas\n" % replicas_reason)
+            sys.stderr.write("bench.py: sharded path failed (%s); falling back to independent replicas (--allow-replicas)\n" % replicas_reason)
 
     if sharded and args.workload == "stark_census":
         return run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gpus)
@@ -362,6 +369,41 @@ def main():
         except Exception:       # noqa: BLE001  (no fixture: the round trip stays the guard)
             reference_sha = None
 
+    stages = weak = None
+    if sharded and args.workload == "ntt":
+        # where the time of the sharded transform goes (per stage, max over ranks), and the OTHER member of the pair strong / weak:
+        # the first multi-GPU run should need no second run to be read
+        try:
+            stages = stage_breakdown(eng, (x, y, z), rank, world, dev, dist, backend, reps=3 if shared_gpus else 10)
+        except Exception as e:       # noqa: BLE001
+            stages = {"error": repr(e)[:300]}
+        try:
+            scaling_is_strong = args.scaling == "strong" and world > 1
+            other_log2n = (20 + (world.bit_length() - 1) + 1) if scaling_is_strong else 24
+            if world > 1 and not args.log2n and other_log2n != log2n:
+                other_steps = 5 if shared_gpus else 50
+                step2, eng2, xyz2, _, _ = sharded_setup(args, other_log2n, rank, world, dev, dist, backend, only=(corner_probes["chosen"], corner_probes["chosen_kwargs"]))
+                for _ in range(2 if shared_gpus else 5):
+                    step2()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(other_steps):
+                    step2()
+                barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sec = float(t.item()) / other_steps
+                weak = strong_record(other_log2n, world, sec, bool(torch.equal(xyz2[2], xyz2[0])), corner_probes["chosen"],
+                                     2 * ((1 << other_log2n) // world) * 16 * (world - 1) // world,
+                                     {"scaling": "weak (2^21 elements per GPU)" if scaling_is_strong else "strong (2^24 in total)", "steps": other_steps,
+                                      "stages_us": stage_breakdown(eng2, xyz2, rank, world, dev, dist, backend, reps=3 if shared_gpus else 10)})
+                if getattr(eng2.stages, "direct", False):
+                    dist.barrier()
+                    eng2.stages.release_direct()
+                del step2, eng2, xyz2
+        except Exception as e:       # noqa: BLE001
+            weak = {"error": repr(e)[:300]}
+
     census = prover = None
     if sharded and world > 1 and not args.no_extras:
         # the whole config-5 pipeline on the same ranks, once warm and once timed (all ranks take part; rank 0 reports)
@@ -419,6 +461,12 @@ def main():
             out["config"]["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
             out["config"]["world_size"] = world
             out["config"]["corner_turn"] = corner_turn
+            out["config"]["corner_turn_probes"] = corner_probes
+            out["config"]["split"] = "n1 = 2^%d x n2 = 2^%d" % (eng.n1.bit_length() - 1, eng.n2.bit_length() - 1)
+            out["config"]["node"] = node_facts(dev)
+            out["roofline"]["stages_us"] = stages
+            if weak is not None:
+                out.setdefault("extras", {})["ntt_other_scaling"] = weak
             out["config"]["all_to_all_bytes_sent_per_rank_per_step"] = 2 * (total_n // world) * 16 * (world - 1) // world
             out["config"]["series"] = ("north_star strong-scaling series: forward + inverse 2^%d for every N; the N = 1 member is extras.ntt_2p24_strong of the "
                                        "N = 1 run (whose headline is BASELINE configs[1], 2^20)" % log2n) if scaling_label == "strong" else \
@@ -469,18 +517,30 @@ def strong_record(log2n, world, seconds_per_pair, roundtrip_ok, corner_turn, byt
     return rec
 
 
-def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4):
+def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4, only=None):
     """The sharded transform of length 2^log2n ready to be timed: every form of the corner turn this job can run is built, its
     forward transform compared with the first form's element for element, its round trip checked, and timed for a few steps;
-    the fastest correct one is returned as (step, engine, (x, y, z), description).  The choice is the same on every rank."""
+    the fastest correct one is returned as (step, engine, (x, y, z), description, probes).  The choice is the same on every
+    rank: a form is dropped on ALL ranks as soon as any rank fails to build it or gets a wrong result (the ranks agree on a flag
+    before the next collective), and the probe times are all-reduced.  only: a (label, kwargs) pair to build without probing."""
     import torch
     from sharded import ShardedNtt, init_native_comm
     n = 1 << log2n
     root = nth_root(n)
     on_dev = backend == "nccl"
+
+    def agreed(flag):
+        """True iff `flag` is true on every rank"""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
     forms = []                                    # (label, ShardedNtt kwargs)
     own = dict(always_exchange=True) if args.force_diag_exchange else {}
-    if world == 1 and not args.force_diag_exchange:
+    if only is not None:
+        forms = [only]
+    elif world == 1 and not args.force_diag_exchange:
         forms.append(("one rank: nothing to exchange, the column stage writes the rank's own block in place", {}))
     else:
         if world > 1 and not args.force_diag_exchange:
@@ -495,55 +555,153 @@ def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4):
                 native = init_native_comm(rank, world, dev)
             except Exception as e1:       # noqa: BLE001
                 sys.stderr.write("bench.py: the library's RCCL communicator is unavailable (%r)\n" % (e1,))
+            native = agreed(native)
         if native:
             forms.append(("library RCCL communicator, one exchange on the compute stream", dict(own, native_exchange=True)))
             forms.append(("library RCCL communicator, 2 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=2)))
             forms.append(("library RCCL communicator, 4 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=4)))
-    candidates, y_ref = [], None
+        if not args.no_direct_store:
+            # no collective at all: the column stage stores block h straight into rank h's receive buffer (HIP IPC over xGMI),
+            # a flag barrier, the row stage -- with the default split and, above 2^16, with the square one (fewer, longer rows)
+            forms.append(("direct store: column stage writes into the peers' receive buffers (HIP IPC), flag barrier, no collective", dict(direct_store=True)))
+            if log2n >= 20:
+                forms.append(("direct store, square split n1 = 2^%d" % (log2n // 2), dict(direct_store=True, log_n1=log2n // 2)))
+        if log2n >= 20 and native:
+            forms.append(("library RCCL communicator, one exchange, square split n1 = 2^%d" % (log2n // 2), dict(own, native_exchange=True, log_n1=log2n // 2)))
+    candidates, y_ref, probes = [], None, []
     for label, kw in forms:
+        eng = x = y = z = None
+        built = True
         try:
             eng = ShardedNtt(log2n, root, rank, world, dev, **kw)
             if kw.get("native_exchange"):
                 eng.stages.native = True
+            if kw.get("direct_store") and not eng.direct_store:
+                raise RuntimeError("the peers' regions could not be mapped")
             x = eng.synthetic_input(seed=1)
             y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
             z = torch.empty_like(x)
-
-            def step(eng=eng, x=x, y=y, z=z):
-                eng.forward(x, y)
-                eng.inverse(y, z)
-
-            step()
-            dist.barrier()
-            torch.cuda.synchronize()
-            same = torch.equal(z, x)
-            if y_ref is None:
-                y_ref = y.clone()
-            else:
-                same = same and torch.equal(y_ref, y)
-            good = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
-            dist.all_reduce(good, op=dist.ReduceOp.MIN)
-            if int(good.item()) != 1:
-                raise RuntimeError("wrong result")
-            for _ in range(2):
-                step()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(probe_steps):
-                step()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if on_dev else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            candidates.append((float(t.item()) / probe_steps, label, step, eng, (x, y, z)))
         except Exception as e1:       # noqa: BLE001
-            sys.stderr.write("bench.py: corner turn form '%s' unavailable (%r)\n" % (label, e1))
+            built = False
+            sys.stderr.write("bench.py: corner turn form '%s' unavailable on rank %d (%r)\n" % (label, rank, e1))
+        if not agreed(built):                      # nobody enters this form's collectives unless everybody can
+            probes.append({"form": label, "available": False})
+            continue
+
+        def step(eng=eng, x=x, y=y, z=z):
+            eng.forward(x, y)
+            eng.inverse(y, z)
+
+        step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        same = torch.equal(z, x)
+        if kw.get("log_n1") and y_ref is not None:
+            pass                                   # another split leaves another slab layout: the round trip is its check
+        elif y_ref is None and not kw.get("log_n1"):
+            y_ref = y.clone()
+        elif y_ref is not None:
+            same = same and torch.equal(y_ref, y)
+        if kw.get("direct_store"):
+            same = same and eng.stages.direct_timed_out() == 0
+        if not agreed(same):
+            sys.stderr.write("bench.py: corner turn form '%s' gave a WRONG result (rank %d: %s)\n" % (label, rank, "ok here" if same else "mismatch"))
+            probes.append({"form": label, "available": True, "correct": False})
+            continue
+        for _ in range(2):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(probe_steps):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if on_dev else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec = float(t.item()) / probe_steps
+        candidates.append((sec, label, step, eng, (x, y, z), kw))
+        probes.append({"form": label, "available": True, "correct": True, "ms_per_pair": sec * 1e3})
     if not candidates:
         raise RuntimeError("no working corner turn")
     best = min(candidates, key=lambda c: c[0])         # the same choice on every rank (times are all-reduced)
     desc = best[1] + "; probe ms/step: " + ", ".join("[%s] %.3f" % (c[1], c[0] * 1e3) for c in candidates)
-    return best[2], best[3], best[4], desc
+    for c in candidates:                               # the losers give their buffers (and mapped regions) back
+        if c is not best and getattr(c[3].stages, "direct", False):
+            dist.barrier()
+            c[3].stages.release_direct()
+    return best[2], best[3], best[4], desc, {"chosen": best[1], "chosen_kwargs": {k: v for k, v in best[5].items()}, "probes": probes}
+
+
+def stage_breakdown(eng, xyz, rank, world, dev, dist, backend, reps=10):
+    """Where a sharded transform's time goes, per direction: the column stage and the row stage of this rank timed ALONE with HIP
+    events (local kernels, no exchange: the stage object's cols / rows on scratch buffers), the whole transform the same way,
+    `exchange_and_waiting_us` = whole - cols - rows (the corner turn plus whatever the stages wait for: a derived figure -- in
+    the direct-store form the column stage's own stores ARE the exchange, so it also holds the slower remote stores).  Max over
+    ranks.  Bytes: what one rank sends to ONE peer per transform."""
+    import torch
+    x, y, z = xyz
+    st = eng.stages
+    G = world
+    on_dev = backend == "nccl"
+    stream = torch.cuda.current_stream(dev)
+    out = {}
+    if st is None:
+        return out
+    scratch_send = torch.empty((eng.n // G, 2), dtype=torch.int64, device=dev)
+    scratch_recv = torch.empty((eng.n // G, 2), dtype=torch.int64, device=dev)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if world > 1:
+            dist.barrier()
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], dtype=torch.float64, device=dev if on_dev else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for name, inv, src, dst in (("forward", 0, x, y), ("inverse", 1, y, z)):
+        cols = timed(lambda: eng._run(lambda: st.cols(inv, src, scratch_send, scratch_recv)))
+        rows = timed(lambda: eng._run(lambda: st.rows(inv, scratch_recv, dst, 0, 1, False)))
+        whole = timed((lambda: eng.forward(x, y)) if inv == 0 else (lambda: eng.inverse(y, z)))
+        out[name] = {"cols_us": cols, "rows_us": rows, "whole_us": whole, "exchange_and_waiting_us": whole - cols - rows}
+    # the timed stages have overwritten y / z with transforms of scratch data: restore the pair the caller checks
+    eng.forward(x, y)
+    eng.inverse(y, z)
+    torch.cuda.synchronize()
+    out["bytes_to_each_peer_per_transform"] = (eng.n // G // G) * 16 if G > 1 else 0
+    out["messages_per_rank_per_transform"] = G - 1
+    return out
+
+
+def node_facts(dev):
+    """what the first multi-GPU run should say about the node without a second run: RCCL / HIP versions, the peer-access matrix"""
+    import torch
+    facts = {}
+    try:
+        facts["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:       # noqa: BLE001
+        facts["rccl_version"] = repr(e)[:80]
+    facts["hip_version"] = getattr(torch.version, "hip", None)
+    n = torch.cuda.device_count()
+    facts["visible_gpus"] = n
+    try:
+        facts["can_access_peer"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]
+    except Exception as e:       # noqa: BLE001
+        facts["can_access_peer"] = repr(e)[:80]
+    try:
+        facts["device_name"] = torch.cuda.get_device_name(dev)
+    except Exception:            # noqa: BLE001
+        pass
+    return facts
 
 
 def collective_label(backend, world, ngpu, shared_gpus):

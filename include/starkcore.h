@@ -127,6 +127,8 @@ int sc_ntt_rows_t_ld_dev(const void* d_in, void* d_out, uint64_t len, uint64_t b
 typedef struct sc_fourstep sc_fourstep_t;
 typedef struct { char internal[128]; } sc_rccl_id_t;   /* = ncclUniqueId */
 int sc_fourstep_create(int log2n, const uint64_t root[2], int rank, int world, sc_fourstep_t** plan);
+/* the same with the split chosen by the caller: n1 = 2^log_n1 (0 = the default: 2^8 above 2^16, square below) */
+int sc_fourstep_create_ex(int log2n, const uint64_t root[2], int rank, int world, int log_n1, sc_fourstep_t** plan);
 int sc_fourstep_free(sc_fourstep_t* plan);
 int sc_fourstep_shape(const sc_fourstep_t* plan, int inverse, uint64_t* rows, uint64_t* cols_total);
 int sc_fourstep_cols_dev(const sc_fourstep_t* plan, int inverse, const void* d_src, void* d_send, void* d_recv_diag, void* stream);
@@ -140,6 +142,23 @@ int sc_comm_init(const char* rccl_path, const sc_rccl_id_t* id, int rank, int wo
 int sc_comm_destroy(void);
 int sc_fourstep_run_dev(const sc_fourstep_t* plan, int inverse, const void* d_src, void* d_send, void* d_recv, void* d_dst, uint64_t nblocks, int defer_last_pass,
                         int force_diag_exchange, void* stream);
+/* DIRECT-STORE corner turn: no collective at all.  Every rank owns a REGION of device memory -- [4 KiB of flags][receive buffer
+ * 0][receive buffer 1], sc_fourstep_region_bytes() bytes -- exported with a HIP IPC handle (64 bytes, carried to the other ranks
+ * by the caller's launcher) and mapped by every peer (sc_ipc_region_open).  sc_fourstep_run_direct_dev then runs the whole
+ * transform: the column stage stores block h of its output STRAIGHT INTO rank h's receive buffer (the stores cross xGMI; no
+ * send buffer, no copy kernel, one HBM write + read per element less than a send/recv exchange), a one-wave kernel raises this
+ * rank's flag at every peer and waits for theirs (system-scope atomics), and the row stage reads the rank's own receive buffer.
+ * Consecutive transforms alternate between the two receive buffers, so a peer's next column stage never overwrites what a row
+ * stage is still reading.  Every rank must run the same transforms in the same order.  A barrier that waits ~2 s for a peer
+ * gives up (sc_fourstep_direct_status reports the epoch); the transform's output is then undefined. */
+int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]);
+int sc_ipc_region_open(const uint8_t handle[64], void** d_region);
+int sc_ipc_region_close(void* d_region);        /* a region opened from a peer's handle */
+int sc_ipc_region_free(void* d_region);         /* a region this process created */
+int sc_fourstep_region_bytes(const sc_fourstep_t* plan, uint64_t* bytes);
+int sc_fourstep_set_peers(sc_fourstep_t* plan, void* const* regions);      /* regions[h]: rank h's region as mapped HERE (own: its own) */
+int sc_fourstep_run_direct_dev(sc_fourstep_t* plan, int inverse, const void* d_src, void* d_dst, void* stream);
+int sc_fourstep_direct_status(const sc_fourstep_t* plan, uint64_t* timed_out_epoch);
 /* d_data[r][c] *= root^((row_base + r) * (col_base + c)) * scale, root of order `order` (scale may be NULL = 1) */
 int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t row_base, uint64_t col_base, const uint64_t root[2], uint64_t order,
                           const uint64_t scale[2], void* stream);

@@ -257,6 +257,11 @@ struct BatchExtras {
     // `out` (PassParams::out_alt): the block of the corner turn a rank keeps for itself
     Fe* diag_out = nullptr;
     uint32_t diag_lo = 0, diag_n = 0;
+    // BATCH_COLS, general form of the same: the natural output rows in blocks of `block_rows` (a power of two), block h stored
+    // into block_out[h] (same element index; len / block_rows <= SC_MAX_BLOCKS entries) -- the direct-store corner turn, where
+    // block_out[h] points into rank h's receive buffer.  Takes precedence over diag_out.
+    Fe* const* block_out = nullptr;
+    uint32_t block_rows = 0;
 };
 
 inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatch, const NttTables& tb,
@@ -335,12 +340,18 @@ inline bool plan_batched(NttPlanDesc& d, BatchKind kind, int loglen, int logbatc
                     p.tw_col_base = 0;
                 }
             }
-            if (lastp && ex.diag_out && ex.diag_n) {
-                p.out_alt = ex.diag_out;
-                p.alt_lo = ex.diag_lo;
-                p.alt_n = ex.diag_n;
-                p.alt_row_k = 1u << logA;                       // natural output row = t_mid + N_1 * k (two passes) or k (one pass)
-                p.alt_row_mid = (m == 2) ? 1u : 0u;
+            if (lastp && ((ex.block_out && ex.block_rows) || (ex.diag_out && ex.diag_n))) {
+                const uint32_t rows = ex.block_out ? ex.block_rows : ex.diag_n;
+                const uint64_t nblk = len / rows;
+                if ((rows & (rows - 1)) || nblk < 1 || nblk > SC_MAX_BLOCKS || nblk * rows != len) return false;
+                if (!ex.block_out && (ex.diag_lo % rows)) return false;
+                p.blk_enable = 1;
+                p.blk_log = 0;
+                while ((1u << p.blk_log) < rows) ++p.blk_log;
+                p.blk_row_k = 1u << logA;                       // natural output row = t_mid + N_1 * k (two passes) or k (one pass)
+                p.blk_row_mid = (m == 2) ? 1u : 0u;
+                for (uint64_t h = 0; h < nblk; ++h)
+                    p.out_blk[h] = ex.block_out ? ex.block_out[h] : (h == ex.diag_lo / rows ? ex.diag_out : p.out);
             }
             pd.ntiles = (uint32_t)((len * batch) >> (logR + logC));
         } else if (!lastp) {

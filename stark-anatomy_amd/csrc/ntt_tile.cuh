@@ -24,6 +24,10 @@
 
 namespace sc {
 
+#ifndef SC_MAX_BLOCKS
+#define SC_MAX_BLOCKS 16        // ranks of one node a column stage can address (destination table of PassParams)
+#endif
+
 struct PassParams {
     const Fe* in;
     Fe* out;
@@ -74,13 +78,18 @@ struct PassParams {
     // round, so the waves of a SIMD reach the barrier together instead of the oldest always winning the VALU arbitration and
     // the youngest finishing alone at half the issue rate (+2-4 % at 2^20; -3..5 % when other workgroups fill the gaps anyway)
     int prio_balance;
-    // optional second destination for a RANGE of natural output rows (column stage of the multi-GPU four-step: the rows a rank
-    // keeps for itself go straight into its receive buffer, so the diagonal block of the corner turn is neither copied nor
-    // sent): elements whose natural row  k * alt_row_k + t_mid * alt_row_mid  lies in [alt_lo, alt_lo + alt_n) are stored at
-    // out_alt[j] instead of out[j] (same index j).  nullptr = off.
-    Fe* out_alt;
-    uint32_t alt_lo, alt_n;
-    uint32_t alt_row_k, alt_row_mid;
+    // optional DESTINATION TABLE for the natural output rows (column stage of the multi-GPU four-step): the rows are cut into
+    // blocks of 2^blk_log rows, block h = what rank h receives in the corner turn, and an element of natural row
+    //   k * blk_row_k + t_mid * blk_row_mid
+    // is stored at out_blk[row >> blk_log][j] instead of out[j] (same element index j).  Two uses: the block a rank keeps for
+    // itself goes straight into its own receive buffer (the diagonal of the corner turn is neither copied nor sent; every
+    // other entry = `out`), and the DIRECT-STORE corner turn: entry h points into rank h's receive buffer, mapped through
+    // HIP IPC, so the stores themselves cross xGMI and no collective kernel, send buffer or extra HBM round trip exists.
+    // blk_enable = 0: off (plain `out`).
+    int blk_enable;
+    int blk_log;
+    uint32_t blk_row_k, blk_row_mid;
+    Fe* out_blk[SC_MAX_BLOCKS];
     // diagnostics (tools/pass_trace.py): per-wave s_memtime stamps of the phases of a workgroup; nullptr in production
     unsigned long long* trace;
 };
@@ -325,10 +334,10 @@ struct Round {
     }
     SC_HD void scatter_global(const PassParams& P, const Fe* x) const {
         Fe none[E];
-        if (P.out_alt != nullptr) scatter_global<true>(P, x, none, false);
+        if (P.blk_enable) scatter_global<true>(P, x, none, false);
         else scatter_global<false>(P, x, none, false);
     }
-    // ALT: the launch has a second destination (PassParams::out_alt).  A compile-time switch: with the test at run time (inside
+    // ALT: the launch has a destination table (PassParams::out_blk).  A compile-time switch: with the test at run time (inside
     // the store loop, or two loops behind one branch) the plain transforms paid 1-2 % more VALU instructions for index math
     // the compiler hoisted above the branch; the geometry-specialised kernels are instantiated for both values.
     template <bool ALT>
@@ -374,9 +383,9 @@ struct Round {
             const uint32_t k = bitrev32(row(i, 0), logR), c = cc[i >> S];
             uint64_t j = (uint64_t)t_hi * P.out_hi + (uint64_t)t_mid * P.out_mid + (uint64_t)t_lo * P.out_lo + (uint64_t)k * P.out_rs + (uint64_t)c * P.out_cs;
             if constexpr (ALT) {
-                // natural rows [alt_lo, alt_lo + alt_n) go to out_alt, the others to out (same element index)
-                const uint32_t nat = k * P.alt_row_k + t_mid * P.alt_row_mid;
-                Fe* dst = (nat - P.alt_lo < P.alt_n) ? P.out_alt : P.out;
+                // the block of the natural row picks the destination (same element index everywhere)
+                const uint32_t nat = k * P.blk_row_k + t_mid * P.blk_row_mid;
+                Fe* dst = P.out_blk[nat >> P.blk_log];
                 dst[j] = v[i];
             } else {
                 P.out[j] = v[i];

@@ -714,9 +714,9 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
             // (a launch with a second destination -- the column stage of the sharded transform -- has its own instantiation; it
             // is never traced: the generic kernel serves that combination)
 #define SC_FIXED(LR, LC)                                                          \
-            if (lr == LR && lc == LC && !(pd.p.trace && pd.p.out_alt)) {          \
+            if (lr == LR && lc == LC && !(pd.p.trace && pd.p.blk_enable)) {          \
                 if (pd.p.trace) SC_LAUNCH_FIXED(LR, LC, true, false);             \
-                else if (pd.p.out_alt) SC_LAUNCH_FIXED(LR, LC, false, true);      \
+                else if (pd.p.blk_enable) SC_LAUNCH_FIXED(LR, LC, false, true);      \
                 else SC_LAUNCH_FIXED(LR, LC, false, false);                       \
                 return;                                                           \
             }
@@ -1878,6 +1878,8 @@ struct BatchCall {
     uint64_t chunks = 1, out_ld = 0, chunk_stride = 0;   // kind 1 (BatchExtras)
     Fe* diag_out = nullptr;          // kind 0: second destination for natural rows [diag_lo, diag_lo + diag_n)
     uint32_t diag_lo = 0, diag_n = 0;
+    Fe* const* block_out = nullptr;  // kind 0: destination table, one entry per block of block_rows natural rows (direct-store corner turn)
+    uint32_t block_rows = 0;
     Fe* work = nullptr;              // work buffer of a two-pass plan (nullptr: scratch slot 0, len * batch elements)
     int pass_lo = 0, pass_hi = 4;    // run passes [pass_lo, pass_hi) of the plan only
     bool roots_checked = false;      // the caller has validated the roots already (a cached plan object)
@@ -1892,7 +1894,7 @@ static int batch_call(const BatchCall& c, hipStream_t st, int* npasses_out = nul
     const uint64_t chunks = c.chunks ? c.chunks : 1;
     if (!is_pow2(chunks) || (chunks > 1 && kind != 1)) return fail(SC_ERR_BAD_ARG, "chunked input is for kind 1 and needs a power-of-two chunk count");
     if (c.outer && kind != 0) return fail(SC_ERR_BAD_ARG, "the outer twiddle belongs to the column stage (kind 0)");
-    if (c.diag_out && kind != 0) return fail(SC_ERR_BAD_ARG, "the second destination belongs to the column stage (kind 0)");
+    if ((c.diag_out || c.block_out) && kind != 0) return fail(SC_ERR_BAD_ARG, "the second destination belongs to the column stage (kind 0)");
     Fe rt = c.root;
     if (!c.roots_checked) SCCHK(check_root(rt, len));
     const int loglen = ilog2(len), logbatch = ilog2(batch);
@@ -1906,6 +1908,8 @@ static int batch_call(const BatchCall& c, hipStream_t st, int* npasses_out = nul
     ex.diag_out = c.diag_out;
     ex.diag_lo = c.diag_lo;
     ex.diag_n = c.diag_n;
+    ex.block_out = c.block_out;
+    ex.block_rows = c.block_rows;
     if (c.out_ld) {
         if (kind != 1 || c.out_ld < batch) return fail(SC_ERR_BAD_ARG, "an output leading dimension belongs to kind 1 and must be >= batch");
         ex.out_ld = c.out_ld;
@@ -2028,7 +2032,13 @@ struct sc_fourstep {
         Fe root_rows;     // root^R: primitive C-th root
         bool ninv;
     } dir[2];
+    // direct-store corner turn (sc_fourstep_set_peers): every rank's region, mapped here through HIP IPC -- [4 KiB of flags]
+    // [receive buffer 0][receive buffer 1], n / world elements each; transform number `epoch` lands in buffer epoch & 1
+    bool peers_set = false;
+    uint8_t* region[SC_MAX_BLOCKS] = {};
+    uint64_t epoch = 0;
 };
+constexpr size_t FOURSTEP_FLAG_BYTES = 4096;
 
 namespace {
 struct RcclApi {
@@ -2153,16 +2163,21 @@ static int fourstep_rows_finish(const sc_fourstep* p, int dirn, Fe* dst, hipStre
 }  // namespace
 
 int sc_fourstep_create(int log2n, const uint64_t root[2], int rank, int world, sc_fourstep_t** out) {
+    return sc_fourstep_create_ex(log2n, root, rank, world, 0, out);
+}
+int sc_fourstep_create_ex(int log2n, const uint64_t root[2], int rank, int world, int log_n1, sc_fourstep_t** out) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!out || !root) return fail(SC_ERR_BAD_ARG, "null argument");
-    if (log2n < 2 || log2n > 40 || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world) return fail(SC_ERR_BAD_ARG, "bad four-step shape");
+    if (log2n < 2 || log2n > 40 || world < 1 || world > SC_MAX_BLOCKS || (world & (world - 1)) || rank < 0 || rank >= world) return fail(SC_ERR_BAD_ARG, "bad four-step shape");
     const uint64_t n = 1ull << log2n;
     Fe rt = fe_from(root);
     SCCHK(check_root(rt, n));
     // small domains: square split; large ones: n1 = 2^8, so that the column stage of the forward transform is ONE pass
-    // (256-point transforms) and the row stage two, and the other way round for the inverse: three passes per transform
-    const int log1 = log2n <= 16 ? (log2n + 1) / 2 : 8;
+    // (256-point transforms) and the row stage two, and the other way round for the inverse: three passes per transform.
+    // log_n1 > 0 overrides the split (e.g. the square 2^12 x 2^12 at 2^24: fewer, longer rows per rank and per message).
+    const int log1 = log_n1 > 0 ? log_n1 : (log2n <= 16 ? (log2n + 1) / 2 : 8);
+    if (log1 < 1 || log1 >= log2n || log1 > 18 || log2n - log1 > 18) return fail(SC_ERR_BAD_ARG, "unsupported split of the four-step transform");
     sc_fourstep* p = new sc_fourstep;
     p->log2n = log2n; p->rank = rank; p->world = world; p->n = n;
     p->n1 = 1ull << log1; p->n2 = n >> log1;
@@ -2212,6 +2227,127 @@ int sc_fourstep_rows_finish_dev(const sc_fourstep_t* plan, int inverse, void* d_
     const sc_fourstep::Dir& d = plan->dir[inverse ? 1 : 0];
     if (batched_passes(ilog2(d.C)) == 1) return SC_OK;     // single-pass rows: nothing was deferred
     return fourstep_rows_finish(plan, inverse ? 1 : 0, (Fe*)d_dst, pick_stream(stream));
+}
+
+// ---- direct-store corner turn: peers' receive buffers mapped through HIP IPC, the column stage stores across xGMI itself
+struct IpcFlags { uint64_t* of[SC_MAX_BLOCKS]; };      // of[h]: rank h's flag array (entry g = the last epoch rank g has finished writing)
+
+// One workgroup, one lane per peer: tell peer t that this rank's column stage of transform `epoch` is complete (the stage is the
+// PREVIOUS kernel on this stream: its stores are released at its end; the fence below orders the flag behind them once more),
+// then wait until every peer has said the same to this rank.  System-scope atomics: the flags live in other GPUs' memory.
+// A peer that never arrives (a crashed rank) must not hang the device for ever: after ~2 s the wait gives up and marks the
+// region (flag word SC_MAX_BLOCKS), the transform's output is then garbage and the caller's checks see it.
+__global__ void __launch_bounds__(64) ipc_barrier_kernel(IpcFlags flags, int rank, int world, uint64_t epoch) {
+    const int t = threadIdx.x;
+    __threadfence_system();
+    if (t < world && t != rank) {
+        __hip_atomic_store(&flags.of[t][rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint64_t spins = 0;
+        while (__hip_atomic_load(&flags.of[rank][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1ull << 22)) { __hip_atomic_store(&flags.of[rank][SC_MAX_BLOCKS], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+    }
+    __threadfence_system();
+}
+
+int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!bytes || !d_region || !handle_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    hipError_t e = hipMemset(p, 0, bytes);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) { (void)hipFree(p); return fail(SC_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+    memcpy(handle_out, &h, 64);
+    *d_region = p;
+    return SC_OK;
+}
+int sc_ipc_region_open(const uint8_t handle[64], void** d_region) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!handle || !d_region) return fail(SC_ERR_BAD_ARG, "null argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SC_ERR_HIP, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e)); }
+    *d_region = p;
+    return SC_OK;
+}
+int sc_ipc_region_close(void* d_region) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_region) return SC_OK;
+    (void)hipDeviceSynchronize();
+    HIPCHK(hipIpcCloseMemHandle(d_region));
+    return SC_OK;
+}
+int sc_ipc_region_free(void* d_region) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_region) return SC_OK;
+    (void)hipDeviceSynchronize();
+    HIPCHK(hipFree(d_region));
+    return SC_OK;
+}
+int sc_fourstep_region_bytes(const sc_fourstep_t* plan, uint64_t* bytes) {
+    if (!plan || !bytes) return fail(SC_ERR_BAD_ARG, "null argument");
+    *bytes = FOURSTEP_FLAG_BYTES + 2 * (plan->n / (uint64_t)plan->world) * sizeof(Fe);
+    return SC_OK;
+}
+int sc_fourstep_set_peers(sc_fourstep_t* plan, void* const* regions) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!plan || !regions) return fail(SC_ERR_BAD_ARG, "null argument");
+    for (int h = 0; h < plan->world; ++h) {
+        if (!regions[h]) return fail(SC_ERR_BAD_ARG, "a rank's region is missing");
+        plan->region[h] = (uint8_t*)regions[h];
+    }
+    plan->peers_set = true;
+    plan->epoch = 0;
+    return SC_OK;
+}
+// the whole transform in the direct-store form: column stage (block h stored straight into rank h's receive buffer, own block
+// included), flag barrier, row stage out of this rank's receive buffer.  Collective in the sense that every rank must call it for
+// the same transforms in the same order; asynchronous on `stream`.
+int sc_fourstep_run_direct_dev(sc_fourstep_t* plan, int inverse, const void* d_src, void* d_dst, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!plan || !d_src || !d_dst) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (!plan->peers_set) return fail(SC_ERR_BAD_ARG, "sc_fourstep_set_peers has not been called");
+    hipStream_t st = pick_stream(stream);
+    const int dirn = inverse ? 1 : 0;
+    const sc_fourstep::Dir& d = plan->dir[dirn];
+    const uint64_t G = (uint64_t)plan->world, g_ = (uint64_t)plan->rank, rw = d.R / G, cw = d.C / G, blk = rw * cw;
+    const uint64_t per_rank = plan->n / G;
+    const uint64_t parity = plan->epoch & 1;
+    auto recv_of = [&](uint64_t h) { return (Fe*)(plan->region[h] + FOURSTEP_FLAG_BYTES) + parity * per_rank; };
+    Fe* table[SC_MAX_BLOCKS];
+    for (uint64_t h = 0; h < G; ++h) table[h] = recv_of(h) + (int64_t)(g_ - h) * (int64_t)blk;     // element j = h * blk + ... lands in block g_ of rank h
+    BatchCall c;
+    c.in = (const Fe*)d_src; c.out = recv_of(g_); c.len = d.R; c.batch = cw; c.kind = 0; c.root = d.root_cols;
+    c.outer = true; c.outer_root = d.root; c.outer_order = plan->n; c.outer_col_base = g_ * cw; c.outer_ninv = d.ninv;
+    c.block_out = table; c.block_rows = (uint32_t)rw;
+    c.roots_checked = true;
+    SCCHK(batch_call(c, st));
+    if (G > 1) {
+        IpcFlags fl;
+        for (uint64_t h = 0; h < SC_MAX_BLOCKS; ++h) fl.of[h] = h < G ? (uint64_t*)plan->region[h] : nullptr;
+        hipLaunchKernelGGL(ipc_barrier_kernel, dim3(1), dim3(64), 0, st, fl, plan->rank, plan->world, plan->epoch + 1);
+        HIPCHK(hipGetLastError());
+    }
+    SCCHK(fourstep_rows(plan, dirn, recv_of(g_), (Fe*)d_dst, 0, 1, false, st));
+    plan->epoch += 1;
+    return SC_OK;
+}
+// 0 while every flag barrier of this plan has completed; the epoch of the first one that gave up waiting otherwise (read after
+// the stream has been synchronised)
+int sc_fourstep_direct_status(const sc_fourstep_t* plan, uint64_t* timed_out_epoch) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!plan || !timed_out_epoch || !plan->peers_set) return fail(SC_ERR_BAD_ARG, "no direct-store set-up");
+    HIPCHK(hipMemcpy(timed_out_epoch, plan->region[plan->rank] + SC_MAX_BLOCKS * sizeof(uint64_t), sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SC_OK;
 }
 
 // ---- native RCCL communicator (one per process) for the corner turn of sc_fourstep_run_dev

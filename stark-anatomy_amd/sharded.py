@@ -98,9 +98,9 @@ class HipEngine:
         """pointwise quotient (code/ntt.py:172); a zero divisor raises the reference's AssertionError("divide by zero")"""
         self.sc._check(self.lib.sc_pointwise_div_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), count, self.sptr))
 
-    def fourstep(self, log2n, root, rank, world):
+    def fourstep(self, log2n, root, rank, world, log_n1=0):
         """the rank's stage object for the sharded transform (sc_fourstep_t)"""
-        return HipFourstep(self.sc, log2n, root, rank, world, self.sptr)
+        return HipFourstep(self.sc, log2n, root, rank, world, self.sptr, log_n1)
 
 
 class _DoneWork:
@@ -124,13 +124,80 @@ class HipFourstep:
     """A rank's share of the sharded transform as ONE library object (sc_fourstep_t, include/starkcore.h): roots, stage shapes,
     the outer-twiddle table and the kernel plans are fixed once; a stage is one ctypes call with pointers only."""
 
-    def __init__(self, sc, log2n, root, rank, world, sptr):
+    def __init__(self, sc, log2n, root, rank, world, sptr, log_n1=0):
         import ctypes
         self.sc, self.lib, self.sptr, self.ct = sc, sc.lib(), sptr, ctypes
+        self.rank, self.world = rank, world
         h = ctypes.c_void_p()
-        sc._check(self.lib.sc_fourstep_create(log2n, _fe(root), rank, world, ctypes.byref(h)))
+        sc._check(self.lib.sc_fourstep_create_ex(log2n, _fe(root), rank, world, int(log_n1), ctypes.byref(h)))
         self._h = h
         self.native = False            # sc_comm_init has been called for this world: run() may be used
+        self.direct = False            # setup_direct() has mapped every rank's receive region: run_direct() may be used
+        self._own_region, self._peer_regions = None, []
+
+    def n1(self):
+        rows = self.ct.c_uint64()
+        self.sc._check(self.lib.sc_fourstep_shape(self._h, 0, self.ct.byref(rows), None))
+        return int(rows.value)
+
+    def setup_direct(self, device, group=None):
+        """The direct-store corner turn (sc_fourstep_run_direct_dev): this rank's receive region is created and exported (HIP IPC),
+        the 64-byte handles travel once through torch.distributed, every peer's region is mapped.  Collective.  Returns True when
+        it is up on EVERY rank."""
+        ct, sc, lib = self.ct, self.sc, self.lib
+        G, g = self.world, self.rank
+        size = ct.c_uint64()
+        sc._check(lib.sc_fourstep_region_bytes(self._h, ct.byref(size)))
+        region, handle = ct.c_void_p(), ct.create_string_buffer(64)
+        ok = 1 if lib.sc_ipc_region_create(size.value, ct.byref(region), handle) == 0 else 0
+        if ok:
+            self._own_region = region
+        regions = [None] * G
+        regions[g] = region.value
+        if G > 1:
+            on_dev = dist.get_backend(group) == "nccl"
+            mine = torch.tensor([ok] + list(handle.raw), dtype=torch.int32)
+            mine = mine.to(device) if on_dev else mine
+            parts = [torch.empty_like(mine) for _ in range(G)]
+            dist.all_gather(parts, mine, group=group)
+            parts = [t.cpu() for t in parts]
+            ok = int(all(int(t[0]) == 1 for t in parts))
+            if ok:
+                for h in range(G):
+                    if h == g:
+                        continue
+                    peer = ct.c_void_p()
+                    if lib.sc_ipc_region_open(bytes(int(v) & 255 for v in parts[h][1:].tolist()), ct.byref(peer)) != 0:
+                        ok = 0
+                        break
+                    self._peer_regions.append(peer)
+                    regions[h] = peer.value
+            flag = torch.tensor([ok], dtype=torch.int32)
+            flag = flag.to(device) if on_dev else flag
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = int(flag.item())
+        if ok:
+            sc._check(lib.sc_fourstep_set_peers(self._h, (ct.c_void_p * G)(*regions)))
+            self.direct = True
+        return bool(ok)
+
+    def run_direct(self, inverse, src, dst):
+        self.sc._check(self.lib.sc_fourstep_run_direct_dev(self._h, inverse, src.data_ptr(), dst.data_ptr(), self.sptr))
+
+    def direct_timed_out(self):
+        """0, or the epoch of the first flag barrier that gave up waiting for a peer (call after synchronising the stream)"""
+        v = self.ct.c_uint64()
+        self.sc._check(self.lib.sc_fourstep_direct_status(self._h, self.ct.byref(v)))
+        return int(v.value)
+
+    def release_direct(self):
+        for peer in self._peer_regions:
+            self.lib.sc_ipc_region_close(peer)
+        self._peer_regions = []
+        if self._own_region is not None:
+            self.lib.sc_ipc_region_free(self._own_region)
+            self._own_region = None
+        self.direct = False
 
     def cols(self, inverse, src, send, recv_diag):
         self.sc._check(self.lib.sc_fourstep_cols_dev(self._h, inverse, src.data_ptr(), send.data_ptr(), None if recv_diag is None else recv_diag.data_ptr(), self.sptr))
@@ -148,6 +215,7 @@ class HipFourstep:
     def __del__(self):
         try:
             if self._h is not None:
+                self.release_direct()
                 self.lib.sc_fourstep_free(self._h)
         except Exception:      # noqa: BLE001
             pass
@@ -193,7 +261,7 @@ def destroy_native_comm():
 
 class ShardedNtt:
     def __init__(self, log2n, root, rank, world, device, engine=None, group=None, always_exchange=False, overlap_chunks=1, native_exchange=False,
-                 defer_last_pass=True):
+                 defer_last_pass=True, direct_store=False, log_n1=None):
         assert world & (world - 1) == 0, "world size must be a power of two"
         self.log2n, self.n = log2n, 1 << log2n
         self.root = int(root)
@@ -212,7 +280,8 @@ class ShardedNtt:
         # n = n1 * n2.  Small domains: square split.  Large ones: n1 = 2^8, so that the column stage of forward() is ONE
         # pass (256-point transforms) and the row stage two, and the other way round for inverse(): 3 passes per
         # transform instead of 4 (measured per-rank compute at 2^21 local elements: 138 us -> see profiles/).
-        self.n1 = 1 << ((log2n + 1) // 2 if log2n <= 16 else 8)
+        # log_n1 overrides the split (e.g. 12 at 2^24: the square split -- 8 x fewer, 16 x longer rows per rank and message)
+        self.n1 = 1 << (log_n1 if log_n1 else ((log2n + 1) // 2 if log2n <= 16 else 8))
         self.n2 = self.n // self.n1
         assert self.n2 >= world and self.n1 >= world, "domain too small to shard over this many ranks"
         self.root_inv = pow(self.root, self.n - 1, P)
@@ -226,7 +295,17 @@ class ShardedNtt:
         self.engine = engine
         # stage object: one library (or test-oracle) object per rank that owns roots, shapes and plans; engines without one
         # take the primitive-by-primitive path (_transform_primitives)
-        self.stages = engine.fourstep(log2n, self.root, rank, world) if hasattr(engine, "fourstep") else None
+        if log_n1 and hasattr(engine, "fourstep"):
+            self.stages = engine.fourstep(log2n, self.root, rank, world, log_n1)
+        else:
+            assert not log_n1 or not hasattr(engine, "fourstep")
+            self.stages = engine.fourstep(log2n, self.root, rank, world) if hasattr(engine, "fourstep") else None
+        # the corner turn as the column stage's own stores into the peers' receive buffers (HIP IPC; no collective): set up
+        # collectively here, used by _transform when it came up on every rank
+        self.direct_store = False
+        if direct_store:
+            assert self.stages is not None and hasattr(self.stages, "setup_direct"), "the direct-store corner turn needs the HIP stage object"
+            self.direct_store = self.stages.setup_direct(device, group)
         self._bufs = {}
         self._a2a_single = True
         self.bytes_exchanged = 0                   # bytes this rank has sent through the corner turn so far
@@ -266,14 +345,17 @@ class ShardedNtt:
             return self._transform_primitives(src, dst, R, C, self.root_inv if inverse else self.root, self.n_inv if inverse else 1)
         st, G, K = self.stages, self.world, self.overlap_chunks
         rw, cw = R // G, C // G
-        send = self._buf("send", (G * rw * cw, 2)).view(G, rw, cw, 2)
-        recv = self._buf("recv", (G * rw * cw, 2)).view(G, rw, cw, 2)
         inv = 1 if inverse else 0
         exchange = G > 1 or self.always_exchange
+        if exchange:
+            self.bytes_exchanged += G * rw * cw * 16 * (G - 1) // G
+        if self.direct_store:
+            st.run_direct(inv, src, dst)                        # column stage stores into the peers' buffers, flag barrier, row stage
+            return
+        send = self._buf("send", (G * rw * cw, 2)).view(G, rw, cw, 2)
+        recv = self._buf("recv", (G * rw * cw, 2)).view(G, rw, cw, 2)
         if K > 1 and (rw % K or (rw // K) & (rw // K - 1)):
             K = 1
-        if exchange:
-            self.bytes_exchanged += send.numel() * 8 * (G - 1) // G
         if not exchange:
             st.cols(inv, src, send, recv)                      # world of one rank: the whole output is the rank's own block
             st.rows(inv, recv, dst, 0, 1, False)

@@ -52,6 +52,15 @@ SIGNATURES = {
     "sc_ntt_batch_ex_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _u64, _int, _u64, _vp]),
     "sc_ntt_rows_t_ld_dev": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _vp]),
     "sc_fourstep_create": (_int, [_int, _vp, _int, _int, ctypes.POINTER(_vp)]),
+    "sc_fourstep_create_ex": (_int, [_int, _vp, _int, _int, _int, ctypes.POINTER(_vp)]),
+    "sc_ipc_region_create": (_int, [_u64, ctypes.POINTER(_vp), _vp]),
+    "sc_ipc_region_open": (_int, [_vp, ctypes.POINTER(_vp)]),
+    "sc_ipc_region_close": (_int, [_vp]),
+    "sc_ipc_region_free": (_int, [_vp]),
+    "sc_fourstep_region_bytes": (_int, [_vp, ctypes.POINTER(_u64)]),
+    "sc_fourstep_set_peers": (_int, [_vp, _vp]),
+    "sc_fourstep_run_direct_dev": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "sc_fourstep_direct_status": (_int, [_vp, ctypes.POINTER(_u64)]),
     "sc_fourstep_free": (_int, [_vp]),
     "sc_fourstep_shape": (_int, [_vp, _int, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
     "sc_fourstep_cols_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),

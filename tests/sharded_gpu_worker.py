@@ -35,8 +35,18 @@ def main():
         want = po.C.ntt(root, full_in, n)
         # the forms of the corner turn: the rank's own block written in place (default) or through the exchange; one blocking
         # exchange or row blocks, with the second pass of the row stage deferred or not -- always the same transform
-        for kw in (dict(), dict(overlap_chunks=4), dict(overlap_chunks=2, defer_last_pass=False), dict(always_exchange=True), dict(always_exchange=True, overlap_chunks=2)):
+        forms = [dict(), dict(overlap_chunks=4), dict(overlap_chunks=2, defer_last_pass=False), dict(always_exchange=True), dict(always_exchange=True, overlap_chunks=2),
+                 # the direct-store corner turn: the column stage stores block h into rank h's receive buffer (mapped through HIP
+                 # IPC -- here between processes on ONE device), a flag barrier instead of a collective
+                 dict(direct_store=True)]
+        if log2n == 20:
+            forms += [dict(log_n1=10), dict(direct_store=True, log_n1=10)]          # another split of the same transform
+        for kw in forms:
             eng = ShardedNtt(log2n, root, rank, world, dev, **kw)
+            if kw.get("direct_store") and not eng.direct_store:
+                print("rank", rank, "the direct-store corner turn did not come up", flush=True)
+                ok = False
+                break
             x = eng.synthetic_input(seed=3)
             y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
             z = torch.empty_like(x)
@@ -46,6 +56,18 @@ def main():
             got = gather_natural(y.cpu(), eng.n2, eng.n1, world).numpy().tobytes()
             ok &= got == want
             ok &= torch.equal(z, x)
+            if kw.get("direct_store"):
+                # several transforms back to back without waiting in between: the two receive buffers alternate, a rank that runs
+                # ahead must not overwrite what a slower rank's row stage still reads
+                for _ in range(5):
+                    eng.forward(x, y)
+                    eng.inverse(y, z)
+                eng.forward(z, y)
+                torch.cuda.synchronize()
+                ok &= gather_natural(y.cpu(), eng.n2, eng.n1, world).numpy().tobytes() == want and torch.equal(z, x)
+                ok &= eng.stages.direct_timed_out() == 0
+                dist.barrier()
+                eng.stages.release_direct()
             if not ok:
                 print("rank", rank, "MISMATCH at log2n", log2n, kw, flush=True)
                 break

@@ -325,6 +325,22 @@ def test_bench_two_ranks_print_the_north_star_record(sc):
     assert 0 < rec["frac"] < 1 and rec["elements_per_s"] > 0 and rec["bytes_sent_per_rank_per_pair"] == 2 * (1 << 23) * 16 // 2
     assert abs(rec["elements_per_s"] - out["value"]) < 1e-6 * out["value"]
     assert rec["corner_turn"] == out["config"]["corner_turn"]
+    # the first multi-GPU run explains itself -- per-stage times (max over ranks), bytes per peer, the probes of every
+    # form of the corner turn (the direct-store form among them), the split, RCCL version and peer-access matrix, and the OTHER
+    # member of strong / weak in the same run
+    for direction in ("forward", "inverse"):
+        st = out["roofline"]["stages_us"][direction]
+        assert st["cols_us"] > 0 and st["rows_us"] > 0 and st["whole_us"] > 0 and "exchange_and_waiting_us" in st
+    assert out["roofline"]["stages_us"]["bytes_to_each_peer_per_transform"] == (1 << 24) // 4 * 16
+    probes = out["config"]["corner_turn_probes"]
+    assert probes["chosen"] in out["config"]["corner_turn"] and any("direct store" in p["form"] for p in probes["probes"])
+    direct = [p for p in probes["probes"] if p["form"].startswith("direct store: ")][0]
+    assert direct["available"] is True and direct["correct"] is True and direct["ms_per_pair"] > 0
+    node = out["config"]["node"]
+    assert "rccl_version" in node and node["visible_gpus"] >= 1 and len(node["can_access_peer"]) == node["visible_gpus"]
+    assert "n1 = 2^" in out["config"]["split"]
+    other = out["extras"]["ntt_other_scaling"]
+    assert other["log2n"] == 22 and other["roundtrip_bit_exact"] is True and "weak" in other["scaling"] and other["stages_us"]["forward"]["cols_us"] > 0
     # the weak series is still there on request
     weak = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--scaling", "weak"])
     assert weak["scaling"] == "weak" and weak["config"]["log2n"] == 22 and "ntt_2p24_strong" not in weak.get("extras", {})
