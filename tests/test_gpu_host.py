@@ -289,6 +289,58 @@ def test_fri_commit_in_library_and_in_python_agree(monkeypatch):
         assert fr.verify(ps5, []) is True
 
 
+def test_fri_commit_with_a_proof_stream_subclass_and_a_long_transcript(monkeypatch):
+    """(1) a ProofStream SUBCLASS that derives its challenges differently (the reference's SignatureProofStream prefixes
+    the document, code/rpsss.py) must never take the library's commit loop, which hashes pickle(objects) itself -- prover and
+    verifier then disagree on every alpha and the proof is rejected without an error; (2) a transcript of many short digests that
+    passes a byte-count test but not the library's (3 bytes of pickle opcodes per item) must fall back to the Python loop instead
+    of raising."""
+    from hashlib import shake_256
+    calls = []
+    real = Fri._commit_in_library
+    monkeypatch.setattr(Fri, "_commit_in_library", lambda self, *a: (calls.append(1), real(self, *a))[1])
+
+    class PrefixedProofStream(ProofStream):
+        def __init__(self, document):
+            ProofStream.__init__(self)
+            self.prefix = shake_256(document).digest(32)
+
+        def prover_fiat_shamir(self, num_bytes=32):
+            return shake_256(self.prefix + self.serialize()).digest(num_bytes)
+
+        def verifier_fiat_shamir(self, num_bytes=32):
+            import pickle
+            return shake_256(self.prefix + pickle.dumps(self.objects[:self.read_index])).digest(num_bytes)
+
+    N = 1 << 10
+    om = field.primitive_nth_root(N)
+    poly = Polynomial([FieldElement(v, field) for v in synth.synth_ints(77, N // 4)])
+    fr = Fri(field.generator(), om, N, 4, 10)
+    cw = fast_coset_evaluate_device(poly, field.generator(), om, N)
+    ps = PrefixedProofStream(b"a document")
+    fr.prove(cw, ps)
+    assert not calls                                                  # the subclass went through proof_stream.prover_fiat_shamir()
+    assert fr.verify(ps, []) is True
+    wrong = PrefixedProofStream(b"another document")
+    wrong.objects = ps.objects
+    assert fr.verify(wrong, []) is False                              # the prefix really is part of every challenge
+    # a plain stream still takes the library loop
+    plain = ProofStream()
+    fr.prove(fast_coset_evaluate_device(poly, field.generator(), om, N), plain)
+    assert calls and fr.verify(plain, []) is True
+    # 990 distinct one-byte "digests": few bytes, many items
+    n_calls = len(calls)
+    prior = [bytes([i % 256, i // 256]) for i in range(990)]
+    long_stream = ProofStream()
+    for o in prior:
+        long_stream.push(o)
+    fr.prove(fast_coset_evaluate_device(poly, field.generator(), om, N), long_stream)      # no exception: Python loop (or the library, if it takes it)
+    for _ in prior:
+        long_stream.pull()
+    assert fr.verify(long_stream, []) is True
+    del n_calls
+
+
 def test_merkle_through_host_api():
     g = load_golden("merkle.json")
     for rec in g["commit"]:

@@ -48,6 +48,7 @@ def run(log2n, steps):
                   ("native_own_block_through_rccl_2_blocks", dict(always_exchange=True, native_exchange=True, overlap_chunks=2)),
                   ("native_own_block_through_rccl_4_blocks", dict(always_exchange=True, native_exchange=True, overlap_chunks=4)),
                   ("native_own_block_through_rccl_4_blocks_not_deferred", dict(always_exchange=True, native_exchange=True, overlap_chunks=4, defer_last_pass=False))]
+    forms.append(("direct_store_no_collective", dict(direct_store=True)))
     only = os.environ.get("TIMELINE_FORMS")
     for name, kw in forms:
         if only and name not in only.split(","):
