@@ -276,6 +276,11 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
  * SHAKE-256 (FIPS 202); Field.sample = big-endian integer of the bytes mod p; pickle.dumps of a list of `count` byte strings
  * (*out_len = bytes needed, copied into out when out_cap suffices) */
 int sc_shake256(const void* in, uint64_t len, void* out, uint64_t out_len);
+/* ProofStream.serialize() (code/ip.py:18-19: pickle.dumps(self.objects), protocol 4) of a proof stream given as a DESCRIPTION of
+ * its object graph instead of Python objects -- lists, bytes, authentication paths, triples, FieldElements with their object
+ * identities (format: csrc/proof_pickle.h).  Byte-identical to CPython's pickler.  moduli: nfields little-endian moduli of
+ * modulus_bytes each.  *out_len = bytes needed; copied into out when out_cap suffices.  Host only (no GPU needed). */
+int sc_pickle_proof(const void* ops, uint64_t ops_len, const void* moduli, uint32_t nfields, uint32_t modulus_bytes, void* out, uint64_t out_cap, uint64_t* out_len);
 /* Field.sample (algebra.py:116-120) of `count` host byte strings of `width` <= 32 bytes each, straight into device memory: the
  * randomizer polynomial of FastStark.prove (fast_stark.py:117: one os.urandom(17) draw per coefficient) without a Python object
  * per coefficient.  Synchronous (the bytes are the caller's host memory). */

@@ -1,0 +1,235 @@
+// proof_pickle.h -- ProofStream.serialize() / prover_fiat_shamir() without a Python object per digest.
+//
+// Reference: code/ip.py:18-25  serialize() = pickle.dumps(self.objects);  prover_fiat_shamir() = shake_256(serialize()).digest(32).
+// A proof of FastStark.prove at a 2^24 FRI domain is ~3 MB: ~50 000 64-byte digests in ~2 800 authentication paths, ~3 000
+// field elements.  Creating those objects and pickling them is 4-5 ms of CPython per proof, a seventh of the whole prover.
+// The bytes are part of the protocol (the verifier unpickles them; the Fiat-Shamir challenges hash them), so they are produced
+// HERE exactly as CPython's C pickler (Modules/_pickle.c, protocol 4, the default of 3.8+) produces them for the object graph a
+// proof stream holds -- from a compact description of that graph (the "ops" below), not from objects:
+//
+//   list (top level and nested)      ]  MEMOIZE  [ item APPEND | ( MARK items... APPENDS, in batches of 1000 ) ]
+//   bytes, fresh object              SHORT_BINBYTES / BINBYTES  MEMOIZE
+//   tuple of three                   items  TUPLE3  MEMOIZE
+//   algebra.FieldElement, first use  global (module and name strings memoized, STACK_GLOBAL, MEMOIZE)  )  NEWOBJ  MEMOIZE
+//                                    }  MEMOIZE  (  'value' int  'field' <Field object>  SETITEMS  BUILD
+//     the same OBJECT again          BINGET / LONG_BINGET of its memo index -- identity is part of the description (`key`)
+//   algebra.Field, first use         global  )  NEWOBJ  MEMOIZE  }  MEMOIZE  'p' int  SETITEM  BUILD
+//   int                              BININT1 / BININT2 / BININT (fits 31 bits + sign)  |  LONG1 with (bit_length >> 3) + 1 bytes
+//   framing                          at the start of every save() call: a frame of >= 64 KiB is closed and a new one begun
+//
+// tests/test_host_cpu.py compares the output with pickle.dumps byte for byte on random object graphs (shared and fresh
+// elements, several fields, lists of every batch size, streams across many frames) and on the reference's golden proofs.
+//
+// ops (little-endian), one item after the other; the top level must be ONE list:
+//   'L' u32 count            a list of the `count` items that follow
+//   'B' u32 len  bytes       a bytes object
+//   'D' u32 depth  64*depth  a list of `depth` bytes objects of 64 bytes each (an authentication path, merkle.py:16-27)
+//   'T'                      a tuple of the 3 items that follow
+//   'E' u32 field  u64 key  16 bytes   a FieldElement: `key` names the OBJECT (equal keys = the same object, pickled once and
+//                            referred to afterwards), value = two u64 limbs; `field` indexes the table of field moduli
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <unordered_map>
+#include <vector>
+
+namespace sc {
+
+struct ProofPickler {
+    std::vector<uint8_t> out;
+    size_t frame_start = 0;          // offset of the open frame's 9-byte header
+    uint32_t memo_next = 0;
+    int64_t m_algebra = -1, m_fe_name = -1, m_fe_class = -1, m_value = -1, m_field_key = -1, m_field_name = -1, m_field_class = -1, m_p = -1;
+    std::unordered_map<uint32_t, uint32_t> field_memo;     // field index -> memo index of the Field object
+    std::unordered_map<uint64_t, uint32_t> elem_memo;      // (field, key) -> memo index of the FieldElement object
+    const uint8_t* moduli = nullptr;                       // table of field moduli, `modulus_bytes` each, little-endian
+    uint32_t nfields = 0, modulus_bytes = 0;
+    bool bad = false;
+
+    static constexpr size_t FRAME_HEADER = 9, FRAME_TARGET = 64 * 1024, FRAME_MIN = 4;
+
+    void put(uint8_t b) { out.push_back(b); }
+    void put(const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; out.insert(out.end(), q, q + n); }
+    void put_u32(uint32_t v) { for (int i = 0; i < 4; ++i) out.push_back((uint8_t)(v >> (8 * i))); }
+
+    void begin() {
+        out.clear();
+        put(0x80); put(0x04);                              // PROTO 4
+        start_frame();
+    }
+    void start_frame() {
+        frame_start = out.size();
+        out.resize(out.size() + FRAME_HEADER);
+    }
+    void commit_frame() {
+        const size_t len = out.size() - frame_start - FRAME_HEADER;
+        if (len >= FRAME_MIN) {
+            out[frame_start] = 0x95;                       // FRAME
+            for (int i = 0; i < 8; ++i) out[frame_start + 1 + i] = (uint8_t)((uint64_t)len >> (8 * i));
+        } else {                                           // too short to be framed
+            memmove(out.data() + frame_start, out.data() + frame_start + FRAME_HEADER, len);
+            out.resize(out.size() - FRAME_HEADER);
+        }
+    }
+    // every save() of the pickler starts here
+    void boundary() {
+        if (out.size() - frame_start - FRAME_HEADER >= FRAME_TARGET) {
+            commit_frame();
+            start_frame();
+        }
+    }
+    uint32_t memoize() { put(0x94); return memo_next++; }
+    void get(uint32_t idx) {
+        if (idx < 256) { put(0x68); put((uint8_t)idx); }   // BINGET
+        else { put(0x6a); put_u32(idx); }                  // LONG_BINGET
+    }
+    // save(str): a string object that is the same object every time it appears (module / attribute names)
+    void save_name(int64_t& slot, const char* text) {
+        boundary();
+        if (slot >= 0) { get((uint32_t)slot); return; }
+        const size_t n = strlen(text);
+        put(0x8c); put((uint8_t)n); put(text, n);          // SHORT_BINUNICODE
+        slot = memoize();
+    }
+    void save_class(int64_t& slot, int64_t& name_slot, const char* name) {
+        boundary();
+        if (slot >= 0) { get((uint32_t)slot); return; }
+        save_name(m_algebra, "algebra");
+        save_name(name_slot, name);
+        put(0x93);                                         // STACK_GLOBAL
+        slot = memoize();
+    }
+    // save(int) of a non-negative integer given as little-endian bytes
+    void save_uint(const uint8_t* le, size_t n) {
+        boundary();
+        while (n && le[n - 1] == 0) --n;
+        size_t bits = n ? 8 * (n - 1) : 0;
+        if (n) { uint8_t top = le[n - 1]; while (top) { ++bits; top >>= 1; } }
+        if (bits <= 31) {
+            uint32_t v = 0;
+            for (size_t i = 0; i < n; ++i) v |= (uint32_t)le[i] << (8 * i);
+            if (v < 256) { put(0x4b); put((uint8_t)v); }                       // BININT1
+            else if (v < 65536) { put(0x4d); put((uint8_t)v); put((uint8_t)(v >> 8)); }   // BININT2
+            else { put(0x4a); put_u32(v); }                                    // BININT
+            return;
+        }
+        const size_t nbytes = (bits >> 3) + 1;             // always room for the sign bit
+        if (nbytes < 256) { put(0x8a); put((uint8_t)nbytes); }                 // LONG1
+        else { put(0x8b); put_u32((uint32_t)nbytes); }                         // LONG4
+        for (size_t i = 0; i < nbytes; ++i) put(i < n ? le[i] : (uint8_t)0);
+    }
+    void save_bytes(const uint8_t* data, size_t len) {
+        // always a FRESH object: whether two equal bytes objects are one object is the interpreter's business (b"" is a
+        // singleton, one-byte objects sometimes are) -- the describer hands a stream with repeated objects to pickle itself
+        boundary();
+        if (len < 256) { put(0x43); put((uint8_t)len); }                       // SHORT_BINBYTES
+        else { put(0x42); put_u32((uint32_t)len); }                            // BINBYTES
+        put(data, len);
+        memoize();
+    }
+    void save_field(uint32_t f) {
+        boundary();
+        auto it = field_memo.find(f);
+        if (it != field_memo.end()) { get(it->second); return; }
+        save_class(m_field_class, m_field_name, "Field");
+        boundary(); put(0x29);                             // save(()) : EMPTY_TUPLE
+        put(0x81);                                         // NEWOBJ
+        field_memo[f] = memoize();
+        boundary(); put(0x7d); memoize();                  // save(state): EMPTY_DICT MEMOIZE ... one item: SETITEM, no MARK
+        save_name(m_p, "p");
+        save_uint(moduli + (size_t)f * modulus_bytes, modulus_bytes);
+        put(0x73);                                         // SETITEM
+        put(0x62);                                         // BUILD
+    }
+    void save_element(uint32_t f, uint64_t key, const uint8_t value[16]) {
+        boundary();
+        const uint64_t id = ((uint64_t)f << 56) ^ key;
+        auto it = elem_memo.find(id);
+        if (it != elem_memo.end()) { get(it->second); return; }
+        save_class(m_fe_class, m_fe_name, "FieldElement");
+        boundary(); put(0x29);                             // EMPTY_TUPLE
+        put(0x81);                                         // NEWOBJ
+        elem_memo[id] = memoize();
+        boundary(); put(0x7d); memoize();                  // EMPTY_DICT MEMOIZE
+        put(0x28);                                         // MARK (two items)
+        save_name(m_value, "value");
+        save_uint(value, 16);
+        save_name(m_field_key, "field");
+        save_field(f);
+        put(0x75);                                         // SETITEMS
+        put(0x62);                                         // BUILD
+    }
+
+    // one item of the description at p; returns the position behind it (nullptr: malformed)
+    const uint8_t* item(const uint8_t* p, const uint8_t* end) {
+        if (p >= end) return nullptr;
+        const uint8_t op = *p++;
+        auto u32 = [&](uint32_t* v) { if (end - p < 4) return false; memcpy(v, p, 4); p += 4; return true; };
+        switch (op) {
+            case 'B': {
+                uint32_t len;
+                if (!u32(&len) || (size_t)(end - p) < len) return nullptr;
+                save_bytes(p, len);
+                return p + len;
+            }
+            case 'D': {
+                uint32_t depth;
+                if (!u32(&depth) || (size_t)(end - p) < (size_t)depth * 64) return nullptr;
+                boundary(); put(0x5d); memoize();          // EMPTY_LIST MEMOIZE
+                list_items(depth, [&](uint32_t i) { save_bytes(p + (size_t)i * 64, 64); return true; });
+                return p + (size_t)depth * 64;
+            }
+            case 'L': {
+                uint32_t count;
+                if (!u32(&count)) return nullptr;
+                boundary(); put(0x5d); memoize();
+                bool ok = true;
+                list_items(count, [&](uint32_t) { p = item(p, end); ok = ok && p != nullptr; return ok; });
+                return ok ? p : nullptr;
+            }
+            case 'T': {
+                boundary();
+                for (int i = 0; i < 3; ++i) { p = item(p, end); if (!p) return nullptr; }
+                put(0x87); memoize();                      // TUPLE3 MEMOIZE
+                return p;
+            }
+            case 'E': {
+                uint32_t f;
+                if (!u32(&f) || f >= nfields || end - p < 24) return nullptr;
+                uint64_t key;
+                memcpy(&key, p, 8);
+                save_element(f, key, p + 8);
+                return p + 24;
+            }
+            default: return nullptr;
+        }
+    }
+    // batch_list_exact of _pickle.c: one item -> item APPEND; else batches of 1000 between MARK and APPENDS
+    template <class F> void list_items(uint32_t count, F save_one) {
+        if (count == 0) return;
+        if (count == 1) { if (save_one(0)) put(0x61); return; }
+        uint32_t done = 0;
+        while (done < count) {
+            put(0x28);
+            uint32_t batch = 0;
+            while (done < count) {
+                if (!save_one(done)) return;
+                ++done;
+                if (++batch == 1000) break;
+            }
+            put(0x65);
+        }
+    }
+    bool run(const uint8_t* ops, size_t len) {
+        begin();
+        const uint8_t* end = ops + len;
+        if (!len || (ops[0] != 'L' && ops[0] != 'D')) return false;
+        const uint8_t* p = item(ops, end);
+        if (p != end) return false;
+        put(0x2e);                                         // STOP
+        commit_frame();
+        return true;
+    }
+};
+
+}  // namespace sc

@@ -23,6 +23,7 @@
 #include "geoseq.cuh"
 #include "ntt_plan.h"
 #include "transcript.h"
+#include "proof_pickle.h"
 
 using namespace sc;
 
@@ -2774,6 +2775,21 @@ int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, 
     if (!transcript_bytes(items, (size_t)count, bytes)) return fail(SC_ERR_UNSUPPORTED, "transcript too large for the fixed layout");
     *out_len = bytes.size();
     if (out && out_cap >= bytes.size()) memcpy(out, bytes.data(), bytes.size());
+    return SC_OK;
+}
+
+// pickle.dumps of the object graph a proof stream holds, from its description (csrc/proof_pickle.h); host only.
+// *out_len = bytes needed; they are copied into `out` when out_cap suffices.
+int sc_pickle_proof(const void* ops, uint64_t ops_len, const void* moduli, uint32_t nfields, uint32_t modulus_bytes, void* out, uint64_t out_cap, uint64_t* out_len) {
+    if (!ops || !out_len || (nfields && !moduli)) return fail(SC_ERR_BAD_ARG, "null argument");
+    ProofPickler pk;
+    pk.moduli = (const uint8_t*)moduli;
+    pk.nfields = nfields;
+    pk.modulus_bytes = modulus_bytes;
+    pk.out.reserve((size_t)ops_len + (size_t)ops_len / 8 + 4096);
+    if (!pk.run((const uint8_t*)ops, (size_t)ops_len)) return fail(SC_ERR_BAD_ARG, "malformed proof description");
+    *out_len = pk.out.size();
+    if (out && out_cap >= pk.out.size()) memcpy(out, pk.out.data(), pk.out.size());
     return SC_OK;
 }
 

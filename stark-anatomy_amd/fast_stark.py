@@ -16,6 +16,7 @@ from multivariate import *
 from ntt import *
 from ntt import _View
 import starkcore as _sc
+import proof_objects as _po
 
 
 def draw_random_bytes(count, width=17):
@@ -318,7 +319,12 @@ class FastStark:
         quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
         quadrupled_indices.sort()
         committed = boundary_quotient_codewords + [randomizer_codeword, transition_zerofier_codeword]
-        if all(isinstance(codeword, DeviceCodeword) for codeword in committed):
+        lazy = _po.lazy_objects(proof_stream) if all(_po.eligible(codeword) for codeword in committed) else None
+        if lazy is not None:
+            # the device's answers as they are (proof_objects.Openings): same transcript bytes, no object per digest
+            for codeword, (values, paths) in zip(committed, _sc.query_codewords_raw(committed, [quadrupled_indices] * len(committed))):
+                lazy.add(_po.Openings(codeword, quadrupled_indices, values, paths))
+        elif all(isinstance(codeword, DeviceCodeword) for codeword in committed):
             # every codeword's openings in ONE device round trip; pushed leaf, path, leaf, path, ... codeword by codeword
             for entries, paths in query_codewords(committed, [quadrupled_indices] * len(committed)):
                 self._push_openings(entries, paths, proof_stream)

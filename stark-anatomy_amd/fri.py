@@ -15,6 +15,7 @@ from ip import *
 from ntt import *
 from univariate import *
 import starkcore as _sc
+import proof_objects as _po
 from starkcore import DeviceCodeword, DeviceVector, query_codewords
 
 
@@ -95,8 +96,13 @@ class Fri:
             codewords = self._commit_in_library(codeword, proof_stream, rounds)
         if codewords is None:
             codewords = self._commit_rounds(codeword, proof_stream, rounds)
-        # the last codeword goes out in the clear, as a plain list (it is pickled into the transcript)
-        proof_stream.push(codewords[-1].tolist())
+        # the last codeword goes out in the clear, as a plain list (it is pickled into the transcript) -- described, not built,
+        # when the stream can hold it that way (proof_objects: the transcript bytes are the same)
+        lazy = _po.lazy_objects(proof_stream) if _po.eligible(codewords[-1]) else None
+        if lazy is not None:
+            lazy.add(_po.ElementList(codewords[-1], codewords[-1].vec.to_bytes()))
+        else:
+            proof_stream.push(codewords[-1].tolist())
         return codewords
 
     def _commit_in_library(self, codeword, proof_stream, rounds):
@@ -188,6 +194,21 @@ class Fri:
             if j > 0:
                 request += per_round[j - 1][:s]
             requests.append(request)
+        lazy = _po.lazy_objects(proof_stream) if all(_po.eligible(cw) for cw in codewords) else None
+        if lazy is not None:
+            # the device's answers go into the stream as they are: residues and paths stay packed, the transcript is pickled from
+            # their description (proof_objects.FriRound); the reference's objects exist only if somebody reads them
+            fetched = _sc.query_codewords_raw(codewords, requests)
+            for i in range(rounds):
+                values, paths = fetched[i]
+                next_values, next_paths = fetched[i + 1]
+                c_at = 2 * s if i + 1 < rounds else 0
+                a = per_round[i][:s]
+                half = len(codewords[i]) // 2
+                lazy.add(_po.FriRound(codewords[i], codewords[i + 1], a, [index + half for index in a], a,
+                                      values[:16 * s], values[16 * s:32 * s], next_values[16 * c_at:16 * (c_at + s)],
+                                      paths[:s], paths[s:2 * s], next_paths[c_at:c_at + s]))
+            return
         if all(isinstance(cw, DeviceCodeword) for cw in codewords):
             fetched = query_codewords(codewords, requests)          # every round's openings in one device round trip
         else:

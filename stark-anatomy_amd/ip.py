@@ -8,9 +8,16 @@ import pickle
 from hashlib import shake_256
 
 
+def _pickled(objects):
+    """pickle.dumps(objects) -- of the plain list the reference keeps, or of the prover's lazily described objects
+    (proof_objects.LazyProofObjects: the same bytes without a Python object per digest)"""
+    pickled = getattr(objects, "pickled", None)
+    return pickled() if pickled is not None else pickle.dumps(objects)
+
+
 def _challenge(objects, num_bytes):
     """SHAKE-256 of the pickled transcript prefix (default pickle protocol: the bytes are part of the protocol)."""
-    return shake_256(pickle.dumps(objects)).digest(num_bytes)
+    return shake_256(_pickled(objects)).digest(num_bytes)
 
 
 class ProofStream:
@@ -25,7 +32,7 @@ class ProofStream:
         self.objects.append(obj)
 
     def serialize(self):
-        return pickle.dumps(self.objects)
+        return _pickled(self.objects)
 
     def prover_fiat_shamir(self, num_bytes=32):
         # the prover hashes everything sent so far

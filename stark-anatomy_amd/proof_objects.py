@@ -1,0 +1,278 @@
+"""What a proof stream holds, without a Python object per digest.
+
+Reference: code/ip.py:4-30 -- `ProofStream.objects` is a plain list; `serialize()` is `pickle.dumps(objects)` and every Fiat-Shamir
+challenge hashes those bytes.  A proof of FastStark.prove at a 2^24 FRI domain is ~50 000 digest objects in ~2 800 authentication
+paths plus ~3 000 field elements: creating and pickling them costs 4-5 ms of CPython per proof, a seventh of the prover, although
+nothing on the prover's side ever looks at them.  The prover therefore pushes what the device answered -- index lists, packed
+residues, packed paths -- as SEGMENTS of a `LazyProofObjects`, which
+
+  * pickles itself from a description of the object graph (csrc/proof_pickle.h, `sc_pickle_proof`): byte-identical to
+    `pickle.dumps` of the materialised list, including which FieldElement OBJECTS are shared (pickle memoises by identity; the
+    reference pushes the same object when a codeword entry appears twice: last codeword <-> query triple, the `c` of one FRI round
+    <-> the `a`/`b` of the next, code/fri.py:91, :104-105);
+  * turns into the reference's objects the moment anything indexes, iterates or compares it (a verifier running on the prover's
+    stream, a test looking at `objects[0]`), through the same identity-preserving caches the object path uses.
+
+Anything it cannot describe (an object of another type pushed by the caller) makes it fall back to materialise + `pickle.dumps`.
+"""
+import pickle
+
+import numpy as np
+
+import starkcore as _sc
+
+_E = np.dtype([("op", "u1"), ("f", "<u4"), ("key", "<u8"), ("v", "u1", (16,))])          # 'E' field key value: 29 bytes, packed
+assert _E.itemsize == 29
+
+
+class _Unsupported(Exception):
+    pass
+
+
+def _path_dtype(depth):
+    return np.dtype([("op", "u1"), ("depth", "<u4"), ("raw", "u1", (64 * depth,))])
+
+
+class _Context:
+    """per serialization: the table of Field objects (by identity) the elements refer to"""
+
+    def __init__(self):
+        self.fields = []
+        self.seen = set()                                  # ids of the real objects described so far
+
+    def field_index(self, field):
+        for i, f in enumerate(self.fields):
+            if f is field:
+                return i
+        self.fields.append(field)
+        return len(self.fields) - 1
+
+
+def _codeword_uid(cw):
+    uid = getattr(cw, "_uid", None)
+    if uid is None:
+        _codeword_uid.counter += 1
+        uid = cw._uid = _codeword_uid.counter
+    return uid
+
+
+_codeword_uid.counter = 0
+
+
+def _element_ops(ctx, cw, indices, values):
+    """the 'E' records of entries `indices` of device codeword `cw` (values: packed residues, 16 bytes each)"""
+    k = len(indices)
+    rec = np.empty(k, dtype=_E)
+    rec["op"] = ord("E")
+    rec["f"] = ctx.field_index(cw.field)
+    rec["key"] = (np.uint64(_codeword_uid(cw)) << np.uint64(32)) | np.asarray(indices, dtype=np.uint64)
+    rec["v"] = np.frombuffer(values, dtype=np.uint8).reshape(k, 16)
+    return rec
+
+
+def _path_ops(paths, depth):
+    """the 'D' records of `paths` (uint8 array [k][64 * depth])"""
+    rec = np.empty(paths.shape[0], dtype=_path_dtype(depth))
+    rec["op"] = ord("D")
+    rec["depth"] = depth
+    if depth:
+        rec["raw"] = paths
+    return rec
+
+
+def eligible(codeword):
+    """a codeword whose entries have no Python objects yet other than the ones its own cache hands out"""
+    return isinstance(codeword, _sc.DeviceCodeword) and codeword._full is None
+
+
+class ElementList:
+    """ONE object: the list of all entries of a device codeword (the last FRI codeword, pushed in the clear: fri.py:91)"""
+    count = 1
+
+    def __init__(self, codeword, values):
+        self.cw, self.values = codeword, values
+
+    def ops(self, ctx):
+        n = len(self.values) // 16
+        return b"L" + int(n).to_bytes(4, "little") + _element_ops(ctx, self.cw, range(n), self.values).tobytes()
+
+    def materialize(self):
+        n = len(self.values) // 16
+        return [self.cw._entries(range(n), _sc.unpack(self.values, n))]
+
+
+class FriRound:
+    """one round of the query phase (fri.py:98-113): s triples (current[a], current[b], next[c]), then per test the
+    authentication paths of a, b, c"""
+
+    def __init__(self, current, following, idx_a, idx_b, idx_c, val_a, val_b, val_c, paths_a, paths_b, paths_c):
+        self.cur, self.nxt = current, following
+        self.idx = (idx_a, idx_b, idx_c)
+        self.val = (val_a, val_b, val_c)
+        self.paths = (paths_a, paths_b, paths_c)
+        self.s = len(idx_a)
+        self.count = 4 * self.s
+
+    def ops(self, ctx):
+        s = self.s
+        if s == 0:
+            return b""
+        d_cur, d_nxt = self.paths[0].shape[1] // 64, self.paths[2].shape[1] // 64
+        triple = np.dtype([("t", "u1"), ("a", _E), ("b", _E), ("c", _E)])
+        t = np.empty(s, dtype=triple)
+        t["t"] = ord("T")
+        t["a"] = _element_ops(ctx, self.cur, self.idx[0], self.val[0])
+        t["b"] = _element_ops(ctx, self.cur, self.idx[1], self.val[1])
+        t["c"] = _element_ops(ctx, self.nxt, self.idx[2], self.val[2])
+        trio = np.dtype([("a", _path_dtype(d_cur)), ("b", _path_dtype(d_cur)), ("c", _path_dtype(d_nxt))])
+        p = np.empty(s, dtype=trio)
+        p["a"] = _path_ops(self.paths[0], d_cur)
+        p["b"] = _path_ops(self.paths[1], d_cur)
+        p["c"] = _path_ops(self.paths[2], d_nxt)
+        return t.tobytes() + p.tobytes()
+
+    def materialize(self):
+        s = self.s
+        ent = [holder._entries(list(idx), _sc.unpack(bytes(val), s)) for holder, idx, val in zip((self.cur, self.cur, self.nxt), self.idx, self.val)]
+        lists = [_sc._path_lists(memoryview(np.ascontiguousarray(p)).cast("B"), 0, p.shape[1] // 64, s) for p in self.paths]
+        return list(zip(*ent)) + [path for trio in zip(*lists) for path in trio]
+
+
+class Openings:
+    """leaf, path, leaf, path, ... of one committed codeword (fast_stark.py:154-175)"""
+
+    def __init__(self, codeword, indices, values, paths):
+        self.cw, self.indices, self.values, self.paths = codeword, indices, values, paths
+        self.count = 2 * len(indices)
+
+    def ops(self, ctx):
+        k = len(self.indices)
+        if k == 0:
+            return b""
+        depth = self.paths.shape[1] // 64
+        pair = np.dtype([("e", _E), ("p", _path_dtype(depth))])
+        rec = np.empty(k, dtype=pair)
+        rec["e"] = _element_ops(ctx, self.cw, self.indices, self.values)
+        rec["p"] = _path_ops(self.paths, depth)
+        return rec.tobytes()
+
+    def materialize(self):
+        k = len(self.indices)
+        entries = self.cw._entries(list(self.indices), _sc.unpack(bytes(self.values), k))
+        paths = _sc._path_lists(memoryview(np.ascontiguousarray(self.paths)).cast("B"), 0, self.paths.shape[1] // 64, k)
+        return [x for pair in zip(entries, paths) for x in pair]
+
+
+class _Real:
+    """objects the caller pushed as objects"""
+
+    def __init__(self, objects):
+        self.objects = objects
+
+    @property
+    def count(self):
+        return len(self.objects)
+
+    def ops(self, ctx):
+        out, seen = [], ctx.seen
+        for o in self.objects:
+            if type(o) is bytes:
+                out.append(b"B" + len(o).to_bytes(4, "little") + o)
+                fresh = [o]
+            elif type(o) is list and all(type(x) is bytes and len(x) == 64 for x in o):
+                out.append(b"D" + len(o).to_bytes(4, "little") + b"".join(o))
+                fresh = o + [o]
+            else:
+                # a FieldElement object (or anything holding one) may be THE SAME object as one a lazy segment describes by
+                # (codeword, index): only the pickler walking real objects gets that right
+                raise _Unsupported(type(o).__name__)
+            for x in fresh:                                # the same object twice is a memo hit in pickle: not described here
+                if id(x) in seen:
+                    raise _Unsupported("the same object pushed twice")
+                seen.add(id(x))
+        return b"".join(out)
+
+    def materialize(self):
+        return self.objects
+
+
+class LazyProofObjects:
+    """`ProofStream.objects` once a prover has pushed device answers: a sequence that reads like the reference's list"""
+
+    def __init__(self, objects=()):
+        self._segments = [_Real(list(objects))]
+        self._cache = {}                                   # segment index -> its materialised objects
+        self._all = None
+
+    # -- the prover's side
+    def append(self, obj):
+        self._all = None
+        if not isinstance(self._segments[-1], _Real):
+            self._segments.append(_Real([]))
+        self._segments[-1].objects.append(obj)
+
+    def extend(self, objs):
+        for o in objs:
+            self.append(o)
+
+    def add(self, segment):
+        self._all = None
+        self._segments.append(segment)
+
+    def pickled(self):
+        """pickle.dumps(list(self)), without making the list"""
+        try:
+            ctx = _Context()
+            body = [seg.ops(ctx) for seg in self._segments]
+            ops = b"L" + len(self).to_bytes(4, "little") + b"".join(body)
+            moduli = b"".join(f.p.to_bytes(32, "little") for f in ctx.fields)
+        except (_Unsupported, OverflowError):
+            return pickle.dumps(self.materialized())
+        return _sc.pickle_proof(ops, moduli, len(ctx.fields), 32)
+
+    # -- the reader's side: the reference's objects, made once
+    def _segment_objects(self, k):
+        got = self._cache.get(k)
+        if got is None:
+            got = self._cache[k] = self._segments[k].materialize()
+        return got
+
+    def materialized(self):
+        if self._all is None:
+            out = []
+            for k, seg in enumerate(self._segments):
+                out.extend(seg.objects if isinstance(seg, _Real) else self._segment_objects(k))
+            self._all = out
+        return self._all
+
+    def __len__(self):
+        return sum(seg.count for seg in self._segments)
+
+    def __getitem__(self, i):
+        return self.materialized()[i]
+
+    def __iter__(self):
+        return iter(self.materialized())
+
+    def __eq__(self, other):
+        return self.materialized() == (other.materialized() if isinstance(other, LazyProofObjects) else other)
+
+    __hash__ = None
+
+    def __reduce__(self):
+        raise TypeError("a proof stream's objects pickle through ProofStream.serialize()")
+
+
+def lazy_objects(proof_stream):
+    """`proof_stream.objects` as a LazyProofObjects (swapped in on first use), or None when the stream is not a plain
+    ip.ProofStream holding a plain list (a subclass may serialize differently; the reference's SignatureProofStream does)"""
+    from ip import ProofStream
+    if type(proof_stream) is not ProofStream:
+        return None
+    objects = proof_stream.objects
+    if isinstance(objects, LazyProofObjects):
+        return objects
+    if type(objects) is not list:
+        return None
+    proof_stream.objects = LazyProofObjects(objects)
+    return proof_stream.objects

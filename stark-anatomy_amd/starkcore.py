@@ -93,6 +93,7 @@ SIGNATURES = {
     "sc_fri_fold_commit_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_fri_commit_dev": (_int, [_vp, _u64, _vp, _vp, ctypes.c_uint32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "sc_shake256": (_int, [_vp, _u64, _vp, _u64]),
+    "sc_pickle_proof": (_int, [_vp, _u64, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _u64, ctypes.POINTER(_u64)]),
     "sc_field_sample": (_int, [_vp, _u64, _vp]),
     "sc_transcript_bytes": (_int, [_vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_u64)]),
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
@@ -218,6 +219,18 @@ def library_stream():
 def stream_join(other):
     """order the library stream and the raw stream handle `other` with each other on the device; the host does not wait"""
     _check(lib().sc_stream_join(_vp(int(other))))
+
+
+def pickle_proof(ops, moduli, nfields, modulus_bytes):
+    """pickle.dumps of the object graph described by `ops` (csrc/proof_pickle.h; host only)"""
+    need = ctypes.c_uint64()
+    cap = len(ops) + len(ops) // 8 + 4096
+    out = ctypes.create_string_buffer(cap)
+    _check(lib().sc_pickle_proof(ops, len(ops), moduli, nfields, modulus_bytes, out, cap, ctypes.byref(need)))
+    if need.value > cap:
+        out = ctypes.create_string_buffer(need.value)
+        _check(lib().sc_pickle_proof(ops, len(ops), moduli, nfields, modulus_bytes, out, need.value, ctypes.byref(need)))
+    return out.raw[:need.value]
 
 
 def fe_bytes(v):
@@ -351,6 +364,35 @@ def query_codewords(codewords, requests):
     for cw, req, d in zip(codewords, requests, depths):
         k = len(req)
         out.append((cw._entries(req, values[vo:vo + k]), _path_lists(view, po, d, k)))
+        vo += k
+        po += 64 * k * d
+    return out
+
+
+def query_codewords_raw(codewords, requests):
+    """query_codewords without objects: [(packed residues (bytes, 16 per opening), paths as a uint8 array [openings][64 * depth])]
+    -- what proof_objects' segments keep until somebody asks for the objects"""
+    import numpy as np
+    n = len(codewords)
+    trees = [cw.tree() for cw in codewords]
+    try:
+        flat = array.array("Q", itertools.chain.from_iterable(requests))
+    except OverflowError:
+        raise AssertionError("cannot open invalid index")
+    total = len(flat)
+    if total == 0:
+        return [(b"", np.zeros((0, 64 * t.depth), dtype=np.uint8)) for t in trees]
+    depths = [t.depth for t in trees]
+    path_bytes = sum(64 * d * len(req) for d, req in zip(depths, requests))
+    elems = ctypes.create_string_buffer(16 * total)
+    paths = ctypes.create_string_buffer(path_bytes if path_bytes else 64)
+    _check(lib().sc_merkle_query_multi_dev(n, (_vp * n)(*[t._h for t in trees]), (_vp * n)(*[cw.vec.ptr for cw in codewords]),
+                                           (ctypes.c_uint64 * total).from_buffer(flat), (ctypes.c_uint64 * n)(*[len(req) for req in requests]), elems, paths))
+    raw_e, raw_p = elems.raw, np.frombuffer(paths, dtype=np.uint8)
+    out, vo, po = [], 0, 0
+    for req, d in zip(requests, depths):
+        k = len(req)
+        out.append((raw_e[16 * vo:16 * (vo + k)], raw_p[po:po + 64 * k * d].reshape(k, 64 * d)))
         vo += k
         po += 64 * k * d
     return out

@@ -1,0 +1,168 @@
+"""ProofStream.serialize() without Python objects (reference code/ip.py:18-25: pickle.dumps(self.objects)): the library's pickler
+(csrc/proof_pickle.h, sc_pickle_proof) and proof_objects.LazyProofObjects against CPython's own pickle.dumps, byte for byte.
+Host only: runs without a GPU."""
+import pickle
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import starkcore as sc
+import proof_objects as po_
+from algebra import Field, FieldElement
+from ip import ProofStream
+
+MAIN = Field.main()
+SMALL = Field(97)
+
+
+def describe(obj, keys, fields, rng):
+    """the ops of csrc/proof_pickle.h for a graph of lists / bytes / 3-tuples / FieldElements; object identity -> key"""
+    if type(obj) is bytes:
+        return b"B" + struct.pack("<I", len(obj)) + obj
+    if type(obj) is list:
+        if obj and all(type(o) is bytes and len(o) == 64 for o in obj) and rng.random() < 0.7:
+            return b"D" + struct.pack("<I", len(obj)) + b"".join(obj)
+        return b"L" + struct.pack("<I", len(obj)) + b"".join(describe(o, keys, fields, rng) for o in obj)
+    if type(obj) is tuple:
+        return b"T" + b"".join(describe(o, keys, fields, rng) for o in obj)
+    assert type(obj) is FieldElement
+    f = [id(x) for x in fields].index(id(obj.field))
+    return b"E" + struct.pack("<IQ", f, keys.setdefault(id(obj), len(keys))) + obj.value.to_bytes(16, "little")
+
+
+def library_pickle(obj, fields, rng):
+    return sc.pickle_proof(describe(obj, {}, fields, rng), b"".join(f.p.to_bytes(17, "little") for f in fields), len(fields), 17)
+
+
+def random_graph(rng, n):
+    fields = [MAIN] if rng.random() < 0.7 else [MAIN, SMALL]
+    pools = {id(f): [] for f in fields}
+
+    def element(field):
+        pool = pools[id(field)]
+        if pool and rng.random() < 0.4:
+            return rng.choice(pool)                      # the SAME object again: a memo hit in pickle
+        v = rng.choice([0, 1, 255, 256, 65535, 65536, 2 ** 31 - 1, 2 ** 31, 2 ** 32, 2 ** 64 - 1, 2 ** 64, 2 ** 120, MAIN.p - 1, rng.randrange(MAIN.p)]) % field.p
+        pool.append(FieldElement(v, field))
+        return pool[-1]
+    items = []
+    for _ in range(n):
+        k, field = rng.random(), rng.choice(fields)
+        if k < 0.3:
+            # (fresh objects: int.to_bytes never returns the interpreter's shared one-byte objects; b"" IS shared, so at most one)
+            size = rng.choice([0, 1, 2, 64, 64, 64, 255, 256, 300])
+            if size == 0 and any(type(o) is bytes and not o for o in items):
+                size = 1
+            items.append(rng.randbytes(size))
+        elif k < 0.6:
+            items.append([rng.randbytes(64) for _ in range(rng.choice([0, 1, 2, 12, 24]))])
+        elif k < 0.75:
+            items.append((element(field), element(field), element(field)))
+        elif k < 0.9:
+            items.append(element(field))
+        else:
+            items.append([element(field) for _ in range(rng.choice([0, 1, 2, 256, 1001]))])
+    return items, fields
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 10, 50, 999, 1000, 1001, 2000, 2001, 3500])
+def test_library_pickler_matches_cpython(n):
+    """lists of every batch size (APPEND / MARK ... APPENDS in thousands), fresh and shared FieldElements of two fields, every
+    integer opcode (BININT1/2, BININT, LONG1 of 5..17 bytes), short and long bytes, streams across many 64 KiB frames"""
+    rng = random.Random(100 + n)
+    for _ in range(4 if n > 100 else 40):
+        items, fields = random_graph(rng, n)
+        want = pickle.dumps(items)
+        got = library_pickle(items, fields, rng)
+        assert got == want, (n, len(got), len(want))
+        assert pickle.loads(got)[:3] == items[:3]
+
+
+def test_library_pickler_rejects_malformed_descriptions():
+    for ops in (b"", b"X", b"L\x02\x00\x00\x00B\x01\x00\x00\x00a", b"L\x01\x00\x00\x00E\x05\x00\x00\x00" + bytes(24), b"B\x01\x00\x00\x00a", b"L\x00\x00\x00\x00junk"):
+        with pytest.raises(sc.StarkCoreError):
+            sc.pickle_proof(ops, MAIN.p.to_bytes(17, "little"), 1, 17)
+
+
+class FakeCodeword:
+    """the part of starkcore.DeviceCodeword the segments use: a field, and entries created once per index"""
+    _full = None
+
+    def __init__(self, n, field, rng):
+        self.field, self.values = field, [rng.randrange(field.p) for _ in range(n)]
+        self._elems = {}
+
+    def __len__(self):
+        return len(self.values)
+
+    def raw(self, indices):
+        return b"".join(self.values[i].to_bytes(16, "little") for i in indices)
+
+    def _entries(self, indices, values):
+        for i, v in zip(indices, values):
+            assert v == self.values[i]
+            if i not in self._elems:
+                self._elems[i] = FieldElement(v, self.field)
+        return [self._elems[i] for i in indices]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lazy_proof_objects_pickle_like_the_objects_they_stand_for(seed):
+    """a stream shaped like FastStark.prove's: roots, the last FRI codeword, query rounds whose `c` entries are the next round's
+    `a` / `b` entries and finally the last codeword's own objects, openings of committed codewords with repeated indices"""
+    rng = random.Random(seed)
+    field = MAIN
+    s, rounds = rng.choice([2, 17, 40]), rng.choice([1, 3, 6])
+    sizes = [(64 if s > 20 else 16) << (rounds - r) for r in range(rounds + 1)]
+    cws = [FakeCodeword(n, field, rng) for n in sizes]
+    stream = ProofStream()
+    for _ in range(rng.choice([0, 3])):
+        stream.push(rng.randbytes(64))
+    for _ in range(rounds + 1):
+        stream.push(rng.randbytes(64))
+    lazy = po_.lazy_objects(stream)
+    assert lazy is stream.objects and po_.lazy_objects(stream) is lazy
+    last = cws[-1]
+    lazy.add(po_.ElementList(last, last.raw(range(len(last)))))
+    challenge_before_queries = stream.prover_fiat_shamir()
+    top = rng.sample(range(sizes[0] // 2), s)
+    idx = top
+    for r in range(rounds):
+        cur, nxt = cws[r], cws[r + 1]
+        half = len(cur) // 2
+        a = [i % half for i in idx]
+        b = [i + half for i in a]
+        depth_c, depth_n = len(cur).bit_length() - 1, len(nxt).bit_length() - 1
+        paths = [np.frombuffer(rng.randbytes(64 * d * s), dtype=np.uint8).reshape(s, 64 * d) for d in (depth_c, depth_c, depth_n)]
+        lazy.add(po_.FriRound(cur, nxt, a, b, a, cur.raw(a), cur.raw(b), nxt.raw(a), *paths))
+        idx = a
+    committed = [FakeCodeword(sizes[0], field, rng) for _ in range(3)] + [cws[0]]          # the last one also went through FRI
+    opened = sorted(top + [(i + 4) % sizes[0] for i in top] + [top[0]])                     # a repeated index
+    for cw in committed:
+        d = len(cw).bit_length() - 1
+        lazy.add(po_.Openings(cw, opened, cw.raw(opened), np.frombuffer(rng.randbytes(64 * d * len(opened)), dtype=np.uint8).reshape(len(opened), 64 * d)))
+    got = stream.serialize()
+    objects = list(stream.objects)
+    assert len(objects) == len(stream.objects)
+    assert got == pickle.dumps(objects)
+    assert stream.prover_fiat_shamir() != challenge_before_queries
+    # what a verifier reads back is the same graph
+    back = ProofStream().deserialize(got)
+    assert [type(o) for o in back.objects] == [type(o) for o in objects]
+    assert back.objects[len(objects) - 2].value == objects[-2].value and back.objects[-1] == objects[-1]
+    # an object the description does not cover: the stream falls back to the interpreter's pickler, same bytes
+    stream.push((objects[-2], 5))
+    assert stream.serialize() == pickle.dumps(list(stream.objects))
+    # a subclass keeps its plain list
+    class Other(ProofStream):
+        pass
+    assert po_.lazy_objects(Other()) is None
+
+
+def test_proof_stream_without_lazy_objects_is_the_reference_stream():
+    stream = ProofStream()
+    stream.push(b"root")
+    stream.push([FieldElement(5, MAIN)])
+    assert type(stream.objects) is list and stream.serialize() == pickle.dumps(stream.objects)
