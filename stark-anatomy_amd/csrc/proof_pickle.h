@@ -48,32 +48,47 @@ struct ProofPickler {
 
     static constexpr size_t FRAME_HEADER = 9, FRAME_TARGET = 64 * 1024, FRAME_MIN = 4;
 
-    void put(uint8_t b) { out.push_back(b); }
-    void put(const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; out.insert(out.end(), q, q + n); }
-    void put_u32(uint32_t v) { for (int i = 0; i < 4; ++i) out.push_back((uint8_t)(v >> (8 * i))); }
+    // the output grows in big steps and is written through a raw pointer: a digest is 67 bytes in four writes, and a proof has
+    // fifty thousand of them
+    // (straight into the caller's buffer while it is big enough; into `out` from the moment it is not)
+    uint8_t* base = nullptr;
+    size_t cap = 0, used = 0;
+    void use_buffer(uint8_t* p, size_t n) { base = p; cap = n; }
+    void room(size_t n) {
+        if (used + n <= cap) return;
+        std::vector<uint8_t> bigger((used + n) * 2 + 4096);
+        if (used) memcpy(bigger.data(), base, used);
+        out.swap(bigger);
+        base = out.data();
+        cap = out.size();
+    }
+    void put(uint8_t b) { room(1); base[used++] = b; }
+    void put(const void* p, size_t n) { room(n); memcpy(base + used, p, n); used += n; }
+    void put_u32(uint32_t v) { room(4); memcpy(base + used, &v, 4); used += 4; }
 
     void begin() {
-        out.clear();
+        used = 0;
         put(0x80); put(0x04);                              // PROTO 4
         start_frame();
     }
     void start_frame() {
-        frame_start = out.size();
-        out.resize(out.size() + FRAME_HEADER);
+        frame_start = used;
+        room(FRAME_HEADER);
+        used += FRAME_HEADER;
     }
     void commit_frame() {
-        const size_t len = out.size() - frame_start - FRAME_HEADER;
+        const size_t len = used - frame_start - FRAME_HEADER;
         if (len >= FRAME_MIN) {
-            out[frame_start] = 0x95;                       // FRAME
-            for (int i = 0; i < 8; ++i) out[frame_start + 1 + i] = (uint8_t)((uint64_t)len >> (8 * i));
+            base[frame_start] = 0x95;                      // FRAME
+            for (int i = 0; i < 8; ++i) base[frame_start + 1 + i] = (uint8_t)((uint64_t)len >> (8 * i));
         } else {                                           // too short to be framed
-            memmove(out.data() + frame_start, out.data() + frame_start + FRAME_HEADER, len);
-            out.resize(out.size() - FRAME_HEADER);
+            memmove(base + frame_start, base + frame_start + FRAME_HEADER, len);
+            used -= FRAME_HEADER;
         }
     }
     // every save() of the pickler starts here
     void boundary() {
-        if (out.size() - frame_start - FRAME_HEADER >= FRAME_TARGET) {
+        if (used - frame_start - FRAME_HEADER >= FRAME_TARGET) {
             commit_frame();
             start_frame();
         }

@@ -2786,10 +2786,10 @@ int sc_pickle_proof(const void* ops, uint64_t ops_len, const void* moduli, uint3
     pk.moduli = (const uint8_t*)moduli;
     pk.nfields = nfields;
     pk.modulus_bytes = modulus_bytes;
-    pk.out.reserve((size_t)ops_len + (size_t)ops_len / 8 + 4096);
+    if (out && out_cap) pk.use_buffer((uint8_t*)out, (size_t)out_cap);     // written in place when it fits
     if (!pk.run((const uint8_t*)ops, (size_t)ops_len)) return fail(SC_ERR_BAD_ARG, "malformed proof description");
-    *out_len = pk.out.size();
-    if (out && out_cap >= pk.out.size()) memcpy(out, pk.out.data(), pk.out.size());
+    *out_len = pk.used;
+    if (out && pk.base != (uint8_t*)out && out_cap >= pk.used) memcpy(out, pk.base, pk.used);
     return SC_OK;
 }
 

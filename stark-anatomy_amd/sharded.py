@@ -731,6 +731,27 @@ class HipFriEngine:
         return [((hi & m) << 64) | (lo & m) for lo, hi in got]
 
 
+class _LayerEntries:
+    """the entries of one committed layer as FieldElement objects, each made once (pickle memoises by identity: the `c` of one
+    round is the `a` / `b` of the next, code/fri.py:104-105) -- the object cache of a layer record behind the interface
+    proof_objects' segments use"""
+    _full = None
+
+    def __init__(self, layer, field):
+        self.layer, self.field = layer, field
+
+    def _entries(self, indices, values):
+        from algebra import FieldElement
+        cache, field, new = self.layer["cache"], self.field, object.__new__
+        for i, v in zip(indices, values):
+            if i not in cache:
+                e = new(FieldElement)
+                e.value = v
+                e.field = field
+                cache[i] = e
+        return [cache[i] for i in indices]
+
+
 class ShardedFri:
     """`Fri.prove` (reference code/fri.py:115-130) on a codeword that lives in the column-slab layout.
 
@@ -910,6 +931,66 @@ class ShardedFri:
             out.append((vals, self._joined_paths(bottoms, got[w[1] + 1][1] if layer["C"] * G > 1 else None)))     # below the sub-roots + above them
         return out
 
+    def _open_many_arrays(self, requests):
+        """[(packed residues (bytes), paths as a uint8 array [openings][64 * depth])] for a list of (layer, global indices): what
+        _open_many_raw gathers, with the two parts of every path joined as arrays and NO object made (proof_objects' segments)"""
+        import numpy as np
+        import starkcore as sc
+        eng = self.engine
+        R, Rw, G, g = self.R, self.Rw, self.world, self.rank
+        sub_level = Rw.bit_length() - 1
+        asks, where = [], []
+        for q, (layer, indices) in enumerate(requests):
+            if layer["kind"] == "local":
+                where.append(("local", len(asks)))
+                asks.append((layer["tree"], layer["vec"], list(indices)))
+                continue
+            mine = [i for i in indices if (i % R) // Rw == g] if G > 1 else indices
+            where.append(("sharded", len(asks)))
+            asks.append((layer["local"], layer["slab"], [(i // R) * Rw + (i % R) % Rw for i in mine], sub_level))
+            asks.append((layer["top"], None, [(i // R) * G + (i % R) // Rw for i in indices] if layer["C"] * G > 1 else []))
+        got = eng.query_many(asks, raw_paths=True)
+        layout, mine, sizes = [[] for _ in range(G)], [], [len(indices) for _, indices in requests]
+        for q, ((layer, indices), w) in enumerate(zip(requests, where)):
+            if w[0] == "local" or not indices:
+                continue
+            if G == 1:
+                layout[0].append((q, range(len(indices)), sub_level))
+                mine.append(got[w[1]])
+                continue
+            owners = [[] for _ in range(G)]
+            for pos, i in enumerate(indices):
+                owners[(i % R) // Rw].append(pos)
+            for r in range(G):
+                if owners[r]:
+                    layout[r].append((q, owners[r], sub_level))
+            if owners[g]:
+                mine.append(got[w[1]])
+        answers = self._gather_answers(layout, mine, sizes) if any(layout) else {}
+        out = []
+        for q, ((layer, indices), w) in enumerate(zip(requests, where)):
+            k = len(indices)
+            if w[0] == "local":
+                vals, paths = got[w[1]]
+                depth = layer["length"].bit_length() - 1
+                paths = np.ascontiguousarray(paths).reshape(k, 64 * depth) if k and depth else np.zeros((k, 0), dtype=np.uint8)
+            elif q not in answers:
+                vals, paths = [], np.zeros((0, 0), dtype=np.uint8)
+            else:
+                vals, bottoms = answers[q]
+                tops = got[w[1] + 1][1] if layer["C"] * G > 1 else None
+                paths = np.concatenate((bottoms, tops), axis=1) if tops is not None and tops.shape[0] == k and tops.shape[1] else bottoms
+            out.append((sc.pack(vals), np.ascontiguousarray(paths)))
+        return out
+
+    @staticmethod
+    def _holder(layer, field):
+        """the layer's entries as proof_objects' segments want them: a field, an identity, FieldElements made once per index"""
+        holder = layer.get("holder")
+        if holder is None:
+            holder = layer["holder"] = _LayerEntries(layer, field)
+        return holder
+
     def _open_many(self, requests):
         """entries as FieldElement objects (one object per index and layer, reused) + fresh path objects per request"""
         from algebra import FieldElement
@@ -969,11 +1050,58 @@ class ShardedFri:
         last_layer = layers[-1]
         last_vec = full if full is not None else self._natural(cur, C)
         last_values = eng.read(last_vec, range(last_layer["length"]))
+        lazy = None
+        if hasattr(eng, "query_many"):                      # (the CPU test engines answer with objects)
+            import proof_objects as _po
+            lazy = _po.lazy_objects(proof_stream)
+        if lazy is not None:
+            # described, not built (proof_objects): the transcript bytes are the same, no object per element / digest
+            import starkcore as _scm
+            lazy.add(_po.ElementList(self._holder(last_layer, field), _scm.pack(last_values)))
+            return self._query_all_lazy(layers, len(last_values), proof_stream, lazy)
         last_list = [FieldElement(v, field) for v in last_values]
         last_layer["cache"] = dict(enumerate(last_list))
         proof_stream.push(last_list)
 
         return self._query_all(layers, last_list, proof_stream)
+
+    def _query_requests(self, layers, last_length, proof_stream):
+        """top-level indices from the transcript and what every layer has to open (fri.py:119-128)"""
+        fr = self.fri
+        N, s = fr.domain_length, fr.num_colinearity_tests
+        top_level_indices = fr.sample_indices(proof_stream.prover_fiat_shamir(), N // 2, last_length, s)
+        nq = len(layers) - 1
+        per_round, indices = [], [i for i in top_level_indices]
+        for i in range(nq):
+            indices = [index % (layers[i]["length"] // 2) for index in indices]
+            per_round.append(indices)
+        requests = []
+        for j, layer in enumerate(layers):
+            request = []
+            if j < nq:
+                request += per_round[j][:s] + [index + layer["length"] // 2 for index in per_round[j][:s]]
+            if j > 0:
+                request += per_round[j - 1][:s]
+            requests.append((layer, request))
+        return top_level_indices, per_round, requests
+
+    def _query_all_lazy(self, layers, last_length, proof_stream, lazy):
+        """_query_all with the owners' answers pushed as they are (proof_objects.FriRound)"""
+        import proof_objects as _po
+        field, s = self.fri.field, self.fri.num_colinearity_tests
+        top_level_indices, per_round, requests = self._query_requests(layers, last_length, proof_stream)
+        fetched = self._open_many_arrays(requests)
+        nq = len(layers) - 1
+        for i in range(nq):
+            values, paths = fetched[i]
+            next_values, next_paths = fetched[i + 1]
+            c_at = 2 * s if i + 1 < nq else 0
+            a = per_round[i][:s]
+            half = layers[i]["length"] // 2
+            lazy.add(_po.FriRound(self._holder(layers[i], field), self._holder(layers[i + 1], field), a, [index + half for index in a], a,
+                                  values[:16 * s], values[16 * s:32 * s], next_values[16 * c_at:16 * (c_at + s)],
+                                  paths[:s], paths[s:2 * s], next_paths[c_at:c_at + s]))
+        return top_level_indices
 
     def _query_all(self, layers, last_list, proof_stream):
         """the query phase of fri.py:124-128 over the committed layers: indices from the transcript, ONE collective for every

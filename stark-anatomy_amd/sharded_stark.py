@@ -331,7 +331,14 @@ class ShardedFastStark(FastStark):
         quadrupled_indices.sort()
         layers = boundary_layers + [randomizer_layer, transition_zerofier_layer]
         # ONE library call and ONE collective for all the codewords' openings; pushed leaf, path, leaf, path, ... per codeword
-        for entries, paths in self.sfri._open_many([(layer, quadrupled_indices) for layer in layers]):
+        import proof_objects as _po
+        lazy = _po.lazy_objects(proof_stream) if hasattr(self.sfri.engine, "query_many") else None
+        if lazy is not None:
+            # the owners' answers as they are (proof_objects.Openings): same transcript bytes, no object per digest
+            for layer, (values, paths) in zip(layers, self.sfri._open_many_arrays([(layer, quadrupled_indices) for layer in layers])):
+                lazy.add(_po.Openings(self.sfri._holder(layer, field), quadrupled_indices, values, paths))
+            layers = []
+        for entries, paths in self.sfri._open_many([(layer, quadrupled_indices) for layer in layers]) if layers else []:
             if type(proof_stream) is ProofStream:            # push == objects.append
                 proof_stream.objects.extend(x for pair in zip(entries, paths) for x in pair)
                 continue

@@ -225,12 +225,12 @@ def pickle_proof(ops, moduli, nfields, modulus_bytes):
     """pickle.dumps of the object graph described by `ops` (csrc/proof_pickle.h; host only)"""
     need = ctypes.c_uint64()
     cap = len(ops) + len(ops) // 8 + 4096
-    out = ctypes.create_string_buffer(cap)
+    out = (ctypes.c_char * cap)()
     _check(lib().sc_pickle_proof(ops, len(ops), moduli, nfields, modulus_bytes, out, cap, ctypes.byref(need)))
     if need.value > cap:
-        out = ctypes.create_string_buffer(need.value)
+        out = (ctypes.c_char * need.value)()
         _check(lib().sc_pickle_proof(ops, len(ops), moduli, nfields, modulus_bytes, out, need.value, ctypes.byref(need)))
-    return out.raw[:need.value]
+    return ctypes.string_at(out, need.value)
 
 
 def fe_bytes(v):
