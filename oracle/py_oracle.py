@@ -286,7 +286,8 @@ class _C:
     @property
     def lib(self):
         if self._lib is None:
-            path = os.path.join(_HERE, "libstark_oracle.so")
+            # STARK_ORACLE_LIB: another build of the same source (tools/sanitize.sh runs the tests against an ASan + UBSan one)
+            path = os.environ.get("STARK_ORACLE_LIB") or os.path.join(_HERE, "libstark_oracle.so")
             if not os.path.exists(path):
                 raise RuntimeError("oracle/libstark_oracle.so missing -- run `make -C oracle` (or __graft_entry__.build())")
             lib = ctypes.CDLL(path)

@@ -16,9 +16,9 @@ EMU_DIR = os.path.join(REPO, "tests", "emu")
 
 @pytest.fixture(scope="module")
 def emu():
-    so = os.path.join(EMU_DIR, "libntt_emu.so")
+    so = os.environ.get("NTT_EMU_LIB") or os.path.join(EMU_DIR, "libntt_emu.so")       # (tools/sanitize.sh: an ASan + UBSan build)
     srcs = [os.path.join(EMU_DIR, "ntt_emu.cpp")] + [os.path.join(REPO, "stark-anatomy_amd", "csrc", f) for f in ("field.cuh", "ntt_tile.cuh", "ntt_plan.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    if not os.environ.get("NTT_EMU_LIB") and (not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]])
     lib = ctypes.CDLL(so)
     lib.emu_ntt.restype = ctypes.c_int

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Sanitizer builds.  `bash tools/sanitize.sh cpu` runs what needs no GPU; `... gpu <outdir>` runs on the GPU box
+# (gpurun -- 'bash tools/sanitize.sh gpu gpurun_out/<dir>').  Clean logs are kept under profiles/.
+#   cpu:  oracle/stark_oracle.c (gcc) and tests/emu/ntt_emu.cpp (g++; the kernels' round bodies, the planner, field.cuh on the
+#         host) under ASan + UBSan against their test suites; the HOST side of libstarkcore.so (hipcc -fsanitize=address,undefined:
+#         device code is not instrumented) against the host-only suites: transcript, proof pickler, ABI
+#   gpu:  the same ASan + UBSan library under the C-ABI parity tests, the Fri / FastStark host tests, the allocator leak check;
+#         a ThreadSanitizer build under tools/thread_stress.py (three prover threads in one process)
+set -u
+REPO=$(cd "$(dirname "$0")/.." && pwd); cd $REPO
+MODE=${1:-cpu}; OUT=${2:-/tmp/sanitize}; mkdir -p $OUT
+LIBS=/tmp/sanitize_libs; mkdir -p $LIBS          # the instrumented libraries (tens of MB) stay out of $OUT, which holds the logs
+CSRC=stark-anatomy_amd/csrc
+CLANG_RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+CLANG_TSAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so 2>/dev/null | head -1)
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1
+export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+build_lib() {   # $1 = sanitizer list, $2 = output
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=$1 -fno-omit-frame-pointer -shared-libsan \
+      -Wno-unused-value -Wno-unused-result -Wno-option-ignored -shared -o $2 $CSRC/starkcore.hip 2>&1 | grep -E "error" ; test -f $2
+}
+status=0
+if [ "$MODE" = cpu ]; then
+  gcc -O1 -g -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared -o $LIBS/libstark_oracle_san.so oracle/stark_oracle.c || status=1
+  g++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared -o $LIBS/libntt_emu_san.so tests/emu/ntt_emu.cpp || status=1
+  GCC_RT="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
+  echo "== oracle (gcc, ASan + UBSan): tests/test_oracle.py tests/test_polytree_model.py tests/test_geoseq_model.py"
+  LD_PRELOAD=$GCC_RT STARK_ORACLE_LIB=$LIBS/libstark_oracle_san.so timeout 1500 python -m pytest tests/test_oracle.py tests/test_polytree_model.py tests/test_geoseq_model.py -x -q 2>&1 | tail -4 || status=1
+  echo "== kernel emulation + planner (g++, ASan + UBSan): tests/test_emu.py"
+  LD_PRELOAD=$GCC_RT STARK_ORACLE_LIB=$LIBS/libstark_oracle_san.so NTT_EMU_LIB=$LIBS/libntt_emu_san.so timeout 2400 python -m pytest tests/test_emu.py -x -q 2>&1 | tail -4 || status=1
+  echo "== libstarkcore.so host side (hipcc, ASan + UBSan): tests/test_proof_pickle.py tests/test_host_cpu.py tests/test_abi.py"
+  build_lib address,undefined $LIBS/libstarkcore_san.so || status=1
+  LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 1500 python -m pytest tests/test_proof_pickle.py tests/test_host_cpu.py tests/test_abi.py -x -q 2>&1 | tail -4 || status=1
+else
+  echo "== libstarkcore.so host side under ASan + UBSan on the GPU"
+  build_lib address,undefined $LIBS/libstarkcore_san.so || status=1
+  for t in "tests/test_gpu_cabi.py -k 'not full_size and not big and not tunings'" "tests/test_gpu_host.py" "tests/test_gpu_stark.py" "tests/test_gpu_geoseq.py -k 'not 1048'"; do
+    echo "-- pytest $t"
+    LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 1500 bash -c "python -m pytest $t -x -q -m gpu 2>&1 | tail -4" || status=1
+  done
+  # (the HIP runtime's own big host allocations exhaust ASan's allocator with the default 256 MB quarantine: keep it small here)
+  echo "-- tools/leak_check.py"; ASAN_OPTIONS=$ASAN_OPTIONS:quarantine_size_mb=8 LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 600 python tools/leak_check.py 2>&1 | grep -v "amdgpu.ids" | tail -6 || status=1
+  echo "-- tools/thread_stress.py 10 3 (ASan)"; LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 600 python tools/thread_stress.py 10 3 2>&1 | tail -3 || status=1
+  if [ -n "$CLANG_TSAN" ]; then
+    echo "== ThreadSanitizer build under three prover threads"
+    build_lib thread $LIBS/libstarkcore_tsan.so || status=1
+    LD_PRELOAD=$CLANG_TSAN TSAN_OPTIONS="report_signal_unsafe=0:ignore_noninstrumented_modules=1:halt_on_error=0:exitcode=0" STARKCORE_LIB=$LIBS/libstarkcore_tsan.so \
+        timeout 900 python tools/thread_stress.py 10 3 > $OUT/tsan_thread_stress.txt 2>&1; tail -3 $OUT/tsan_thread_stress.txt
+    echo "ThreadSanitizer reports naming libstarkcore frames: $(grep -c 'libstarkcore_tsan' $OUT/tsan_thread_stress.txt)   (all reports: $(grep -c 'WARNING: ThreadSanitizer' $OUT/tsan_thread_stress.txt))"
+  else
+    echo "no ThreadSanitizer runtime in this toolchain"
+  fi
+fi
+echo "sanitize.sh $MODE: status $status"
+exit $status
