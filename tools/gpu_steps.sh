@@ -5,7 +5,7 @@
 #   bench            python bench.py (default window)            bench:<args>      bench.py with arguments (comma = space)
 #   rocprof:<args>   rocprofv3 --kernel-trace --stats of bench.py <args>; keeps the kernel_stats.csv head and the JSON line
 #   prover:<log>     tools/sharded_stark_profile.py <log>        timeline:<forms>  tools/sharded_timeline.py under --kernel-trace
-#   py:<script>      python tools/<script>.py
+#   py:<script>      python tools/<script>.py           ubench:<name>     build and run tools/microbench/<name>.hip
 O=gpurun_out/$1; shift; mkdir -p $O
 export TMPDIR=/tmp
 for step in "$@"; do
@@ -23,6 +23,7 @@ for step in "$@"; do
     timeline) (cd /tmp && TIMELINE_FORMS=${arg// /,} timeout 900 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/tl_$tag -o t --output-format csv -- python $GRAFT_REPO_ROOT/tools/sharded_timeline.py run 21 200 > $GRAFT_REPO_ROOT/$O/timeline_run_$tag.txt 2>&1)
              f=$(ls $O/tl_$tag/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && python tools/sharded_timeline.py report $f > $O/timeline_$tag.txt; rm -rf $O/tl_$tag
              grep '^{' $O/timeline_run_$tag.txt; head -30 $O/timeline_$tag.txt ;;
+    ubench)  (cd tools/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-unused-result -o /tmp/ub_$arg $arg.hip 2>&1 | grep -E "error" ; timeout 300 /tmp/ub_$arg) > $O/ubench_$tag.txt 2>&1; cat $O/ubench_$tag.txt ;;
     py)      s=${arg%% *}; rest=${arg#"$s"}; (timeout 1500 python tools/$s.py $rest > $O/py_$tag.txt 2>&1); tail -40 $O/py_$tag.txt ;;
     *) echo "unknown step $step" ;;
   esac
