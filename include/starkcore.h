@@ -237,6 +237,9 @@ int sc_geodomain_free(sc_geodomain_t* domain);
  * d_out[i] = sum_t coefs[t] * prod_j vals[j][i]^exps[t][j].  With n > the degree of the result, an inverse NTT of d_out
  * gives exactly the polynomial the reference builds from schoolbook products (§8(f)-2). */
 int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, void* stream);
+/* the same for several constraints over ONE set of point values: vals_converted != 0 says d_vals has been through an earlier call.
+ * n may be any count (a rank's slab of a sharded value domain: the evaluation is pointwise). */
+int sc_mpoly_eval_ex_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, int vals_converted, void* stream);
 
 /* ---- FRI split-and-fold : code/fri.py:85 ---------------------------------------------------- */
 /* out[i] = 2^-1 * ((1 + alpha/(offset*omega^i)) * in[i] + (1 - alpha/(offset*omega^i)) * in[N/2+i]), i < N/2 */

@@ -387,7 +387,10 @@ hipStream_t g_comm_stream_for_free = nullptr;   // the library's communication s
 // hundreds of MiB cost more than the kernels that fill them.  Exact-size free lists, bounded total.
 std::multimap<size_t, void*> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t POOL_CAP = 8ull << 30;
+// What the pool may keep: a quarter of the device's memory (72 GB of the MI355X's 288: the machine's HBM is there to be used --
+// a FastStark proof at a 2^24 FRI domain cycles through ~12 GB of trees and vectors, and a buffer that does not fit the pool costs
+// a hipFree now and a multi-GB hipMalloc in the next proof, tens of milliseconds each); set at init, 8 GB if the device does not say.
+size_t g_pool_cap = 8ull << 30;
 
 void reap_pending(bool block);
 hipError_t pool_alloc(void** p, size_t bytes) {
@@ -425,7 +428,7 @@ hipError_t pool_alloc(void** p, size_t bytes) {
 
 void pool_free(void* p, size_t bytes) {
     if (!p) return;
-    if (g_pool_bytes + bytes <= POOL_CAP) {            // (small buffers too: hipFree waits for the whole device)
+    if (g_pool_bytes + bytes <= g_pool_cap) {          // (small buffers too: hipFree waits for the whole device)
         g_pool.emplace(bytes, p);
         g_pool_bytes += bytes;
     } else {
@@ -504,6 +507,7 @@ int ensure_init() {
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g.num_cus = cus; }
+    { size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) g_pool_cap = total_b / 4; else (void)hipGetLastError(); }
     g.device = dev;
     g.init = true;
     return SC_OK;
@@ -3300,6 +3304,11 @@ int sc_geodomain_free(sc_geodomain_t* domain) {
 
 // ---- MPolynomial.evaluate_symbolic in the value domain
 int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, void* stream) {
+    return sc_mpoly_eval_ex_dev(d_vals, nvars, n, exps, coefs, nterms, d_out, 0, stream);
+}
+// vals_converted != 0: d_vals has been through an earlier call already (several constraints over the same point values: the
+// conversion to the library's internal form happens once)
+int sc_mpoly_eval_ex_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, int vals_converted, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     hipStream_t st = pick_stream(stream);
@@ -3315,7 +3324,7 @@ int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* e
     SCCHK(scratch(4, cbytes + nterms * nvars + 256, &buf));
     SCCHK(upload(buf, cm.data(), cm.size() * sizeof(Fe), st));
     if (nterms) SCCHK(upload((char*)buf + cbytes, exps, nterms * nvars, st));
-    hipLaunchKernelGGL(to_mont_kernel, dim3((unsigned)((nvars * n + 255) / 256)), dim3(256), 0, st, (Fe*)d_vals, nvars * n);
+    if (!vals_converted) hipLaunchKernelGGL(to_mont_kernel, dim3((unsigned)((nvars * n + 255) / 256)), dim3(256), 0, st, (Fe*)d_vals, nvars * n);
     hipLaunchKernelGGL(mpoly_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fe*)d_vals, (uint32_t)nvars, n,
                        (const uint8_t*)((char*)buf + cbytes), (const Fe*)buf, (uint32_t)nterms, (Fe*)d_out);
     HIPCHK(hipGetLastError());

@@ -135,6 +135,29 @@ class MPolynomial:
             acc = acc + term
         return acc
 
+    def value_domain_terms(self, degrees):
+        """What evaluating this polynomial POINTWISE on the values of point polynomials of the given degrees needs: (degree bound of
+        the result, [(exponents padded to len(degrees), coefficient residue)] of the terms that do not vanish); bound -1: every
+        term vanishes; NotImplemented for a shape mpoly_eval_kernel does not take."""
+        nvars = len(degrees)
+        if nvars > 255:
+            return NotImplemented
+        bound, terms = -1, []
+        for k, v in self.dictionary.items():
+            if len(k) > nvars or max(k, default=0) > 255:
+                return NotImplemented
+            d, dead = 0, False
+            for i, e in enumerate(k):
+                if degrees[i] < 0:
+                    dead = True               # Polynomial.__xor__ returns the zero polynomial for a zero base whatever the
+                    break                     # exponent, 0 included (univariate.py:139-140): the term vanishes
+                d += e * degrees[i]
+            if dead or v.value == 0:
+                continue
+            terms.append((tuple(k) + (0,) * (nvars - len(k)), v.value))
+            bound = max(bound, d)
+        return bound, terms
+
     def _evaluate_symbolic_value_domain(self, point):
         """The same polynomial computed pointwise: the point polynomials are evaluated on a power-of-two domain larger than
         the degree of the result (one zero-padded NTT each), the AIR is evaluated value by value (`mpoly_eval_kernel`), and
@@ -157,23 +180,11 @@ class MPolynomial:
         if field is None or field.p != Field.P_MAIN:
             return NotImplemented if any(on_device) else None
         nvars = len(point)
-        if nvars > 255:
-            return NotImplemented
         degs = [q.degree() for q in point]
-        bound, terms = -1, []
-        for k, v in self.dictionary.items():
-            if len(k) > nvars or max(k, default=0) > 255:
-                return NotImplemented
-            d, dead = 0, False
-            for i, e in enumerate(k):
-                if degs[i] < 0:
-                    dead = True               # Polynomial.__xor__ returns the zero polynomial for a zero base whatever the
-                    break                     # exponent, 0 included (univariate.py:139-140): the term vanishes
-                d += e * degs[i]
-            if dead or v.value == 0:
-                continue
-            terms.append((tuple(k) + (0,) * (nvars - len(k)), v.value))
-            bound = max(bound, d)
+        plan = self.value_domain_terms(degs)
+        if plan is NotImplemented:
+            return NotImplemented
+        bound, terms = plan
         if bound < 0:
             # no live term: a zero factor kills its term whatever the exponent (univariate.py:139-140), zero coefficients add
             # nothing -- the sum is the zero polynomial

@@ -528,20 +528,25 @@ class ShardedNtt:
         fb = self._buf("div_b", self.local_shape(False))
         self.forward(sa, fa)
         self.forward(sb, fb)
+        self.divide_values(fa, fb, fa)
+        self.inverse(fa, out_local)
+        self.coset_scale(out_local, pow(int(offset), P - 2, P))
+
+    def divide_values(self, a, b, out):
+        """out = a / b pointwise on slabs of values (code/ntt.py:172); a zero of the divisor raises the reference's "divide by zero"
+        on EVERY rank: it may sit in another rank's slab, so the ranks agree on the outcome (4 bytes) before anyone enters the next
+        collective"""
         failed = 0
         try:
-            self._run(lambda: self.engine.pointwise_div(fa, fb, fa, fa.numel() // 2))
+            self._run(lambda: self.engine.pointwise_div(a, b, out, a.numel() // 2))
         except AssertionError:
             failed = 1
         if self.world > 1:
-            # the zero may sit in another rank's slab: agree on the outcome (4 bytes) before anyone enters the next collective
             backend = dist.get_backend(self.group)
             flag = torch.tensor([failed], dtype=torch.int32, device=self.device if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
             failed = int(flag.item())
         assert(not failed), "divide by zero"
-        self.inverse(fa, out_local)
-        self.coset_scale(out_local, pow(int(offset), P - 2, P))
 
     def forward(self, x_local, y_local):
         """x_local [n1][n2/G] -> y_local [n2][n1/G]  (column slab of X[k2*n1 + k1])."""

@@ -102,6 +102,15 @@ class HipReplicatedSteps:
     def combination(self, shifted, weights, max_degree):
         return self.stark._combination_on_device(shifted, weights, max_degree)
 
+    def air_values(self, vals, nvars, count, terms, out, converted):
+        """out[i] = sum_t coef_t * prod_j vals[j][i]^e_tj on a rank's slab (multivariate.py:83-90 pointwise; sc_mpoly_eval_ex_dev);
+        vals [nvars][count][2] is converted to the library's internal form by the first call (converted=False)"""
+        exps = bytes(e for k, _ in terms for e in k)
+        coefs = b"".join(v.to_bytes(16, "little") for _, v in terms)
+        self.join()
+        _sc._check(_sc.lib().sc_mpoly_eval_ex_dev(vals.data_ptr(), nvars, count, exps, coefs, len(terms), out.data_ptr(), 1 if converted else 0, None))
+        self.join()
+
     # -- between a polynomial and the torch tensor the collectives and the sharded transforms work on
     def coefficients(self, poly, length=None):
         """coefficients as a torch tensor [length][2] (a copy: torch owns what the collectives touch)"""
@@ -141,6 +150,7 @@ class ShardedFastStark(FastStark):
         with self._on_stream():
             self.steps = HipReplicatedSteps(self) if replicated_steps is None else replicated_steps(self)
             self._ntts = {}
+            self._zerofier_values = {}        # transform order -> (the zerofier, its values on this rank's slab of that coset)
             self.ntt_fri = self._ntt(self.fri_domain_length, self.omega.value)
             self.sfri = ShardedFri(self.fri, self.ntt_fri.n1, rank, world, device, engine=self.steps.fri_engine(), group=group)
 
@@ -250,6 +260,74 @@ class ShardedFastStark(FastStark):
             assert(tail.degree() == -1), "cannot perform polynomial division because remainder is not zero"
         return self._polynomial(full, n_out)
 
+    def _transition_quotients(self, constraints, point, tz_dev):
+        """fast_stark.py:107-113: `a.evaluate_symbolic(point)` divided by the transition zerofier, for every constraint a.
+
+        The reference builds the transition polynomial from schoolbook products and divides it on the coset g * <root'>, root' of the
+        order ntt.py:155-157 shrinks to.  Here the whole computation stays in the VALUE domain of that coset, SHARDED: the point
+        polynomials (X, trace(X), trace(omicron X)) are evaluated on it with the sharded transform -- one per variable, shared by
+        all constraints of the same order --, the AIR is evaluated pointwise on the rank's slab (mpoly_eval_kernel: values are
+        values, whatever the layout), divided pointwise by the zerofier's values (kept per order: they depend on the prover's
+        parameters only), and ONE sharded inverse per constraint returns the quotient's coefficients.  4 + 2 transforms instead of
+        the 9 + 4 of "substitute (replicated), then divide (sharded)", and nothing of it replicated.
+        Same result as the reference: the order is chosen from the degree BOUND of the transition polynomial; an exact division
+        gives the same quotient on any coset large enough, and its length is its degree + 1.  Where that cannot be guaranteed --
+        the interpolant of the pointwise quotient is longer than an exact quotient could be (a false witness: the reference then
+        returns a truncation that depends on the transition polynomial's true degree), a shape the kernel does not take, an order
+        too small to shard -- the constraint goes the replicated way."""
+        steps = self.steps
+        replicated = lambda a: self._coset_divide(a.evaluate_symbolic(point), tz_dev)
+        if not hasattr(steps, "air_values"):
+            return [replicated(a) for a in constraints]
+        degrees = [q.degree() for q in point]
+        dr = tz_dev.degree()
+        out, groups = [None] * len(constraints), {}
+        for i, a in enumerate(constraints):
+            plan = a.value_domain_terms(degrees)
+            if plan is NotImplemented or plan[0] < max(dr, 8) or dr < 0:
+                continue
+            bound, terms = plan
+            root, order = _shrink_order(self.omicron, self.omicron_domain_length, max(bound, dr))
+            log2 = order.bit_length() - 1
+            if log2 < ShardedFastStark.MIN_SHARDED_LOG2 or (1 << (log2 // 2)) < self.world or len(tz_dev) > order or any(len(q) > order for q in point):
+                continue
+            groups.setdefault(order, (root, []))[1].append((i, bound, terms))
+        for order, (root, members) in groups.items():
+            ntt = self._ntt(order, root.value)
+            shape = ntt.local_shape(False)
+            count = shape[0] * shape[1]
+            nvars = len(point)
+            used = [any(k[j] for _, _, terms in members for k, _ in terms) for j in range(nvars)]
+            vals = torch.empty((nvars,) + tuple(shape), dtype=torch.int64, device=self.device)
+            for j, q in enumerate(point):
+                if used[j]:
+                    ntt.coset_evaluate(self._tensor(q, degrees[j] + 1), self.generator.value, vals[j])
+            kept = self._zerofier_values.get(order)
+            if kept is not None and kept[0] is tz_dev:
+                zvals = kept[1]
+            else:
+                zvals = torch.empty(shape, dtype=torch.int64, device=self.device)
+                ntt.coset_evaluate(self._tensor(tz_dev, dr + 1), self.generator.value, zvals)
+                if len(self._zerofier_values) >= 4:
+                    self._zerofier_values.clear()
+                self._zerofier_values[order] = (tz_dev, zvals)
+            converted = False
+            for i, bound, terms in members:
+                tvals = torch.empty(shape, dtype=torch.int64, device=self.device)
+                steps.air_values(vals, nvars, count, terms, tvals, converted)
+                converted = True
+                ntt.divide_values(tvals, zvals, tvals)                   # "divide by zero" on every rank together
+                q = torch.empty(ntt.local_shape(True), dtype=torch.int64, device=self.device)
+                ntt.inverse(tvals, q)
+                ntt.coset_scale(q, pow(self.generator.value, self.field.p - 2, self.field.p))
+                full = self._gather_natural(q, ntt.n1, ntt.n2)
+                whole = self._polynomial(full, order)
+                degree = whole.degree()
+                if degree > bound - dr:
+                    continue                                             # not the quotient of an exact division: the reference's way
+                out[i] = DevicePolynomial(whole.vec, self.field, degree + 1) if degree >= 0 else steps.zero()
+        return [q if q is not None else replicated(a) for q, a in zip(out, constraints)]
+
     # -- preprocessing (fast_stark.py:36-40) -----------------------------------------------------------
     def preprocess(self, device_resident=False):
         """-> (transition_zerofier, its committed codeword as a sharded layer record, the root).  device_resident=True: the
@@ -297,11 +375,9 @@ class ShardedFastStark(FastStark):
         # replicated: the AIR substituted in (X, trace(X), trace(omicron X)) in the value domain; sharded: the quotients
         x = Polynomial([field.zero(), field.one()])
         point = [steps.lift(x)] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
-        transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
-        self._mark("AIR substitution in the value domain (replicated)")
         tz_dev = steps.lift(transition_zerofier)
-        transition_quotients = [self._coset_divide(tp, tz_dev) for tp in transition_polynomials]
-        self._mark("transition quotients (sharded division)")
+        transition_quotients = self._transition_quotients(transition_constraints, point, tz_dev)
+        self._mark("AIR substitution + transition quotients (value domain, sharded)")
 
         # randomizer polynomial (rank 0's draws), its sharded LDE and commitment
         max_degree = self.max_degree(transition_constraints)

@@ -165,6 +165,16 @@ def stark_check(rank, world, dev):
         columns = fast_stark.DeviceTrace.from_rows(trace, field)
         tz3, layer3, root3 = many.preprocess(device_resident=True)
         good = good and root3 == tzr and many.prove(columns, air, boundary, tz3, layer3) == want
+        # a FALSE WITNESS (a trace cell that no boundary condition pins, perturbed): the transition quotients are not exact any more,
+        # the value-domain route must notice and hand the constraint to the reference's way -- same bytes as the one-GPU prover,
+        # and a proof the verifier rejects
+        bent = [list(row) for row in trace]
+        bent[T // 2][0] = bent[T // 2][0] + FieldElement(12345, field)
+        seeded()
+        want_bent = one.prove(bent, air, boundary, tz, tzc)
+        seeded()
+        got_bent = many.prove(bent, air, boundary, tz2, layer)
+        good = good and got_bent == want_bent and one.verify(got_bent, air, boundary, tzr) is False
         if not good:
             print("rank", rank, "STARK MISMATCH k", k, root == tzr, len(got), len(want), flush=True)
         ok &= good

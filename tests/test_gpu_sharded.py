@@ -206,6 +206,43 @@ def test_sharded_fast_stark_one_rank(sc):
         assert sharded_gpu_worker.stark_check(0, 1, dev)
 
 
+def test_sharded_fast_stark_reproduces_the_reference_proofs_one_rank(sc, monkeypatch):
+    """The REFERENCE's golden Rescue-Prime proofs (tests/golden/fast_stark.json) through sharded_stark.ShardedFastStark with the HIP
+    engine at world 1 and every division forced through the sharded route: the AIR there uses the variable X (round constants)
+    and has one constraint per register, so the value-domain transition quotients (one set of point values, several constraints,
+    X evaluated on the coset) are pinned to the reference byte for byte."""
+    import hashlib
+    import random
+    import fast_stark
+    import sharded_stark
+    from algebra import Field, FieldElement
+    from conftest import load_golden
+    from workload_rescue_prime import RescuePrime
+    monkeypatch.setattr(sharded_stark.ShardedFastStark, "MIN_SHARDED_LOG2", 4)
+    taken = []
+    real = sharded_stark.ShardedFastStark._coset_divide
+    monkeypatch.setattr(sharded_stark.ShardedFastStark, "_coset_divide", lambda self, *a, **k: (taken.append(1), real(self, *a, **k))[1])
+    field = Field.main()
+    rp = RescuePrime()
+    dev = torch.device("cuda", 0)
+    genuine = fast_stark.os.urandom
+    try:
+        for rec in load_golden("fast_stark.json")["runs"]:
+            rng = random.Random(rec["urandom_seed"])
+            fast_stark.os.urandom = lambda k, rng=rng: bytes(rng.getrandbits(8) for _ in range(k))
+            input_element = FieldElement(int(rec["input"]), field)
+            output_element = rp.hash(input_element)
+            stark = sharded_stark.ShardedFastStark(field, rec["expansion_factor"], rec["num_colinearity_checks"], rec["security_level"], rp.m, rp.N + 1, 0, 1, dev)
+            tz, layer, root = stark.preprocess()
+            assert root.hex() == rec["zerofier_root"]
+            del taken[:]
+            proof = stark.prove(rp.trace(input_element), rp.transition_constraints(stark.omicron), rp.boundary_constraints(output_element), tz, layer)
+            assert hashlib.sha256(proof).hexdigest() == rec["proof_sha256"]
+            assert len(taken) == rp.m                      # only the boundary quotients went through _coset_divide: the transition quotients took the value-domain route
+    finally:
+        fast_stark.os.urandom = genuine
+
+
 def test_bench_stark_prove_workload(sc):
     """`bench.py --workload stark_prove`: BASELINE configs[4] as a prover, on one rank and on two ranks sharing the GPU -- the same
     proof (randomness is rank 0's; the proofs differ between RUNS, so only the verdicts are compared), accepted by the verifier"""
