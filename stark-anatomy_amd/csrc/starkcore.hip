@@ -7,6 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cerrno>
 #include <thread>
 #include <sys/random.h>
@@ -402,7 +403,13 @@ hipError_t pool_alloc(void** p, size_t bytes) {
         g_pool_bytes -= bytes;
         return hipSuccess;
     }
+    const bool slow_log = getenv("STARKCORE_LOG_SLOW_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, bytes);
+    if (slow_log) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 1.0) fprintf(stderr, "starkcore: hipMalloc(%zu MB) took %.1f ms (pool %zu MB in %zu buffers)\n", bytes >> 20, ms, g_pool_bytes >> 20, g_pool.size());
+    }
     if (e != hipSuccess) {                             // out of memory: first what is parked behind events
         (void)hipGetLastError();
         reap_pending(true);
@@ -432,7 +439,12 @@ void pool_free(void* p, size_t bytes) {
         g_pool.emplace(bytes, p);
         g_pool_bytes += bytes;
     } else {
+        const auto t0 = std::chrono::steady_clock::now();
         (void)hipFree(p);
+        if (getenv("STARKCORE_LOG_SLOW_ALLOC")) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > 1.0) fprintf(stderr, "starkcore: hipFree(%zu MB) took %.1f ms (pool at its cap of %zu MB)\n", bytes >> 20, ms, g_pool_cap >> 20);
+        }
     }
 }
 

@@ -743,11 +743,13 @@ class _LayerEntries:
     _full = None
 
     def __init__(self, layer, field):
-        self.layer, self.field = layer, field
+        # (only the cache: a reference to the layer record would close a cycle layer -> holder -> layer, and the layer's trees --
+        # gigabytes at a 2^24 domain -- would then wait for the cycle collector instead of going back to the pool with the proof)
+        self.cache, self.field = layer["cache"], field
 
     def _entries(self, indices, values):
         from algebra import FieldElement
-        cache, field, new = self.layer["cache"], self.field, object.__new__
+        cache, field, new = self.cache, self.field, object.__new__
         for i, v in zip(indices, values):
             if i not in cache:
                 e = new(FieldElement)

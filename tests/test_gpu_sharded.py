@@ -243,6 +243,37 @@ def test_sharded_fast_stark_reproduces_the_reference_proofs_one_rank(sc, monkeyp
         fast_stark.os.urandom = genuine
 
 
+def test_a_proof_leaves_no_device_memory_to_the_cycle_collector(sc):
+    """Everything a proof allocates on the device (trees of gigabytes at a 2^24 domain) must go back to the pool when the proof's
+    objects die -- by reference counting, not whenever the cycle collector gets round to it: a tree that waits in a cycle makes the
+    next proof miss the pool, and a 2 GB hipMalloc costs 60 ms (seen as 300-800 ms outliers, profiles/r04)."""
+    import gc
+    import bench
+    import starkcore
+    from fast_stark import DeviceTrace, FastStark
+    from sharded_stark import ShardedFastStark
+    field, T, packed, air, boundary = bench.synthetic_stark_instance(14, 40)
+    trace = DeviceTrace.from_packed(packed, field)
+    dev = torch.device("cuda", 0)
+    provers = [ShardedFastStark(field, 4, 40, 80, 2, T, 0, 1, dev), FastStark(field, 4, 40, 80, 2, T)]
+    setups = [p.preprocess(device_resident=True) for p in provers]
+    for p, (tz, committed, root) in zip(provers, setups):
+        p.prove(trace, air, boundary, tz, committed)
+    gc.collect()
+    gc.disable()
+    try:
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        for p, (tz, committed, root) in zip(provers, setups):
+            p.prove(trace, air, boundary, tz, committed)
+        gc.collect()
+        held = [o for o in gc.garbage if isinstance(o, (starkcore.MerkleTree, starkcore.DeviceVector, starkcore.DeviceCodeword, torch.Tensor))]
+        assert not held, [type(o).__name__ for o in held][:10]
+    finally:
+        gc.set_debug(0)
+        gc.garbage.clear()
+        gc.enable()
+
+
 def test_bench_stark_prove_workload(sc):
     """`bench.py --workload stark_prove`: BASELINE configs[4] as a prover, on one rank and on two ranks sharing the GPU -- the same
     proof (randomness is rank 0's; the proofs differ between RUNS, so only the verdicts are compared), accepted by the verifier"""

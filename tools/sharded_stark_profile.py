@@ -19,8 +19,28 @@ print("trace generated on the host in %.2f s (T = %d rows, 2 registers)" % (time
 stark = ShardedFastStark(field, 4, s, 2 * s, 2, T, 0, 1, dev)
 trace = DeviceTrace.from_packed(packed, field)
 t0 = time.perf_counter(); tz, layer, root = stark.preprocess(device_resident=True); torch.cuda.synchronize(); print("preprocess ms", round((time.perf_counter() - t0) * 1e3, 2))
-for _ in range(3):
-    t0 = time.perf_counter(); proof = stark.prove(trace, air, boundary, tz, layer); torch.cuda.synchronize(); print("prove ms", round((time.perf_counter() - t0) * 1e3, 2))
+runs = max([int(a.split("=")[1]) for a in sys.argv if a.startswith("--runs=")] + [3])
+import gc
+gc_pauses = []
+def _gc_watch(phase, info, _t=[0.0]):
+    if phase == "start": _t[0] = time.perf_counter()
+    else:
+        ms = (time.perf_counter() - _t[0]) * 1e3
+        if ms > 2: gc_pauses.append((info.get("generation"), round(ms, 1)))
+gc.callbacks.append(_gc_watch)
+times = []
+for k in range(runs):
+    stark.phase_log = [] if "--outliers" in sys.argv else None
+    t0 = time.perf_counter(); proof = stark.prove(trace, air, boundary, tz, layer); torch.cuda.synchronize(); times.append(round((time.perf_counter() - t0) * 1e3, 2))
+    if times[-1] > 3 * min(times):
+        st = torch.cuda.memory_stats()
+        print("run", k, times[-1], "ms; torch reserved MB", torch.cuda.memory_reserved() >> 20, "device allocs", st.get("num_device_alloc"), "frees", st.get("num_device_free"),
+              "retries", st.get("num_alloc_retries"), "free device MB", torch.cuda.mem_get_info()[0] >> 20, "gc pauses", gc_pauses)
+    if stark.phase_log and times[-1] > 3 * min(times):
+        print("run", k, times[-1], "ms; phases over 3 ms:", [(n[:40], round(s_ * 1e3, 1)) for n, s_ in stark.phase_log if s_ > 3e-3], "gc pauses", gc_pauses)
+    del gc_pauses[:]
+stark.phase_log = None
+print("prove ms", times)
 stark.phase_log = []
 t0 = time.perf_counter(); stark.prove(trace, air, boundary, tz, layer); total = time.perf_counter() - t0
 print("per phase (device waited for after each phase; %.2f ms in total this way):" % (total * 1e3))
