@@ -293,6 +293,9 @@ int sc_sample_bytes_dev(const void* bytes, uint64_t count, uint32_t width, void*
  * callers whose os.urandom is the operating system's (a patched, seeded os.urandom must go through sc_sample_bytes_dev, whose
  * bytes and order are the caller's). */
 int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* stream);
+/* start those draws NOW on host threads and return: a later sc_sample_urandom_dev of the same (count, width) uses them (the prover
+ * calls this at the top of a proof; the kernel randomness is drawn while the GPU works on the trace) */
+int sc_urandom_prefetch(uint64_t count, uint32_t width);
 int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]);
 int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len);
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */

@@ -12,6 +12,7 @@
 #include <thread>
 #include <sys/random.h>
 #include <deque>
+#include <future>
 #include <map>
 #include <mutex>
 #include <string>
@@ -383,6 +384,8 @@ constexpr long SPIN_POLLS = 40000000;     // ~ tens of milliseconds of polling b
 Ctx g;
 std::mutex g_mu;
 hipStream_t g_comm_stream_for_free = nullptr;   // the library's communication stream once it exists (sc_fourstep_run_dev)
+std::future<void> g_rand_worker;                // a draw of kernel randomness started ahead of time (sc_urandom_prefetch) ...
+size_t g_rand_prefetched = 0;                   // ... and its size in bytes (0: none in flight)
 
 // Small caching allocator for the big short-lived device objects (vectors, Merkle trees): hipMalloc/hipFree of
 // hundreds of MiB cost more than the kernels that fill them.  Exact-size free lists, bounded total.
@@ -1620,6 +1623,7 @@ int sc_init(int device) {
 
 int sc_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_rand_worker.valid()) { g_rand_worker.get(); g_rand_prefetched = 0; }
     if (!g.init) return SC_OK;
     hipDeviceSynchronize();
     reap_pending(true);
@@ -1772,6 +1776,58 @@ namespace {
 uint8_t* g_rand_host = nullptr;
 size_t g_rand_host_bytes = 0;
 hipEvent_t g_rand_copied = nullptr;
+std::atomic<int> g_rand_failed{0};
+
+// the draw itself: `bytes` of getrandom into g_rand_host, split over host threads (at least 256 KiB each, at most 32)
+void rand_fill(size_t bytes) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthreads = bytes / (256u << 10);
+    if (nthreads > 32) nthreads = 32;
+    if (hw && nthreads > hw) nthreads = hw;
+    if (nthreads < 1) nthreads = 1;
+    auto fill = [](size_t a, size_t b) {
+        while (a < b) {
+            size_t want = b - a < (1u << 20) ? b - a : (1u << 20);
+            ssize_t r = getrandom(g_rand_host + a, want, 0);
+            if (r < 0) { if (errno == EINTR) continue; g_rand_failed = 1; return; }
+            a += (size_t)r;
+        }
+    };
+    if (nthreads == 1) { fill(0, bytes); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (bytes + nthreads - 1) / nthreads;
+    for (size_t i = 0; i < nthreads; ++i) {
+        const size_t a = i * per, b = a + per < bytes ? a + per : bytes;
+        if (a < b) pool.emplace_back(fill, a, b);
+    }
+    for (auto& t : pool) t.join();
+}
+// the staging buffer is free (the previous call's copy has left it, no draw is running) and holds at least `bytes`
+int rand_buffer(size_t bytes) {
+    if (g_rand_worker.valid()) { g_rand_worker.get(); g_rand_prefetched = 0; }
+    if (g_rand_copied) HIPCHK(hipEventSynchronize(g_rand_copied));
+    if (g_rand_host_bytes < bytes) {
+        if (g_rand_host) { (void)hipHostFree(g_rand_host); g_rand_host = nullptr; g_rand_host_bytes = 0; }
+        HIPCHK(hipHostMalloc((void**)&g_rand_host, bytes, hipHostMallocDefault));
+        g_rand_host_bytes = bytes;
+    }
+    if (!g_rand_copied) HIPCHK(hipEventCreateWithFlags(&g_rand_copied, hipEventDisableTiming));
+    return SC_OK;
+}
+}
+// Start the draws of a later sc_sample_urandom_dev(count, width, ...) NOW, on host threads, and return: the prover calls this at
+// the top of a proof, and the 3 ms of kernel randomness for the randomizer polynomial pass while the GPU interpolates the trace
+// and commits to the boundary quotients.  (Only for the operating system's randomness, which has no order to keep.)
+int sc_urandom_prefetch(uint64_t count, uint32_t width) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!count || width == 0 || width > 32) return fail(SC_ERR_BAD_ARG, "byte strings of 1..32 bytes expected");
+    const size_t bytes = (size_t)count * width;
+    SCCHK(rand_buffer(bytes));
+    g_rand_failed = 0;
+    g_rand_prefetched = bytes;
+    g_rand_worker = std::async(std::launch::async, rand_fill, bytes);
+    return SC_OK;
 }
 int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1780,38 +1836,15 @@ int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* str
     if (!d_out || width == 0 || width > 32) return fail(SC_ERR_BAD_ARG, "byte strings of 1..32 bytes expected");
     hipStream_t st = pick_stream(stream);
     const size_t bytes = (size_t)count * width;
-    if (g_rand_copied) HIPCHK(hipEventSynchronize(g_rand_copied));            // the previous call's copy has left the buffer
-    if (g_rand_host_bytes < bytes) {
-        if (g_rand_host) { (void)hipHostFree(g_rand_host); g_rand_host = nullptr; g_rand_host_bytes = 0; }
-        HIPCHK(hipHostMalloc((void**)&g_rand_host, bytes, hipHostMallocDefault));
-        g_rand_host_bytes = bytes;
+    if (g_rand_worker.valid() && g_rand_prefetched == bytes) {         // drawn ahead of time: wait for the threads, use the bytes
+        g_rand_worker.get();
+        g_rand_prefetched = 0;
+    } else {
+        SCCHK(rand_buffer(bytes));
+        g_rand_failed = 0;
+        rand_fill(bytes);
     }
-    if (!g_rand_copied) HIPCHK(hipEventCreateWithFlags(&g_rand_copied, hipEventDisableTiming));
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nthreads = bytes / (256u << 10);                                    // at least 256 KiB per thread
-    if (nthreads > 32) nthreads = 32;
-    if (hw && nthreads > hw) nthreads = hw;
-    if (nthreads < 1) nthreads = 1;
-    std::atomic<int> failed{0};
-    auto fill = [&](size_t a, size_t b) {
-        while (a < b) {
-            size_t want = b - a < (1u << 20) ? b - a : (1u << 20);
-            ssize_t r = getrandom(g_rand_host + a, want, 0);
-            if (r < 0) { if (errno == EINTR) continue; failed = 1; return; }
-            a += (size_t)r;
-        }
-    };
-    if (nthreads == 1) fill(0, bytes);
-    else {
-        std::vector<std::thread> pool;
-        const size_t per = (bytes + nthreads - 1) / nthreads;
-        for (size_t i = 0; i < nthreads; ++i) {
-            const size_t a = i * per, b = a + per < bytes ? a + per : bytes;
-            if (a < b) pool.emplace_back(fill, a, b);
-        }
-        for (auto& t : pool) t.join();
-    }
-    if (failed) return fail(SC_ERR_HIP, "getrandom failed");
+    if (g_rand_failed) return fail(SC_ERR_HIP, "getrandom failed");
     void* buf;
     SCCHK(scratch(6, bytes + 256, &buf));
     HIPCHK(hipMemcpyAsync(buf, g_rand_host, bytes, hipMemcpyHostToDevice, st));

@@ -81,6 +81,13 @@ def random_polynomial(count, field, width=17):
     return DevicePolynomial(vec, field, count)
 
 
+def prefetch_random_polynomial(count, width=17):
+    """start the draws of a later random_polynomial(count, ...) on the library's host threads and return (a no-op under a patched
+    os.urandom, whose draws must be made one by one in the reference's order)"""
+    if count > 0 and os_urandom_is_genuine():
+        _sc._check(_sc.lib().sc_urandom_prefetch(count, width))
+
+
 def device_powers(base, count):
     """base^i, i < count, as a DeviceVector (Polynomial.scale of the all-ones vector: no host loop)"""
     ones = DeviceVector.from_bytes((1).to_bytes(16, "little") * count)
@@ -235,6 +242,9 @@ class FastStark:
         # per row -- the caller's list is not touched either way
         if isinstance(trace, DeviceTrace):
             assert(field.p == Field.P_MAIN), "a device-resident trace lives in the main field"
+            # the randomizer polynomial's draws (fast_stark.py:116-117: one os.urandom(17) per coefficient, 36 MB at a 2^24 FRI
+            # domain) start now and pass while the GPU works on the trace
+            prefetch_random_polynomial(self.max_degree(transition_constraints) + 1)
             columns = self._randomized_columns(trace, draw_random_bytes(self.num_randomizers * self.num_registers))
             trace_rows, on_device = len(trace) + self.num_randomizers, True
         else:

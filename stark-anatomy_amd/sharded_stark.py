@@ -355,6 +355,9 @@ class ShardedFastStark(FastStark):
         # randomizer rows appended to the trace (draw order: row by row, register by register)
         raw = self._shared_random_bytes(self.num_randomizers * self.num_registers)
         trace_rows = len(trace) + self.num_randomizers
+        if hasattr(self.steps, "random_polynomial"):
+            # this rank's share of the randomizer polynomial's draws starts now and passes while the GPU works on the trace
+            _fs.prefetch_random_polynomial(-(-(self.max_degree(transition_constraints) + 1) // self.world))
 
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)

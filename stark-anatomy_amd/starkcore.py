@@ -46,6 +46,7 @@ SIGNATURES = {
     "sc_memcpy_dev": (_int, [_vp, _vp, _u64, _vp]),
     "sc_sample_bytes_dev": (_int, [_vp, _u64, ctypes.c_uint32, _vp, _vp]),
     "sc_sample_urandom_dev": (_int, [_u64, ctypes.c_uint32, _vp, _vp]),
+    "sc_urandom_prefetch": (_int, [_u64, ctypes.c_uint32]),
     "sc_ntt": (_int, [_vp, _vp, _u64, _vp, _int]),
     "sc_ntt_dev": (_int, [_vp, _vp, _u64, _vp, _int, _vp]),
     "sc_ntt_batch_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp]),
