@@ -701,3 +701,49 @@ def test_vec_degree_looks_at_the_top_first_and_then_at_the_rest(sc):
                 sc._check(lib.sc_vec_upload(v._h, want // 2, (1).to_bytes(16, "little"), 1))     # a lower non-zero entry must not win
         sc._check(lib.sc_vec_degree_dev(v.ptr, n, ctypes.byref(deg), None))
         assert deg.value == want
+
+
+def test_stream_handle_and_event_join(sc):
+    """sc_stream / sc_stream_join: work enqueued on the library's stream, then consumed on ANOTHER stream with nothing but the
+    event-based join in between (the host waits for the second stream only); and the library stream wrapped as a torch stream"""
+    import torch
+    lib = sc.lib()
+    n = 1 << 20
+    root = po.primitive_nth_root(n)
+    data = synth.synth_packed(321, n).tobytes()
+    want = po.C.ntt(root, data, n)
+    src, dst = sc.DeviceVector.from_bytes(data), sc.DeviceVector(n)
+    assert sc.library_stream() != 0
+    other = torch.cuda.Stream()
+    out = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        sc._check(lib.sc_ntt_dev(src.ptr, dst.ptr, n, sc.fe_bytes(root), 0, None))        # asynchronous, library stream
+        sc.stream_join(other.cuda_stream)
+        sc._check(lib.sc_memcpy_dev(out.data_ptr(), dst.ptr, n, ctypes.c_void_p(other.cuda_stream)))   # on the other stream
+        other.synchronize()
+        assert out.cpu().numpy().tobytes() == want
+        sc._check(lib.sc_vec_zero(dst._h))
+    sc.stream_join(sc.library_stream())                                                   # joining a stream with itself: nothing to do
+    ext = torch.cuda.ExternalStream(sc.library_stream())
+    with torch.cuda.stream(ext):
+        sc._check(lib.sc_ntt_dev(src.ptr, dst.ptr, n, sc.fe_bytes(root), 0, None))
+        t = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+        sc._check(lib.sc_memcpy_dev(t.data_ptr(), dst.ptr, n, None))
+        doubled = t.clone()                                                                # a torch op on the library's stream: ordered by construction
+    ext.synchronize()
+    assert doubled.cpu().numpy().tobytes() == want
+
+
+def test_urandom_prefetch_then_sample(sc):
+    """sc_urandom_prefetch + sc_sample_urandom_dev: the prefetched draws are used when the sizes match, a mismatch draws afresh;
+    canonical residues, no repeats either way"""
+    lib = sc.lib()
+    p = po.P
+    count = (1 << 17) + 11
+    for ahead in (count, count - 5):
+        sc._check(lib.sc_urandom_prefetch(ahead, 17))
+        v = sc.DeviceVector(count)
+        sc._check(lib.sc_sample_urandom_dev(count, 17, v.ptr, None))
+        vals = sc.unpack(v.to_bytes())
+        assert all(0 <= x < p for x in vals) and len(set(vals)) == count
+    sc._check(lib.sc_urandom_prefetch(1000, 17))                                          # left unused: the next call (or shutdown) collects it
