@@ -164,3 +164,47 @@ def test_fuzz_commit_rounds_and_wide_queries(sc):
                     assert pa.raw[po_:po_ + 64 * d] == b"".join(C.merkle_open(d_, m, i))
                 eo += 16
                 po_ += 64 * d
+
+
+def test_fuzz_progressions(sc):
+    """fast_zerofier / fast_evaluate / fast_interpolate on geometric progressions (csrc/geoseq.cuh) with random first points, ratios
+    of every kind (roots of unity of order >= n, arbitrary residues, 2, p - 1 squared away), edge residues among the values, and
+    polynomials shorter and longer than the domain -- through the host-buffer C-ABI entries (which must DETECT the progression) and
+    against the oracle's restatement of the reference recursion"""
+    rng = random.Random(104)
+    lib = sc.lib()
+    order = 1 << 10
+    root = po.primitive_nth_root(order)
+    for trial in range(40):
+        n = rng.choice([2, 3, 5, 8, 13, 32, 33, 64, 100, 129, 200])
+        kind = rng.randrange(4)
+        if kind == 0:
+            q = pow(root, rng.randrange(order) | 1, P)                     # a primitive 2^10-th root: a prefix of a subgroup
+        elif kind == 1:
+            q = pow(po.primitive_nth_root(1 << rng.choice([8, 9, 12, 20])), rng.randrange(1 << 8) | 1, P)
+            if pow(q, 1, P) == 1 or any(pow(q, k, P) == 1 for k in range(1, n)):
+                continue
+        elif kind == 2:
+            q = rng.randrange(2, P)
+        else:
+            q = 2
+        c = rng.choice([1, P - 1, po.GENERATOR, rng.randrange(1, P)])
+        pts, x = [], c
+        for _ in range(n):
+            pts.append(x)
+            x = x * q % P
+        if len(set(pts)) != n:
+            continue
+        out = ctypes.create_string_buffer(16 * (n + 1))
+        sc._check(lib.sc_zerofier(synth.pack_ints(pts), n, out))
+        assert synth.unpack_ints(out.raw) == po.fast_zerofier(pts, root, order), (trial, n, kind)
+        m = rng.choice([0, 1, n // 2, n, n + 1, 2 * n + 3])
+        f = rand_vals(rng, m)
+        sc._check(lib.sc_evaluate(synth.pack_ints(f), m, synth.pack_ints(pts), n, out))
+        assert synth.unpack_ints(out.raw)[:n] == [po.evaluate(f, x) for x in pts], (trial, n, m, kind)
+        vals = rand_vals(rng, n)
+        sc._check(lib.sc_interpolate(synth.pack_ints(pts), synth.pack_ints(vals), n, out))
+        assert synth.unpack_ints(out.raw)[:n] == po.fast_interpolate(pts, vals, root, order), (trial, n, kind)
+        dom = sc.GeoDomain.create(c, q, n)
+        assert dom is not None and synth.unpack_ints(dom.interpolate(sc.DeviceVector.from_bytes(synth.pack_ints(vals))).to_bytes()) == po.fast_interpolate(pts, vals, root, order)
+        dom.free()
