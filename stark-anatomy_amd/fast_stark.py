@@ -14,7 +14,7 @@ from fri import *
 from univariate import *
 from multivariate import *
 from ntt import *
-from ntt import _View
+from ntt import _View, _shrink_order
 import starkcore as _sc
 import proof_objects as _po
 
@@ -121,6 +121,7 @@ class FastStark:
         self._omicron_domain = None
         self._trace_domains = {}          # rows -> DeviceDomain of {omicron^i, i < rows} (progression tables, built once)
         self._lifted = {}                 # id(host Polynomial) -> (the Polynomial, its DevicePolynomial): lifted once, not per proof
+        self._zerofier_values = {}        # transform order -> (the transition zerofier, its values on that order's coset)
 
         self.fri = Fri(self.generator, self.omega, self.fri_domain_length, expansion_factor, num_colinearity_checks)
 
@@ -282,11 +283,10 @@ class FastStark:
         # transition polynomials: AIR evaluated symbolically in (X, trace(X), trace(omicron X)), then quotients
         x = Polynomial([field.zero(), field.one()])
         point = [DevicePolynomial.from_polynomial(x, field) if on_device else x] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
-        transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
         if on_device:
-            tz_dev = self._lift(transition_zerofier)
-            transition_quotients = [coset_divide_device(tp, tz_dev, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
+            transition_quotients = self._transition_quotients_on_device(transition_constraints, point, self._lift(transition_zerofier))
         else:
+            transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
             transition_quotients = [fast_coset_divide(tp, transition_zerofier, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
 
         # randomizer polynomial
@@ -343,6 +343,67 @@ class FastStark:
                 self._open_all(codeword, quadrupled_indices, proof_stream)
 
         return proof_stream.serialize()
+
+    def _transition_quotients_on_device(self, constraints, point, tz_dev):
+        """fast_stark.py:107-113 -- `a.evaluate_symbolic(point)` divided by the transition zerofier -- without ever building the
+        transition polynomial: on the coset g * <root'> (root' of the order code/ntt.py:155-157 shrinks to, taken from the degree
+        BOUND) the point polynomials are evaluated once for all constraints of that order, the AIR is evaluated value by value
+        (mpoly_eval_kernel), divided pointwise by the zerofier's values, and one inverse transform per constraint returns the
+        quotient's coefficients: 4 + 2 transforms for the two-register AIR instead of the 9 + 4 of "substitute, then divide".
+        The same polynomial as the reference's: an exact division gives the same quotient on any coset that is large enough, and
+        its list length is its degree + 1.  Exactness is DECIDED, not assumed: the interpolant Q of the pointwise quotient satisfies
+        Q * Z = transition polynomial as polynomials whenever deg Q <= bound - deg Z (both sides then have degree below the order
+        and agree on the coset); a longer interpolant means the division is not exact (a false witness), and the reference's
+        result then depends on the transition polynomial's true degree -- that constraint goes the reference's way
+        (evaluate_symbolic, then coset_divide_device), as does any shape the kernel does not take (sharded_stark.py does the same
+        on slabs)."""
+        field = self.field
+        reference_way = lambda a: coset_divide_device(a.evaluate_symbolic(point), tz_dev, self.generator, self.omicron, self.omicron_domain_length)
+        degrees = [q.degree() for q in point]
+        dr = tz_dev.degree()
+        out, groups = [None] * len(constraints), {}
+        for i, a in enumerate(constraints):
+            plan = a.value_domain_terms(degrees)
+            if plan is NotImplemented or dr < 0 or plan[0] < max(dr, MPolynomial.VALUE_DOMAIN_MIN_DEGREE):
+                continue
+            bound, terms = plan
+            root, order = _shrink_order(self.omicron, self.omicron_domain_length, max(bound, dr))
+            if len(tz_dev) > order or any(len(q) > order for q in point):
+                continue
+            groups.setdefault(order, (root, []))[1].append((i, bound, terms))
+        lib, gen = _sc.lib(), _sc.fe_bytes(self.generator.value)
+        for order, (root, members) in groups.items():
+            nvars, rt = len(point), _sc.fe_bytes(root.value)
+            used = [any(k[j] for _, _, terms in members for k, _ in terms) for j in range(nvars)]
+            vals = DeviceVector(nvars * order)
+            for j, q in enumerate(point):
+                if used[j]:
+                    _sc._check(lib.sc_coset_evaluate_dev(q.vec.ptr, degrees[j] + 1, gen, rt, order, vals.ptr + 16 * j * order, None))
+            kept = self._zerofier_values.get(order)
+            if kept is not None and kept[0] is tz_dev:
+                zvals = kept[1]
+            else:
+                zvals = DeviceVector(order)
+                _sc._check(lib.sc_coset_evaluate_dev(tz_dev.vec.ptr, dr + 1, gen, rt, order, zvals.ptr, None))
+                if len(self._zerofier_values) >= 4:
+                    self._zerofier_values.clear()
+                self._zerofier_values[order] = (tz_dev, zvals)
+            converted = 0
+            for i, bound, terms in members:
+                exps = bytes(e for k, _ in terms for e in k)
+                coefs = b"".join(v.to_bytes(16, "little") for _, v in terms)
+                tvals, whole = DeviceVector(order), DeviceVector(order)
+                _sc._check(lib.sc_mpoly_eval_ex_dev(vals.ptr, nvars, order, exps, coefs, len(terms), tvals.ptr, converted, None))
+                converted = 1
+                _sc._check(lib.sc_pointwise_div_dev(tvals.ptr, zvals.ptr, tvals.ptr, order, None))      # "divide by zero" like algebra.py:92
+                _sc._check(lib.sc_ntt_dev(tvals.ptr, whole.ptr, order, rt, 1, None))
+                _sc._check(lib.sc_scale_dev(whole.ptr, whole.ptr, order, _sc.fe_bytes(self.generator.inverse().value), None))
+                quotient = DevicePolynomial(whole, field, order)
+                degree = quotient.degree()
+                if degree > bound - dr:
+                    continue                                             # not exact: the reference's way decides what comes out
+                out[i] = DevicePolynomial(whole, field, degree + 1) if degree >= 0 else DevicePolynomial(DeviceVector(1), field, 0)
+        return [q if q is not None else reference_way(a) for q, a in zip(out, constraints)]
 
     def _randomized_columns(self, trace, raw):
         """the columns of a DeviceTrace with the randomizer rows appended (fast_stark.py:79-81): `raw` holds the draws of
