@@ -1802,22 +1802,50 @@ void rand_fill(size_t bytes) {
     }
     for (auto& t : pool) t.join();
 }
-// the staging buffer is free (the previous call's copy has left it, no draw is running) and holds at least `bytes`
+// The device side of the staging: the drawn bytes' own device buffer (never the shared scratch: a prefetched copy is in flight
+// while other calls run), a copy stream, and two events -- `copied`: the bytes have left the pinned buffer and are on the device;
+// `consumed`: the sampling kernel that read them has finished.
+uint8_t* g_rand_dev = nullptr;
+size_t g_rand_dev_bytes = 0;
+hipStream_t g_rand_stream = nullptr;
+hipEvent_t g_rand_consumed = nullptr;
+
+// both buffers are free (no draw running, the previous copy and the previous sampling kernel done) and hold at least `bytes`
 int rand_buffer(size_t bytes) {
     if (g_rand_worker.valid()) { g_rand_worker.get(); g_rand_prefetched = 0; }
     if (g_rand_copied) HIPCHK(hipEventSynchronize(g_rand_copied));
+    if (g_rand_consumed) HIPCHK(hipEventSynchronize(g_rand_consumed));
     if (g_rand_host_bytes < bytes) {
         if (g_rand_host) { (void)hipHostFree(g_rand_host); g_rand_host = nullptr; g_rand_host_bytes = 0; }
         HIPCHK(hipHostMalloc((void**)&g_rand_host, bytes, hipHostMallocDefault));
         g_rand_host_bytes = bytes;
     }
+    if (g_rand_dev_bytes < bytes) {
+        if (g_rand_dev) { (void)hipFree(g_rand_dev); g_rand_dev = nullptr; g_rand_dev_bytes = 0; }
+        HIPCHK(hipMalloc((void**)&g_rand_dev, bytes + 256));
+        g_rand_dev_bytes = bytes;
+    }
     if (!g_rand_copied) HIPCHK(hipEventCreateWithFlags(&g_rand_copied, hipEventDisableTiming));
+    if (!g_rand_consumed) HIPCHK(hipEventCreateWithFlags(&g_rand_consumed, hipEventDisableTiming));
+    if (!g_rand_stream) HIPCHK(hipStreamCreateWithFlags(&g_rand_stream, hipStreamNonBlocking));
     return SC_OK;
+}
+// the prefetch worker: draw, then put the copy to the device on the copy stream (36 MB at a 2^24 FRI domain: 0.7 ms that the
+// compute stream would otherwise sit through, because a stream is in-order)
+void rand_fill_and_copy(size_t bytes, int device) {
+    rand_fill(bytes);
+    if (g_rand_failed) return;
+    if (hipSetDevice(device) != hipSuccess || hipMemcpyAsync(g_rand_dev, g_rand_host, bytes, hipMemcpyHostToDevice, g_rand_stream) != hipSuccess ||
+        hipEventRecord(g_rand_copied, g_rand_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        g_rand_failed = 2;
+    }
 }
 }
 // Start the draws of a later sc_sample_urandom_dev(count, width, ...) NOW, on host threads, and return: the prover calls this at
-// the top of a proof, and the 3 ms of kernel randomness for the randomizer polynomial pass while the GPU interpolates the trace
-// and commits to the boundary quotients.  (Only for the operating system's randomness, which has no order to keep.)
+// the top of a proof, and the 3 ms of kernel randomness for the randomizer polynomial (and their copy to the device) pass while
+// the GPU interpolates the trace and commits to the boundary quotients.  (Only for the operating system's randomness, which has
+// no order to keep.)
 int sc_urandom_prefetch(uint64_t count, uint32_t width) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
@@ -1826,7 +1854,7 @@ int sc_urandom_prefetch(uint64_t count, uint32_t width) {
     SCCHK(rand_buffer(bytes));
     g_rand_failed = 0;
     g_rand_prefetched = bytes;
-    g_rand_worker = std::async(std::launch::async, rand_fill, bytes);
+    g_rand_worker = std::async(std::launch::async, rand_fill_and_copy, bytes, g.device);
     return SC_OK;
 }
 int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* stream) {
@@ -1836,21 +1864,23 @@ int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* str
     if (!d_out || width == 0 || width > 32) return fail(SC_ERR_BAD_ARG, "byte strings of 1..32 bytes expected");
     hipStream_t st = pick_stream(stream);
     const size_t bytes = (size_t)count * width;
-    if (g_rand_worker.valid() && g_rand_prefetched == bytes) {         // drawn ahead of time: wait for the threads, use the bytes
+    if (g_rand_worker.valid() && g_rand_prefetched == bytes) {         // drawn (and copied) ahead of time: wait for the worker, order the stream behind the copy
         g_rand_worker.get();
         g_rand_prefetched = 0;
+        if (g_rand_failed == 1) return fail(SC_ERR_HIP, "getrandom failed");
+        if (g_rand_failed == 2) return fail(SC_ERR_HIP, "copy of the drawn bytes failed");
+        HIPCHK(hipStreamWaitEvent(st, g_rand_copied, 0));
     } else {
         SCCHK(rand_buffer(bytes));
         g_rand_failed = 0;
         rand_fill(bytes);
+        if (g_rand_failed) return fail(SC_ERR_HIP, "getrandom failed");
+        HIPCHK(hipMemcpyAsync(g_rand_dev, g_rand_host, bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(g_rand_copied, st));
     }
-    if (g_rand_failed) return fail(SC_ERR_HIP, "getrandom failed");
-    void* buf;
-    SCCHK(scratch(6, bytes + 256, &buf));
-    HIPCHK(hipMemcpyAsync(buf, g_rand_host, bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipEventRecord(g_rand_copied, st));
-    hipLaunchKernelGGL(sample_bytes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const uint8_t*)buf, count, width, (Fe*)d_out);
+    hipLaunchKernelGGL(sample_bytes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const uint8_t*)g_rand_dev, count, width, (Fe*)d_out);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(g_rand_consumed, st));
     return SC_OK;
 }
 

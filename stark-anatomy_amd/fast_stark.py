@@ -320,19 +320,28 @@ class FastStark:
             combination = reduce(lambda a, b: a + b, [Polynomial([weights[i]]) * terms[i] for i in range(len(terms))], Polynomial([]))
             combined_codeword = self._lde(combination)
 
-        # low-degree test of the combination
-        indices = self.fri.prove(combined_codeword, proof_stream)
-
-        # open the queried positions (and their expansion_factor / half-domain companions)
+        # low-degree test of the combination; the openings of the committed codewords depend on the same sampled indices, so they
+        # are fetched in the query phase's own device round trip (AlsoOpen) when every codeword lives on the device
         N = self.fri.domain_length
-        duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
-        quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
-        quadrupled_indices.sort()
         committed = boundary_quotient_codewords + [randomizer_codeword, transition_zerofier_codeword]
+
+        def opened_positions(indices):
+            # the queried positions and their expansion_factor / half-domain companions (fast_stark.py:154-158)
+            duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
+            quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
+            quadrupled_indices.sort()
+            return quadrupled_indices
+        together = None
+        if all(_po.eligible(codeword) for codeword in committed) and type(proof_stream) is ProofStream:
+            together = AlsoOpen(lambda indices: (committed, [opened_positions(indices)] * len(committed)))
+        indices = self.fri.prove(combined_codeword, proof_stream, together) if together is not None else self.fri.prove(combined_codeword, proof_stream)
+
+        quadrupled_indices = opened_positions(indices)
         lazy = _po.lazy_objects(proof_stream) if all(_po.eligible(codeword) for codeword in committed) else None
         if lazy is not None:
             # the device's answers as they are (proof_objects.Openings): same transcript bytes, no object per digest
-            for codeword, (values, paths) in zip(committed, _sc.query_codewords_raw(committed, [quadrupled_indices] * len(committed))):
+            answers = together.answers if together is not None and together.answers is not None else _sc.query_codewords_raw(committed, [quadrupled_indices] * len(committed))
+            for codeword, (values, paths) in zip(committed, answers):
                 lazy.add(_po.Openings(codeword, quadrupled_indices, values, paths))
         elif all(isinstance(codeword, DeviceCodeword) for codeword in committed):
             # every codeword's openings in ONE device round trip; pushed leaf, path, leaf, path, ... codeword by codeword

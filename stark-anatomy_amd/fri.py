@@ -19,6 +19,14 @@ import proof_objects as _po
 from starkcore import DeviceCodeword, DeviceVector, query_codewords
 
 
+class AlsoOpen:
+    """Openings a caller wants together with the query phase: `requests(top_level_indices)` -> (codewords, index lists); `answers`
+    = [(packed residues, paths array)] per codeword once the query phase has fetched them, or None if it took another route"""
+
+    def __init__(self, requests):
+        self.requests, self.answers = requests, None
+
+
 class Fri:
     def __init__(self, offset, omega, initial_domain_length, expansion_factor, num_colinearity_tests):
         self.offset, self.omega, self.field = offset, omega, omega.field
@@ -169,14 +177,16 @@ class Fri:
                 proof_stream.push(path)
         return lower + upper
 
-    def prove(self, codeword, proof_stream):
+    def prove(self, codeword, proof_stream, also_open=None):
+        """also_open (optional, an AlsoOpen): further device codewords to open at positions that depend on the sampled indices --
+        FastStark's committed codewords (fast_stark.py:154-175) -- fetched in the SAME device round trip as the query phase"""
         assert(self.domain_length == len(codeword)), "initial codeword length does not match length of initial codeword"
         codewords = self.commit(codeword, proof_stream)
         top_level_indices = self.sample_indices(proof_stream.prover_fiat_shamir(), len(codewords[0]) // 2, len(codewords[-1]), self.num_colinearity_tests)
-        self._query_all(codewords, top_level_indices, proof_stream)
+        self._query_all(codewords, top_level_indices, proof_stream, also_open)
         return top_level_indices
 
-    def _query_all(self, codewords, top_level_indices, proof_stream):
+    def _query_all(self, codewords, top_level_indices, proof_stream, also_open=None):
         """The query phase of fri.py:124-128 with ONE device round trip for all rounds: everything a codeword has to open
         (its a/b entries for its own round, the c entries of the previous round) is fetched together, then pushed in the
         reference's order (per round: s triples, then 3*s paths as a, b, c)."""
@@ -198,7 +208,10 @@ class Fri:
         if lazy is not None:
             # the device's answers go into the stream as they are: residues and paths stay packed, the transcript is pickled from
             # their description (proof_objects.FriRound); the reference's objects exist only if somebody reads them
-            fetched = _sc.query_codewords_raw(codewords, requests)
+            more_codewords, more_requests = also_open.requests(top_level_indices) if also_open is not None else ([], [])
+            fetched = _sc.query_codewords_raw(list(codewords) + list(more_codewords), requests + list(more_requests))
+            if also_open is not None:
+                also_open.answers = fetched[len(codewords):]
             for i in range(rounds):
                 values, paths = fetched[i]
                 next_values, next_paths = fetched[i + 1]

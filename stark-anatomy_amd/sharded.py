@@ -1019,7 +1019,9 @@ class ShardedFri:
         return self._open_many([(layer, indices)])[0]
 
     # -- the protocol -----------------------------------------------------------------------------
-    def prove(self, slab, proof_stream):
+    def prove(self, slab, proof_stream, also_open=None):
+        """also_open (a fri.AlsoOpen whose `requests` returns (layer records, index lists)): further committed layers opened in the
+        same library call and collective as the query phase"""
         from algebra import FieldElement
         fr, eng, field = self.fri, self.engine, self.fri.field
         N, R, Rw = fr.domain_length, self.R, self.Rw
@@ -1065,7 +1067,7 @@ class ShardedFri:
             # described, not built (proof_objects): the transcript bytes are the same, no object per element / digest
             import starkcore as _scm
             lazy.add(_po.ElementList(self._holder(last_layer, field), _scm.pack(last_values)))
-            return self._query_all_lazy(layers, len(last_values), proof_stream, lazy)
+            return self._query_all_lazy(layers, len(last_values), proof_stream, lazy, also_open)
         last_list = [FieldElement(v, field) for v in last_values]
         last_layer["cache"] = dict(enumerate(last_list))
         proof_stream.push(last_list)
@@ -1092,12 +1094,17 @@ class ShardedFri:
             requests.append((layer, request))
         return top_level_indices, per_round, requests
 
-    def _query_all_lazy(self, layers, last_length, proof_stream, lazy):
+    def _query_all_lazy(self, layers, last_length, proof_stream, lazy, also_open=None):
         """_query_all with the owners' answers pushed as they are (proof_objects.FriRound)"""
         import proof_objects as _po
         field, s = self.fri.field, self.fri.num_colinearity_tests
         top_level_indices, per_round, requests = self._query_requests(layers, last_length, proof_stream)
+        if also_open is not None:
+            more_layers, more_indices = also_open.requests(top_level_indices)
+            requests = requests + list(zip(more_layers, more_indices))
         fetched = self._open_many_arrays(requests)
+        if also_open is not None:
+            also_open.answers = fetched[len(layers):]
         nq = len(layers) - 1
         for i in range(nq):
             values, paths = fetched[i]

@@ -406,21 +406,30 @@ class ShardedFastStark(FastStark):
         slab = torch.empty(self.ntt_fri.local_shape(False), dtype=torch.int64, device=self.device)
         self.ntt_fri.coset_evaluate(self._tensor(combination), self.generator.value, slab)
         self._mark("LDE of the combination (sharded)")
-        indices = self.sfri.prove(slab, proof_stream)
-        self._mark("FRI: commit + query phases (sharded)")
-
-        # open the queried positions (and their expansion_factor / half-domain companions) on every committed codeword
+        # the openings of the committed codewords depend on the same sampled indices as the query phase: fetched with it, in ONE
+        # library call and ONE collective (fri.AlsoOpen), when the stream takes the device's answers as they are
         N = self.fri.domain_length
-        duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
-        quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
-        quadrupled_indices.sort()
         layers = boundary_layers + [randomizer_layer, transition_zerofier_layer]
-        # ONE library call and ONE collective for all the codewords' openings; pushed leaf, path, leaf, path, ... per codeword
+
+        def opened_positions(indices):
+            # the queried positions and their expansion_factor / half-domain companions (fast_stark.py:154-158)
+            duplicated_indices = [i for i in indices] + [(i + self.expansion_factor) % N for i in indices]
+            quadrupled_indices = [i for i in duplicated_indices] + [(i + (N // 2)) % N for i in duplicated_indices]
+            quadrupled_indices.sort()
+            return quadrupled_indices
         import proof_objects as _po
+        together = None
+        if hasattr(self.sfri.engine, "query_many") and type(proof_stream) is ProofStream:
+            together = AlsoOpen(lambda indices: (layers, [opened_positions(indices)] * len(layers)))
+        indices = self.sfri.prove(slab, proof_stream, together) if together is not None else self.sfri.prove(slab, proof_stream)
+        self._mark("FRI: commit + query phases (sharded), openings fetched with them")
+
+        quadrupled_indices = opened_positions(indices)
         lazy = _po.lazy_objects(proof_stream) if hasattr(self.sfri.engine, "query_many") else None
         if lazy is not None:
             # the owners' answers as they are (proof_objects.Openings): same transcript bytes, no object per digest
-            for layer, (values, paths) in zip(layers, self.sfri._open_many_arrays([(layer, quadrupled_indices) for layer in layers])):
+            answers = together.answers if together is not None and together.answers is not None else self.sfri._open_many_arrays([(layer, quadrupled_indices) for layer in layers])
+            for layer, (values, paths) in zip(layers, answers):
                 lazy.add(_po.Openings(self.sfri._holder(layer, field), quadrupled_indices, values, paths))
             layers = []
         for entries, paths in self.sfri._open_many([(layer, quadrupled_indices) for layer in layers]) if layers else []:
