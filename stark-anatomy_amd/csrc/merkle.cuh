@@ -161,6 +161,12 @@ __device__ __forceinline__ uint64_t sel6(const uint64_t W[6], uint32_t idx) {
 
 // Decimal ASCII of a canonical residue into the first words of a zeroed BLAKE2b block; returns the length.
 __device__ __forceinline__ uint32_t leaf_message(Fe x, uint64_t m[16]) {
+#ifdef SC_LEAF_ABLATION   // measurement only (wrong digests): what the tree would cost if the decimal conversion were free
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = 0;
+    m[0] = x.lo; m[1] = x.hi; m[2] = x.lo ^ 0x3030303030303030ull; m[3] = x.hi | 0x3030303030303030ull; m[4] = x.lo + x.hi;
+    return 39;
+#endif
     uint32_t d[4] = {(uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.hi, (uint32_t)(x.hi >> 32)};
     uint32_t grp[5];   // base-10^9 digits, least significant first
     // Long division by 10^9, limb by limb.  The quotient loses ~29.9 bits per group, so for ANY 128-bit input its top limbs
