@@ -59,6 +59,48 @@ def _codeword_uid(cw):
 _codeword_uid.counter = 0
 
 
+class _Entries:
+    """What a segment keeps of the codeword it describes: its field, its identity, and a WEAK reference -- a proof stream that
+    somebody holds on to must not keep gigabytes of device memory (the codeword, its Merkle tree) alive, which the object path
+    never did.  Objects are made through the codeword's own cache while it lives (so `cw[i]` and the stream's entry are one
+    object), through a cache of this holder's afterwards.  One holder per codeword (`cw._proof_entries`)."""
+    _full = None
+
+    def __init__(self, codeword):
+        import weakref
+        self.field, self._uid = codeword.field, _codeword_uid(codeword)
+        self._alive = weakref.ref(codeword)
+        # the codeword's OWN cache of entry objects (index -> FieldElement), shared: whatever the codeword hands out -- to the
+        # object path of a mixed stream, to a caller indexing it -- is the object this holder hands out, also after the codeword
+        # is gone (DeviceCodeword.tolist, which retires that cache, copies its objects here first)
+        self._own = codeword._elems if codeword._elems is not None else dict(enumerate(codeword._full))
+
+    def _entries(self, indices, values):
+        cw = self._alive()
+        if cw is not None:
+            return cw._entries(indices, values)
+        from algebra import FieldElement
+        own, field, new = self._own, self.field, object.__new__
+        for i, v in zip(indices, values):
+            if i not in own:
+                e = new(FieldElement)
+                e.value = v
+                e.field = field
+                own[i] = e
+        return [own[i] for i in indices]
+
+
+def entries_of(codeword):
+    """the holder a segment keeps instead of the codeword itself (holders that are not device codewords -- the sharded prover's
+    layer caches -- are kept as they are: they hold no device memory)"""
+    if not isinstance(codeword, _sc.DeviceCodeword):
+        return codeword
+    holder = getattr(codeword, "_proof_entries", None)
+    if holder is None:
+        holder = codeword._proof_entries = _Entries(codeword)
+    return holder
+
+
 def _element_ops(ctx, cw, indices, values):
     """the 'E' records of entries `indices` of device codeword `cw` (values: packed residues, 16 bytes each)"""
     k = len(indices)
@@ -90,7 +132,7 @@ class ElementList:
     count = 1
 
     def __init__(self, codeword, values):
-        self.cw, self.values = codeword, values
+        self.cw, self.values = entries_of(codeword), values
 
     def ops(self, ctx):
         n = len(self.values) // 16
@@ -106,7 +148,7 @@ class FriRound:
     authentication paths of a, b, c"""
 
     def __init__(self, current, following, idx_a, idx_b, idx_c, val_a, val_b, val_c, paths_a, paths_b, paths_c):
-        self.cur, self.nxt = current, following
+        self.cur, self.nxt = entries_of(current), entries_of(following)
         self.idx = (idx_a, idx_b, idx_c)
         self.val = (val_a, val_b, val_c)
         self.paths = (paths_a, paths_b, paths_c)
@@ -142,7 +184,7 @@ class Openings:
     """leaf, path, leaf, path, ... of one committed codeword (fast_stark.py:154-175)"""
 
     def __init__(self, codeword, indices, values, paths):
-        self.cw, self.indices, self.values, self.paths = codeword, indices, values, paths
+        self.cw, self.indices, self.values, self.paths = entries_of(codeword), indices, values, paths
         self.count = 2 * len(indices)
 
     def ops(self, ctx):

@@ -702,6 +702,9 @@ class DeviceCodeword(Sequence):
             known = self._elems
             ints = unpack(self.vec.to_bytes(), self.vec.n)
             self._full = [known[i] if i in known else self._fe(v) for i, v in enumerate(ints)]
+            holder = getattr(self, "_proof_entries", None)
+            if holder is not None:                          # a proof stream describes entries of this codeword: it shares the
+                known.update(enumerate(self._full))         # cache that is retired here and must know every object
             self._elems = None
         return self._full
 

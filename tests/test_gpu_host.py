@@ -341,6 +341,36 @@ def test_fri_commit_with_a_proof_stream_subclass_and_a_long_transcript(monkeypat
     del n_calls
 
 
+def test_a_kept_proof_stream_does_not_keep_the_codewords(monkeypatch):
+    """The proof stream of Fri.prove describes the device's answers (proof_objects); somebody who keeps the stream must not keep the
+    codewords and their Merkle trees alive with it (the object path never did): the segments refer to the codewords weakly, and the
+    stream still serializes to the same bytes, materialises and verifies after the codewords are gone."""
+    import gc
+    import weakref
+    import starkcore as sc
+    rec = [r for r in load_golden("fri.json")["prove_synth"] if r["logN"] == 12][0]
+    N = 1 << rec["logN"]
+    om = field.primitive_nth_root(N)
+    poly = Polynomial([FieldElement(v, field) for v in synth.synth_ints(rec["coeff_seed"], N // 4)])
+    fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+    cw = fast_coset_evaluate_device(poly, field.generator(), om, N)
+    seen = []
+    real = Fri.commit
+    monkeypatch.setattr(Fri, "commit", lambda self, *a, **k: (lambda out: (seen.extend(weakref.ref(c) for c in out), out)[1])(real(self, *a, **k)))
+    ps = ProofStream()
+    top = fr.prove(cw, ps)
+    assert top == rec["top_level_indices"] and len(seen) == fr.num_rounds()
+    before = ps.serialize()
+    assert hashlib.sha256(before).hexdigest() == rec["serialized_sha256"]
+    del cw
+    gc.collect()
+    assert all(ref() is None for ref in seen), "the proof stream keeps codewords (and their trees) alive"
+    assert ps.serialize() == before                        # described from packed answers, not from the codewords
+    assert fr.verify(ps, []) is True                       # materialised without them: objects from the stream's own caches
+    import pickle
+    assert pickle.dumps(list(ps.objects)) == before
+
+
 def test_merkle_through_host_api():
     g = load_golden("merkle.json")
     for rec in g["commit"]:
