@@ -27,6 +27,13 @@
 //   'T'                      a tuple of the 3 items that follow
 //   'E' u32 field  u64 key  16 bytes   a FieldElement: `key` names the OBJECT (equal keys = the same object, pickled once and
 //                            referred to afterwards), value = two u64 limbs; `field` indexes the table of field moduli
+// and, inside a list only, two ops that stand for MANY of its items with their payload packed (what the provers push):
+//   'R' u32 s  u32 field  u64 key_base_cur  u64 key_base_next  u32 d_cur  u32 d_next  | u32 idx_a[s] idx_b[s] idx_c[s] | values of
+//       a, b, c (16 s each) | paths of a, b (64 d_cur s each), of c (64 d_next s)
+//                            one round of the FRI query phase (fri.py:98-113): s tuples (cur[a], cur[b], next[c]), then per
+//                            test the paths of a, b, c -- 4 s items; an element's key is key_base | index
+//   'O' u32 k  u32 field  u64 key_base  u32 depth  | u32 idx[k] | values 16 k | paths 64 depth k
+//                            leaf, path, leaf, path, ... of one committed codeword (fast_stark.py:154-175): 2 k items
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -175,10 +182,79 @@ struct ProofPickler {
         put(0x62);                                         // BUILD
     }
 
-    // one item of the description at p; returns the position behind it (nullptr: malformed)
-    const uint8_t* item(const uint8_t* p, const uint8_t* end) {
+    // A list being written (batch_list_exact of _pickle.c): one item -> item APPEND; else MARK items... APPENDS in batches of 1000.
+    // The ops of a list may produce several of its items each ('R', 'O'), so the batching is driven item by item.
+    struct ListCtx { uint32_t count, done, batch; };
+    void item_begin(ListCtx& L) { if (L.count != 1 && L.batch == 0) put(0x28); }      // MARK
+    void item_end(ListCtx& L) {
+        ++L.done;
+        if (L.count == 1) { put(0x61); return; }                                       // APPEND
+        if (++L.batch == 1000 || L.done == L.count) { put(0x65); L.batch = 0; }         // APPENDS
+    }
+    void save_path(const uint8_t* raw, uint32_t depth) {
+        boundary(); put(0x5d); memoize();                                              // EMPTY_LIST MEMOIZE
+        ListCtx L{depth, 0, 0};
+        for (uint32_t i = 0; i < depth; ++i) { item_begin(L); save_bytes(raw + (size_t)i * 64, 64); item_end(L); }
+    }
+
+    // one op of the description at p, writing into list L (nullptr: an op that is not inside a list -- it must produce exactly
+    // one item); returns the position behind it (nullptr: malformed)
+    const uint8_t* item(const uint8_t* p, const uint8_t* end, ListCtx* L = nullptr) {
         if (p >= end) return nullptr;
         const uint8_t op = *p++;
+        auto u32 = [&](uint32_t* v) { if (end - p < 4) return false; memcpy(v, p, 4); p += 4; return true; };
+        auto u64 = [&](uint64_t* v) { if (end - p < 8) return false; memcpy(v, p, 8); p += 8; return true; };
+        if (op == 'R' || op == 'O') {                      // several items of the enclosing list
+            if (!L) return nullptr;
+            uint32_t k, f;
+            if (!u32(&k) || !u32(&f) || f >= nfields) return nullptr;
+            if (op == 'O') {
+                // 'O' k field key_base depth | idx u32[k] | values 16k | paths 64*depth*k :  leaf, path, leaf, path, ...
+                uint64_t base; uint32_t depth;
+                if (!u64(&base) || !u32(&depth)) return nullptr;
+                const size_t need = (size_t)k * (4 + 16 + (size_t)64 * depth);
+                if ((size_t)(end - p) < need || L->done + 2ull * k > L->count) return nullptr;
+                const uint8_t *idx = p, *val = p + 4ull * k, *path = val + 16ull * k;
+                for (uint32_t t = 0; t < k; ++t) {
+                    uint32_t i; memcpy(&i, idx + 4ull * t, 4);
+                    item_begin(*L); save_element(f, base | i, val + 16ull * t); item_end(*L);
+                    item_begin(*L); save_path(path + (size_t)t * 64 * depth, depth); item_end(*L);
+                }
+                return p + need;
+            }
+            // 'R' s field key_base_cur key_base_next d_cur d_next | idx_a idx_b idx_c u32[s] | val_a val_b val_c 16s |
+            //     paths_a paths_b 64*d_cur*s | paths_c 64*d_next*s :  s triples (cur[a], cur[b], next[c]), then per test the three paths
+            uint64_t bc, bn; uint32_t dc, dn;
+            if (!u64(&bc) || !u64(&bn) || !u32(&dc) || !u32(&dn)) return nullptr;
+            const size_t need = (size_t)k * (12 + 48 + (size_t)64 * (2 * dc + dn));
+            if ((size_t)(end - p) < need || L->done + 4ull * k > L->count) return nullptr;
+            const uint8_t *ia = p, *ib = ia + 4ull * k, *ic = ib + 4ull * k, *va = ic + 4ull * k, *vb = va + 16ull * k, *vc = vb + 16ull * k;
+            const uint8_t *pa = vc + 16ull * k, *pb = pa + (size_t)64 * dc * k, *pc = pb + (size_t)64 * dc * k;
+            for (uint32_t t = 0; t < k; ++t) {
+                uint32_t a, b_, c;
+                memcpy(&a, ia + 4ull * t, 4); memcpy(&b_, ib + 4ull * t, 4); memcpy(&c, ic + 4ull * t, 4);
+                item_begin(*L);
+                boundary();                                // save(tuple)
+                save_element(f, bc | a, va + 16ull * t);
+                save_element(f, bc | b_, vb + 16ull * t);
+                save_element(f, bn | c, vc + 16ull * t);
+                put(0x87); memoize();                      // TUPLE3 MEMOIZE
+                item_end(*L);
+            }
+            for (uint32_t t = 0; t < k; ++t) {
+                item_begin(*L); save_path(pa + (size_t)t * 64 * dc, dc); item_end(*L);
+                item_begin(*L); save_path(pb + (size_t)t * 64 * dc, dc); item_end(*L);
+                item_begin(*L); save_path(pc + (size_t)t * 64 * dn, dn); item_end(*L);
+            }
+            return p + need;
+        }
+        if (L) item_begin(*L);
+        const uint8_t* q = single(op, p, end);
+        if (q && L) item_end(*L);
+        return q;
+    }
+    // the ops that are exactly one object
+    const uint8_t* single(uint8_t op, const uint8_t* p, const uint8_t* end) {
         auto u32 = [&](uint32_t* v) { if (end - p < 4) return false; memcpy(v, p, 4); p += 4; return true; };
         switch (op) {
             case 'B': {
@@ -190,17 +266,16 @@ struct ProofPickler {
             case 'D': {
                 uint32_t depth;
                 if (!u32(&depth) || (size_t)(end - p) < (size_t)depth * 64) return nullptr;
-                boundary(); put(0x5d); memoize();          // EMPTY_LIST MEMOIZE
-                list_items(depth, [&](uint32_t i) { save_bytes(p + (size_t)i * 64, 64); return true; });
+                save_path(p, depth);
                 return p + (size_t)depth * 64;
             }
             case 'L': {
                 uint32_t count;
                 if (!u32(&count)) return nullptr;
-                boundary(); put(0x5d); memoize();
-                bool ok = true;
-                list_items(count, [&](uint32_t) { p = item(p, end); ok = ok && p != nullptr; return ok; });
-                return ok ? p : nullptr;
+                boundary(); put(0x5d); memoize();          // EMPTY_LIST MEMOIZE
+                ListCtx L{count, 0, 0};
+                while (L.done < count) { p = item(p, end, &L); if (!p) return nullptr; }
+                return p;
             }
             case 'T': {
                 boundary();
@@ -217,22 +292,6 @@ struct ProofPickler {
                 return p + 24;
             }
             default: return nullptr;
-        }
-    }
-    // batch_list_exact of _pickle.c: one item -> item APPEND; else batches of 1000 between MARK and APPENDS
-    template <class F> void list_items(uint32_t count, F save_one) {
-        if (count == 0) return;
-        if (count == 1) { if (save_one(0)) put(0x61); return; }
-        uint32_t done = 0;
-        while (done < count) {
-            put(0x28);
-            uint32_t batch = 0;
-            while (done < count) {
-                if (!save_one(done)) return;
-                ++done;
-                if (++batch == 1000) break;
-            }
-            put(0x65);
         }
     }
     bool run(const uint8_t* ops, size_t len) {

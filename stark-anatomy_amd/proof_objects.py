@@ -16,6 +16,7 @@ residues, packed paths -- as SEGMENTS of a `LazyProofObjects`, which
 Anything it cannot describe (an object of another type pushed by the caller) makes it fall back to materialise + `pickle.dumps`.
 """
 import pickle
+import struct as _struct
 
 import numpy as np
 
@@ -156,22 +157,18 @@ class FriRound:
         self.count = 4 * self.s
 
     def ops(self, ctx):
+        """the 'R' op of csrc/proof_pickle.h: header, the three index lists, the packed residues and paths as they came back"""
         s = self.s
         if s == 0:
             return b""
         d_cur, d_nxt = self.paths[0].shape[1] // 64, self.paths[2].shape[1] // 64
-        triple = np.dtype([("t", "u1"), ("a", _E), ("b", _E), ("c", _E)])
-        t = np.empty(s, dtype=triple)
-        t["t"] = ord("T")
-        t["a"] = _element_ops(ctx, self.cur, self.idx[0], self.val[0])
-        t["b"] = _element_ops(ctx, self.cur, self.idx[1], self.val[1])
-        t["c"] = _element_ops(ctx, self.nxt, self.idx[2], self.val[2])
-        trio = np.dtype([("a", _path_dtype(d_cur)), ("b", _path_dtype(d_cur)), ("c", _path_dtype(d_nxt))])
-        p = np.empty(s, dtype=trio)
-        p["a"] = _path_ops(self.paths[0], d_cur)
-        p["b"] = _path_ops(self.paths[1], d_cur)
-        p["c"] = _path_ops(self.paths[2], d_nxt)
-        return t.tobytes() + p.tobytes()
+        f = ctx.field_index(self.cur.field)
+        if ctx.field_index(self.nxt.field) != f:
+            raise _Unsupported("two fields in one round")
+        head = _struct.pack("<cIIQQII", b"R", s, f, _codeword_uid(self.cur) << 32, _codeword_uid(self.nxt) << 32, d_cur, d_nxt)
+        idx = np.asarray(self.idx, dtype=np.uint32).tobytes()
+        return b"".join((head, idx, bytes(self.val[0]), bytes(self.val[1]), bytes(self.val[2]),
+                         self.paths[0].tobytes(), self.paths[1].tobytes(), self.paths[2].tobytes()))
 
     def materialize(self):
         s = self.s
@@ -188,15 +185,13 @@ class Openings:
         self.count = 2 * len(indices)
 
     def ops(self, ctx):
+        """the 'O' op of csrc/proof_pickle.h"""
         k = len(self.indices)
         if k == 0:
             return b""
         depth = self.paths.shape[1] // 64
-        pair = np.dtype([("e", _E), ("p", _path_dtype(depth))])
-        rec = np.empty(k, dtype=pair)
-        rec["e"] = _element_ops(ctx, self.cw, self.indices, self.values)
-        rec["p"] = _path_ops(self.paths, depth)
-        return rec.tobytes()
+        head = _struct.pack("<cIIQI", b"O", k, ctx.field_index(self.cw.field), _codeword_uid(self.cw) << 32, depth)
+        return b"".join((head, np.asarray(self.indices, dtype=np.uint32).tobytes(), bytes(self.values), self.paths.tobytes()))
 
     def materialize(self):
         k = len(self.indices)
