@@ -192,15 +192,18 @@ class Fri:
         reference's order (per round: s triples, then 3*s paths as a, b, c)."""
         s = self.num_colinearity_tests
         rounds = len(codewords) - 1
+        halves = [len(cw) // 2 for cw in codewords]           # (len() of a device codeword is a call into the binding: once each)
         per_round, indices = [], [index for index in top_level_indices]
         for i in range(rounds):
-            indices = [index % (len(codewords[i]) // 2) for index in indices]
+            half = halves[i]
+            indices = [index % half for index in indices]
             per_round.append(indices)
         requests = []
-        for j, cw in enumerate(codewords):
+        for j in range(len(codewords)):
             request = []
             if j < rounds:
-                request += per_round[j][:s] + [index + len(cw) // 2 for index in per_round[j][:s]]
+                half = halves[j]
+                request += per_round[j][:s] + [index + half for index in per_round[j][:s]]
             if j > 0:
                 request += per_round[j - 1][:s]
             requests.append(request)
@@ -217,7 +220,7 @@ class Fri:
                 next_values, next_paths = fetched[i + 1]
                 c_at = 2 * s if i + 1 < rounds else 0
                 a = per_round[i][:s]
-                half = len(codewords[i]) // 2
+                half = halves[i]
                 lazy.add(_po.FriRound(codewords[i], codewords[i + 1], a, [index + half for index in a], a,
                                       values[:16 * s], values[16 * s:32 * s], next_values[16 * c_at:16 * (c_at + s)],
                                       paths[:s], paths[s:2 * s], next_paths[c_at:c_at + s]))

@@ -386,11 +386,12 @@ def query_codewords_raw(codewords, requests):
         return [(b"", np.zeros((0, 64 * t.depth), dtype=np.uint8)) for t in trees]
     depths = [t.depth for t in trees]
     path_bytes = sum(64 * d * len(req) for d, req in zip(depths, requests))
-    elems = ctypes.create_string_buffer(16 * total)
-    paths = ctypes.create_string_buffer(path_bytes if path_bytes else 64)
+    elems = np.empty(16 * total, dtype=np.uint8)                  # (uninitialised: the library fills every byte it is asked for;
+    raw_p = np.empty(path_bytes if path_bytes else 64, dtype=np.uint8)   # a zeroed ctypes buffer of megabytes is a memset for nothing)
     _check(lib().sc_merkle_query_multi_dev(n, (_vp * n)(*[t._h for t in trees]), (_vp * n)(*[cw.vec.ptr for cw in codewords]),
-                                           (ctypes.c_uint64 * total).from_buffer(flat), (ctypes.c_uint64 * n)(*[len(req) for req in requests]), elems, paths))
-    raw_e, raw_p = elems.raw, np.frombuffer(paths, dtype=np.uint8)
+                                           (ctypes.c_uint64 * total).from_buffer(flat), (ctypes.c_uint64 * n)(*[len(req) for req in requests]),
+                                           _vp(elems.ctypes.data), _vp(raw_p.ctypes.data)))
+    raw_e = elems.tobytes()
     out, vo, po = [], 0, 0
     for req, d in zip(requests, depths):
         k = len(req)
