@@ -150,8 +150,12 @@ int sc_fourstep_run_dev(const sc_fourstep_t* plan, int inverse, const void* d_sr
  * rank's flag at every peer and waits for theirs (system-scope atomics), and the row stage reads the rank's own receive buffer.
  * Consecutive transforms alternate between the two receive buffers, so a peer's next column stage never overwrites what a row
  * stage is still reading.  Every rank must run the same transforms in the same order.  A barrier that waits ~2 s for a peer
- * gives up (sc_fourstep_direct_status reports the epoch); the transform's output is then undefined. */
+ * gives up (sc_fourstep_direct_status reports the epoch); the transform's output is then undefined.
+ * The region is FINE-GRAINED device memory (hipExtMallocWithFlags, as RCCL's peer-written buffers are): peers write into it
+ * while this GPU's kernels poll and read it.  STARKCORE_IPC_COARSE=1 selects plain hipMalloc instead (A/B on real peers);
+ * sc_ipc_region_kind: 1 fine-grained, 0 coarse-grained, -1 no region created yet. */
 int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]);
+int sc_ipc_region_kind(int* fine_grained);
 int sc_ipc_region_open(const uint8_t handle[64], void** d_region);
 int sc_ipc_region_close(void* d_region);        /* a region opened from a peer's handle */
 int sc_ipc_region_free(void* d_region);         /* a region this process created */

@@ -2331,19 +2331,43 @@ __global__ void __launch_bounds__(64) ipc_barrier_kernel(IpcFlags flags, int ran
     __threadfence_system();
 }
 
+static int g_ipc_fine_grained = -1;      // the kind of the last region created: 1 fine-grained, 0 coarse-grained, -1 none yet
 int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!bytes || !d_region || !handle_out) return fail(SC_ERR_BAD_ARG, "null argument");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
+    // FINE-GRAINED device memory: other GPUs store into this region and raise flags in it WHILE kernels of this GPU poll and read
+    // it.  Coarse-grained memory (plain hipMalloc) is only promised coherent between agents at kernel boundaries -- this GPU's L2
+    // may keep serving a line a peer has rewritten -- which is why RCCL allocates the buffers its peers write into the same way.
+    // STARKCORE_IPC_COARSE=1 selects plain hipMalloc (for an A/B on a node with several GPUs); a runtime that cannot export a
+    // fine-grained allocation falls back to it as well.  sc_ipc_region_kind() tells which one the last region got.
+    const char* coarse_env = getenv("STARKCORE_IPC_COARSE");
+    const bool want_fine = !(coarse_env && coarse_env[0] == '1');
     void* p = nullptr;
-    HIPCHK(hipMalloc(&p, bytes));
-    hipError_t e = hipMemset(p, 0, bytes);
     hipIpcMemHandle_t h;
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
-    if (e != hipSuccess) { (void)hipFree(p); return fail(SC_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+    hipError_t e = hipErrorUnknown;
+    if (want_fine) {
+        e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+        if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+        if (e != hipSuccess) { if (p) (void)hipFree(p); p = nullptr; (void)hipGetLastError(); }
+        else g_ipc_fine_grained = 1;
+    }
+    if (!p) {
+        HIPCHK(hipMalloc(&p, bytes));
+        e = hipMemset(p, 0, bytes);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+        if (e != hipSuccess) { (void)hipFree(p); return fail(SC_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+        g_ipc_fine_grained = 0;
+    }
     memcpy(handle_out, &h, 64);
     *d_region = p;
+    return SC_OK;
+}
+int sc_ipc_region_kind(int* fine_grained) {
+    if (!fine_grained) return fail(SC_ERR_BAD_ARG, "null argument");
+    *fine_grained = g_ipc_fine_grained;
     return SC_OK;
 }
 int sc_ipc_region_open(const uint8_t handle[64], void** d_region) {

@@ -181,6 +181,12 @@ class HipFourstep:
             self.direct = True
         return bool(ok)
 
+    def region_kind(self):
+        """'fine-grained' / 'coarse-grained': the kind of device memory the last receive region of this process got"""
+        v = self.ct.c_int(-1)
+        self.sc._check(self.lib.sc_ipc_region_kind(self.ct.byref(v)))
+        return {1: "fine-grained", 0: "coarse-grained"}.get(int(v.value), "none")
+
     def run_direct(self, inverse, src, dst):
         self.sc._check(self.lib.sc_fourstep_run_direct_dev(self._h, inverse, src.data_ptr(), dst.data_ptr(), self.sptr))
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sc_fourstep_create_ex": (_int, [_int, _vp, _int, _int, _int, ctypes.POINTER(_vp)]),
     "sc_ipc_region_create": (_int, [_u64, ctypes.POINTER(_vp), _vp]),
     "sc_ipc_region_open": (_int, [_vp, ctypes.POINTER(_vp)]),
+    "sc_ipc_region_kind": (_int, [ctypes.POINTER(_int)]),
     "sc_ipc_region_close": (_int, [_vp]),
     "sc_ipc_region_free": (_int, [_vp]),
     "sc_fourstep_region_bytes": (_int, [_vp, ctypes.POINTER(_u64)]),

@@ -353,7 +353,7 @@ def test_sharded_lde_then_sharded_fri_one_rank(sc):
     assert hashlib.sha256(ps.serialize()).hexdigest() == rec["serialized_sha256"]
 
 
-def _run_bench(args, timeout=900):
+def _run_bench(args, timeout=900, env_extra=None):
     """bench.py from a BARE shell (no RANK / WORLD_SIZE in the environment), exactly as the driver's `python3 bench.py --gpus N`"""
     import json
     import os
@@ -361,6 +361,7 @@ def _run_bench(args, timeout=900):
     import sys
     from conftest import REPO
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -404,6 +405,7 @@ def test_bench_two_ranks_print_the_north_star_record(sc):
     assert probes["chosen"] in out["config"]["corner_turn"] and any("direct store" in p["form"] for p in probes["probes"])
     direct = [p for p in probes["probes"] if p["form"].startswith("direct store: ")][0]
     assert direct["available"] is True and direct["correct"] is True and direct["ms_per_pair"] > 0
+    assert direct["receive_region_memory"] == "fine-grained"      # peers store into it while this GPU's kernels poll and read it
     node = out["config"]["node"]
     assert "rccl_version" in node and node["visible_gpus"] >= 1 and len(node["can_access_peer"]) == node["visible_gpus"]
     assert "n1 = 2^" in out["config"]["split"]
@@ -444,3 +446,15 @@ def test_bench_bare_launch_two_ranks_and_census_parity(sc):
     coeffs = synth.synth_packed(60, No // 2).tobytes()
     lde = po.C.coset_evaluate(coeffs, No // 2, po.GENERATOR, po.primitive_nth_root(Nf), Nf)
     assert po.C.merkle_commit(lde, Nf).hex()[:16] == s1["roots"][0]
+
+
+def test_bench_measures_again_when_the_direct_store_fails_in_the_timed_run(sc):
+    """The direct-store corner turn has never run between two physical GPUs; if it passes its probe and the timed run's round trip
+    (or a flag barrier) then fails, the bench must not end without a number: it discards the form on every rank together and
+    measures again through the collectives.  The failure is injected after the timed windows (BENCH_INJECT_DIRECT_STORE_FAULT)."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--scaling", "weak"],
+                     env_extra={"BENCH_INJECT_DIRECT_STORE_FAULT": "1"})
+    probes = out["config"]["corner_turn_probes"]
+    assert "direct store" in probes["discarded_after_timed_run"] and "direct store" not in probes["chosen"]
+    assert any("direct store" in p["form"] for p in probes["probes"])            # its probe times stay in the record
+    assert out["config"]["roundtrip_bit_exact"] is True and out["value"] > 0 and probes["chosen"] in out["config"]["corner_turn"]
