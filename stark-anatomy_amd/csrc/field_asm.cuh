@@ -217,7 +217,7 @@ __device__ __forceinline__ void mont_mul2_asm(Fe xa, Fe wa, Fe xb, Fe wb, Fe& ra
     B.b0 = lo32(wb.lo); B.b1 = hi32(wb.lo); B.b2 = lo32(wb.hi); B.b3 = hi32(wb.hi);
     const uint64_t zero64 = 0;
     const uint32_t zero32 = 0, PHc = PH3;
-#define SC_BOTH(STEP) { MulState& M = A; constexpr int W = 0; STEP } { MulState& M = B; constexpr int W = 1; STEP }
+#define SC_BOTH(STEP) { MulState& M = A; [[maybe_unused]] constexpr int W = 0; STEP } { MulState& M = B; [[maybe_unused]] constexpr int W = 1; STEP }
     // ---- product.  Carry counters travel in PAIRS: the odd accumulator O_k covers columns (2k+1, 2k+2), and the overflow counts
     // of O_{k-1} (weight: column 2k+1) and of E_k (weight: column 2k+2) are exactly the low and the high word of the 64-bit addend
     // of O_k's first v_mad -- {nO0, nE1} for O1, {nO1, nE2} for O2 -- so no counter is ever zero-extended into a register pair
@@ -299,7 +299,7 @@ __device__ __forceinline__ void fe_addsub2_asm(Fe ua, Fe va, Fe ub, Fe vb, Fe& s
     B.u0 = lo32(ub.lo); B.u1 = hi32(ub.lo); B.u2 = lo32(ub.hi); B.u3 = hi32(ub.hi);
     B.v0 = lo32(vb.lo); B.v1 = hi32(vb.lo); B.v2 = lo32(vb.hi); B.v3 = hi32(vb.hi);
     const uint32_t zero32 = 0, one32 = 1, PHc = PH3;
-#define SC_BOTH(STEP) { AddSubState& M = A; constexpr int W = 0; STEP } { AddSubState& M = B; constexpr int W = 1; STEP }
+#define SC_BOTH(STEP) { AddSubState& M = A; [[maybe_unused]] constexpr int W = 0; STEP } { AddSubState& M = B; [[maybe_unused]] constexpr int W = 1; STEP }
     // sum chain (r, carry ca) and difference chain (d, borrow bd), limb by limb
     SC_BOTH(SC_V_ADDCO(M.r0, M.ca, M.u0, M.v0); SC_V_SUBCO(M.d0, M.bd, M.u0, M.v0);)
     SC_BOTH(SC_V_ADDC(M.r1, M.ca, M.u1, M.v1, M.ca); SC_V_SUBB(M.d1, M.bd, M.u1, M.v1, M.bd);)
