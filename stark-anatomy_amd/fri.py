@@ -27,6 +27,22 @@ class AlsoOpen:
         self.requests, self.answers = requests, None
 
 
+def library_transcript(proof_stream, rounds):
+    """The byte strings in `proof_stream` if the library may run `rounds` rounds of the commit phase on it itself
+    (sc_fri_commit_dev computes SHAKE-256(pickle(objects)) on its own), else None.  Only a plain ProofStream: a subclass may derive
+    its challenges differently (the reference's SignatureProofStream prefixes the document).  Only distinct byte strings so far
+    (roots): that list has a fixed pickle layout.  The size test counts what the C side counts (3 bytes of pickle opcodes per prior
+    item, 67 per root of this commit); the library still answers "unsupported" for anything else it does not take, and then the
+    caller's Python loop runs."""
+    if type(proof_stream) is not ProofStream:
+        return None
+    prior = list(proof_stream.objects)
+    if (len(prior) + rounds < 999 and all(type(o) is bytes and len(o) < 256 for o in prior) and len(set(map(id, prior))) == len(prior)
+            and sum(len(o) + 3 for o in prior) + 67 * rounds < 60000):
+        return prior
+    return None
+
+
 class Fri:
     def __init__(self, offset, omega, initial_domain_length, expansion_factor, num_colinearity_tests):
         self.offset, self.omega, self.field = offset, omega, omega.field
@@ -92,15 +108,8 @@ class Fri:
         # fri.py:68 asserts omega_r^(N_r - 1) == omega_r^-1, i.e. omega_r^(N_r) == 1, in every round; omega_r = omega^(2^r) and
         # N_r = N / 2^r, so every round's condition is omega^N == 1: checked once, before anything is enqueued
         assert(self.omega ^ (len(codeword) - 1) == self.omega.inverse()), "error in commit: omega does not have the right order!"
-        prior = proof_stream.objects
-        # only a plain ProofStream: a subclass may derive its challenges differently (the reference's SignatureProofStream prefixes
-        # the document), and the library computes SHAKE-256(pickle(objects)) itself.  The size test counts what the C side counts
-        # (3 bytes of pickle opcodes per prior item, 67 per root of this commit); the library still answers "unsupported" for
-        # anything else it does not take, and then the Python loop runs.
         codewords = None
-        if (type(proof_stream) is ProofStream and len(codeword) >= 2 and codeword._tree is None and len(prior) + rounds < 999
-                and all(type(o) is bytes and len(o) < 256 for o in prior) and len(set(map(id, prior))) == len(prior)
-                and sum(len(o) + 3 for o in prior) + 67 * rounds < 60000):
+        if len(codeword) >= 2 and codeword._tree is None and library_transcript(proof_stream, rounds) is not None:
             codewords = self._commit_in_library(codeword, proof_stream, rounds)
         if codewords is None:
             codewords = self._commit_rounds(codeword, proof_stream, rounds)

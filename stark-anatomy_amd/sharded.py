@@ -677,6 +677,46 @@ class HipFriEngine:
         self._done(sptr)
         return dst
 
+    class _LibraryVector:
+        """a folded codeword the library handed out (sc_fri_commit_dev), behind the two things the layer records ask of a tensor"""
+
+        def __init__(self, vec):
+            self.vec = vec
+
+        def data_ptr(self):
+            return self.vec.ptr
+
+        def contiguous(self):
+            return self
+
+    def commit_rounds(self, full, N, offset, omega, rounds, prior):
+        """The remaining `rounds` rounds of the commit phase on a codeword every rank holds whole (`full`, N elements): trees,
+        Fiat-Shamir steps and folds in ONE library call (sc_fri_commit_dev, what Fri.commit uses on one GPU).  prior: the byte
+        strings in the proof stream so far.  [(codeword, tree, root)] per round, or None when the library does not take the
+        transcript (or under torch's null stream): the caller's round loop runs then."""
+        sptr = self._stream()
+        if sptr is None:
+            return None
+        ct, sc = self.ctypes, self.sc
+        full = full.contiguous()
+        k = len(prior)
+        vecs = (ct.c_void_p * max(1, rounds - 1))()
+        trees = (ct.c_void_p * rounds)()
+        roots = ct.create_string_buffer(64 * rounds)
+        alphas = (ct.c_uint64 * max(2, 2 * (rounds - 1)))()
+        rc = self.lib.sc_fri_commit_dev(full.data_ptr(), N, _fe(offset), _fe(omega), rounds, b"".join(prior), (ct.c_uint32 * max(1, k))(*map(len, prior)), k,
+                                        vecs, trees, roots, alphas, sptr)
+        if rc == sc.SC_ERR_UNSUPPORTED:
+            return None
+        sc._check(rc)
+        out, raw = [], roots.raw
+        for r in range(rounds):
+            n = N >> r
+            vec = full if r == 0 else HipFriEngine._LibraryVector(sc.DeviceVector.adopt(vecs[r - 1], n))
+            root = raw[64 * r:64 * r + 64]
+            out.append((vec, HipFriEngine._Tree(sc.MerkleTree(ct.c_void_p(trees[r]), root, n), vec), root))
+        return out
+
     def lde(self, coeffs, offset, generator, order):
         """fast_coset_evaluate (code/ntt.py:132-135) of packed coefficients (bytes) -> device tensor [order][2]"""
         m = len(coeffs) // 16
@@ -736,6 +776,10 @@ class HipFriEngine:
         """values (Python ints) of elems.view(-1, 2)[flat_indices]"""
         if len(flat_indices) == 0:
             return []
+        if isinstance(elems, HipFriEngine._LibraryVector):
+            torch.cuda.current_stream(self.device).synchronize()        # the copy below runs on the library's stream
+            values = self.sc.unpack(elems.vec.to_bytes(), elems.vec.n)
+            return [values[i] for i in flat_indices]
         idx = torch.tensor(list(flat_indices), dtype=torch.int64, device=elems.device)
         got = elems.reshape(-1, 2)[idx].cpu().tolist()
         m = (1 << 64) - 1
@@ -778,11 +822,20 @@ class ShardedFri:
     any broadcast, and every rank ends up with the identical, reference-identical proof stream.
     """
 
-    def __init__(self, fri, R, rank, world, device, engine=None, group=None):
+    # A 2^16-leaf tree is two latency-bound launches (0.066 ms, DESIGN 3.4) whatever the number of ranks; its sharded form -- local
+    # subtree, level copy, all-gather, top tree -- is four steps of the same kind plus a collective.  Above 2^17 nodes the hashing is
+    # throughput-bound and sharding pays.
+    LOCAL_TAIL = 1 << 16
+
+    def __init__(self, fri, R, rank, world, device, engine=None, group=None, local_tail=None):
+        """local_tail: once a round's codeword is this short it is gathered on every rank and the remaining rounds run locally
+        (replicated): such rounds are bound by launch and hashing latency on any number of ranks, a collective per round only
+        adds to it, and on the HIP engine the rest of the commit phase is then ONE library call (0: only when one row is left)."""
         self.fri, self.R, self.rank, self.world, self.device, self.group = fri, int(R), rank, world, device, group
         assert R % world == 0 and fri.domain_length % R == 0
         self.Rw = self.R // world
         self.engine = engine if engine is not None else HipFriEngine(device)
+        self.local_tail = self.LOCAL_TAIL if local_tail is None else int(local_tail)
 
     # -- collectives ------------------------------------------------------------------------------
     def _all_gather(self, t):
@@ -1039,8 +1092,12 @@ class ShardedFri:
         assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
         for r in range(rounds):
             Nr = N >> r
-            if full is None and C == 1:
-                full = self._natural(cur, 1)                # one row left: collect it everywhere, go local
+            if full is None and (C == 1 or Nr <= self.local_tail):
+                full = self._natural(cur, C)                # one row left / a short codeword: collect it everywhere, go local
+                rest = self._commit_tail(full, Nr, offset, omega, rounds - r, proof_stream)
+                if rest is not None:                        # ... and the library ran every remaining round in one call
+                    layers.extend(rest)
+                    break
             if full is None:
                 layer = self._commit_sharded(cur, C, local)
             else:
@@ -1052,7 +1109,8 @@ class ShardedFri:
                 break
             alpha = field.sample(proof_stream.prover_fiat_shamir())
             if full is None:
-                if C > 2 and hasattr(eng, "fold_slab_tree"):          # the folded slab is committed to as a slab again: fold + subtree in one call
+                # the folded slab is committed to as a slab again (not gathered): fold + local subtree in one call
+                if C > 2 and (Nr >> 1) > self.local_tail and hasattr(eng, "fold_slab_tree"):
                     cur, local = eng.fold_slab_tree(cur, C, Rw, R, self.rank * Rw, alpha.value, offset.value, omega.value)
                 else:
                     cur, local = eng.fold_slab(cur, C, Rw, R, self.rank * Rw, alpha.value, offset.value, omega.value), None
@@ -1063,7 +1121,7 @@ class ShardedFri:
             offset = offset ^ 2
         # last codeword in the clear (fri.py:91): natural order, plain list; its objects are reused by the last query round
         last_layer = layers[-1]
-        last_vec = full if full is not None else self._natural(cur, C)
+        last_vec = last_layer["vec"] if last_layer["kind"] == "local" else self._natural(cur, C)
         last_values = eng.read(last_vec, range(last_layer["length"]))
         lazy = None
         if hasattr(eng, "query_many"):                      # (the CPU test engines answer with objects)
@@ -1079,6 +1137,25 @@ class ShardedFri:
         proof_stream.push(last_list)
 
         return self._query_all(layers, last_list, proof_stream)
+
+    def _commit_tail(self, full, Nr, offset, omega, rounds_left, proof_stream):
+        """the remaining rounds of the commit phase on the gathered codeword through the engine's whole-loop call, when there is
+        one and the proof stream qualifies (fri.library_transcript: what Fri.commit checks on one GPU); layer records or None"""
+        eng = self.engine
+        if not hasattr(eng, "commit_rounds") or Nr < 2:
+            return None
+        from fri import library_transcript
+        prior = library_transcript(proof_stream, rounds_left)
+        if prior is None:
+            return None
+        got = eng.commit_rounds(full, Nr, offset.value, omega.value, rounds_left, prior)
+        if got is None:
+            return None
+        rest = []
+        for k, (vec, tree, root) in enumerate(got):
+            proof_stream.push(root)
+            rest.append({"kind": "local", "vec": vec, "tree": tree, "root": root, "length": Nr >> k, "cache": {}})
+        return rest
 
     def _query_requests(self, layers, last_length, proof_stream):
         """top-level indices from the transcript and what every layer has to open (fri.py:119-128)"""

@@ -206,13 +206,15 @@ def fri_check(rank, world, dev):
             C, Rw = N // R, R // world
             slab = torch.from_numpy(cw.reshape(C, R, 2)[:, rank * Rw:(rank + 1) * Rw, :].copy()).to(dev)
             fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
-            ps = ProofStream()
-            top = ShardedFri(fr, R, rank, world, dev).prove(slab, ps)
-            ser = ps.serialize()
-            good = (top == rec["top_level_indices"] and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
-            if not good:
-                print("rank", rank, "FRI MISMATCH logN", logN, "R", R, flush=True)
-            ok &= good
+            # local_tail: never gather early / gather half way through the rounds / the default (these sizes: before round 0)
+            for tail in (0, N >> 2, None):
+                ps = ProofStream()
+                top = ShardedFri(fr, R, rank, world, dev, local_tail=tail).prove(slab, ps)
+                ser = ps.serialize()
+                good = (top == rec["top_level_indices"] and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
+                if not good:
+                    print("rank", rank, "FRI MISMATCH logN", logN, "R", R, "tail", tail, flush=True)
+                ok &= good
         # the NATURAL contiguous layout (SURVEY 8(e) "FRI fold": one neighbour exchange per fold), HIP engine on every rank
         from sharded import ContiguousFri
         seg = N // world

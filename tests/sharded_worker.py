@@ -312,14 +312,16 @@ def fri_main():
             C, Rw = N // R, R // world
             slab = torch.from_numpy(cw.reshape(C, R, 2)[:, rank * Rw:(rank + 1) * Rw, :].copy())
             fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
-            ps = ProofStream()
-            top = ShardedFri(fr, R, rank, world, torch.device("cpu"), engine=OracleFriEngine()).prove(slab, ps)
-            ser = ps.serialize()
-            good = (top == rec["top_level_indices"] and [o.hex() for o in ps.objects[:rec["num_rounds"]]] == rec["roots"]
-                    and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
-            if not good:
-                print("rank", rank, "MISMATCH logN", logN, "R", R, top == rec["top_level_indices"], len(ser), rec["serialized_len"], flush=True)
-            ok &= good
+            # local_tail: never gather early / gather half way through the rounds / the default (these sizes: before round 0)
+            for tail in (0, N >> 2, None):
+                ps = ProofStream()
+                top = ShardedFri(fr, R, rank, world, torch.device("cpu"), engine=OracleFriEngine(), local_tail=tail).prove(slab, ps)
+                ser = ps.serialize()
+                good = (top == rec["top_level_indices"] and [o.hex() for o in ps.objects[:rec["num_rounds"]]] == rec["roots"]
+                        and len(ser) == rec["serialized_len"] and hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"])
+                if not good:
+                    print("rank", rank, "MISMATCH logN", logN, "R", R, "tail", tail, top == rec["top_level_indices"], len(ser), rec["serialized_len"], flush=True)
+                ok &= good
         # SURVEY 8(e), row "FRI fold": the same proof from the NATURAL contiguous layout (one neighbour exchange per fold)
         from sharded import ContiguousFri
         if N // world >= 1:

@@ -310,18 +310,21 @@ def test_sharded_fri_hip_engine_matches_reference_proofs(sc):
             fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
             # under torch's null stream the engine runs on the library's stream and folds with a kernel of its own; on a side
             # stream (how the sharded prover runs) a round's fold happens in the leaf stage of the next local subtree
-            for side_stream in (False, True):
+            # local_tail: the codeword is never gathered early / gathered half way through the rounds / the default (2^16: from
+            # the first round on for these records) -- on a side stream the rounds after the
+            # gather are ONE library call (sc_fri_commit_dev), under the null stream the Python loop
+            for side_stream, tail in ((False, 0), (True, 0), (False, N >> 2), (True, N >> 2), (False, None), (True, None)):
                 ps = ProofStream()
                 if side_stream:
                     torch.cuda.synchronize()
                     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                        top = ShardedFri(fr, R, 0, 1, dev).prove(cw.reshape(N // R, R, 2), ps)
+                        top = ShardedFri(fr, R, 0, 1, dev, local_tail=tail).prove(cw.reshape(N // R, R, 2), ps)
                     torch.cuda.synchronize()
                 else:
-                    top = ShardedFri(fr, R, 0, 1, dev).prove(cw.reshape(N // R, R, 2), ps)
+                    top = ShardedFri(fr, R, 0, 1, dev, local_tail=tail).prove(cw.reshape(N // R, R, 2), ps)
                 ser = ps.serialize()
-                assert top == rec["top_level_indices"], (rec["logN"], R, side_stream)
-                assert hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"], (rec["logN"], R, side_stream)
+                assert top == rec["top_level_indices"], (rec["logN"], R, side_stream, tail)
+                assert hashlib.sha256(ser).hexdigest() == rec["serialized_sha256"], (rec["logN"], R, side_stream, tail)
 
 
 def test_sharded_lde_then_sharded_fri_one_rank(sc):
