@@ -2734,7 +2734,7 @@ int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t 
         void* fl;
         SCCHK(scratch(7, 256, &fl));
         long long deg = -1;
-        HIPCHK(hipMemcpyAsync(fl, &deg, sizeof deg, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(fl, 0xFF, sizeof deg, st));          // -1, without a pageable host-to-device copy in front of the kernel
         if (order > n_out) {
             const uint64_t cnt = order - n_out;
             hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const Fe*)full + n_out, cnt, (long long*)fl);
@@ -2754,7 +2754,7 @@ int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* st
     void* fl;
     SCCHK(scratch(7, 256, &fl));
     long long deg = -1;
-    HIPCHK(hipMemcpyAsync(fl, &deg, sizeof deg, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(fl, 0xFF, sizeof deg, st));              // -1, without a pageable host-to-device copy in front of the kernel
     // the leading coefficient of a polynomial is almost always in its last few entries: look at the top 2^16 first, and at
     // the rest only when those are all zero
     const uint64_t top = n < (1ull << 16) ? n : (1ull << 16);

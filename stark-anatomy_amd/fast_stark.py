@@ -420,10 +420,11 @@ class FastStark:
         the host and written behind each column's copy"""
         assert(len(trace.columns) == self.num_registers), "one column per register"
         width, rows, extra = self.num_registers, len(trace), self.num_randomizers
-        sample = self.field.sample
+        # Field.sample (algebra.py:116-120: big-endian accumulate, then % p) of every 17-byte draw, without an object per draw
+        p, big = self.field.p, int.from_bytes
         columns = []
         for s in range(width):
-            tail = b"".join(sample(raw[17 * (r * width + s):17 * (r * width + s) + 17]).value.to_bytes(16, "little") for r in range(extra))
+            tail = b"".join((big(raw[17 * (r * width + s):17 * (r * width + s) + 17], "big") % p).to_bytes(16, "little") for r in range(extra))
             column = DeviceVector(rows + extra)
             _sc._check(_sc.lib().sc_memcpy_dev(column.ptr, trace.columns[s].ptr, rows, None))
             if extra:

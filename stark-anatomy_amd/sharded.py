@@ -14,6 +14,8 @@ Per transform and rank:   (1) column NTTs of length R on the local slab         
                           (4) row NTTs of length C, written transposed            (local, HIP)
 There is no reduction anywhere, so no all-reduce / ring is used.
 """
+import itertools
+
 import torch
 import torch.distributed as dist
 
@@ -563,7 +565,8 @@ class ShardedNtt:
         self._run(lambda: self._transform(y_local, x_local, True))
 
     def _run(self, fn):
-        if self.stream is not None and torch.cuda.current_stream(self.device).cuda_stream != self.stream.cuda_stream:
+        # (the raw getter: a tenth of the cost of building a torch.cuda.Stream object per transform)
+        if self.stream is not None and _current_raw_stream(self.device) != self.stream.cuda_stream:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             try:
                 with torch.cuda.stream(self.stream):
@@ -728,42 +731,44 @@ class HipFriEngine:
         self._done(sptr)
         return out
 
-    def query_many(self, requests, raw_paths=False):
+    def query_many(self, requests, raw_paths=False, raw_values=False):
         """[(tree, elems tensor or None, indices[, keep])] -> [(values as ints or None, authentication paths)]: every opening of
         every layer in ONE library call and one launch (sc_merkle_query_multi_dev), instead of a device round trip per tree.
         keep: only the first `keep` digests of each path are wanted (the part below a sharded commitment's sub-roots).
         raw_paths: the paths of a request come back as ONE uint8 array [openings][64 * digests] instead of lists of bytes
-        objects (the sharded openings join two such parts per path before any object is made)."""
+        objects (the sharded openings join two such parts per path before any object is made).  raw_values: the opened elements
+        come back as a uint8 array [openings][16] (packed residues, as the device wrote them) instead of Python ints."""
         import numpy as np
         ct, sc = self.ctypes, self.sc
         requests = [(r[0], r[1], r[2], r[3] if len(r) > 3 else None) for r in requests]
-        live = [(q, t, e, idx if isinstance(idx, list) else list(idx), keep) for q, (t, e, idx, keep) in enumerate(requests) if len(idx)]
+        live = [(q, t, e, idx, keep) for q, (t, e, idx, keep) in enumerate(requests) if len(idx)]
+        no_values = np.zeros((0, 16), dtype=np.uint8) if raw_values else []
         if raw_paths:
-            out = [(None if e is None else [], np.zeros((0, 0), dtype=np.uint8)) for t, e, idx, _ in requests]
+            out = [(None if e is None else no_values, np.zeros((0, 0), dtype=np.uint8)) for t, e, idx, _ in requests]
         else:
-            out = [(None if e is None else [], [[] for _ in idx]) for t, e, idx, _ in requests]
+            out = [(None if e is None else no_values, [[] for _ in idx]) for t, e, idx, _ in requests]
         if not live:
             return out
         torch.cuda.current_stream(self.device).synchronize()        # the library call runs on the library's stream
         n = len(live)
-        flat = [i for _, _, _, idx, _ in live for i in idx]
-        total = len(flat)
+        counts = [len(idx) for _, _, _, idx, _ in live]
+        flat = np.fromiter(itertools.chain.from_iterable(idx for _, _, _, idx, _ in live), dtype=np.uint64, count=sum(counts))
+        total = int(flat.size)
         depths = [t.tree.depth for _, t, _, _, _ in live]
-        path_bytes = sum(64 * d * len(idx) for d, (_, _, _, idx, _) in zip(depths, live))
-        elems_out = ct.create_string_buffer(16 * total)
-        paths_out = ct.create_string_buffer(max(path_bytes, 64))
+        path_bytes = sum(64 * d * k for d, k in zip(depths, counts))
+        elems_out = np.empty((total, 16), dtype=np.uint8)            # (every byte is written by the call: nothing to zero first)
+        paths_out = np.empty(max(path_bytes, 64), dtype=np.uint8)
         # a tree over digests has no element vector: any readable pointer will do, the value is not used
         ptrs = [(e if e is not None else t.keep).data_ptr() for _, t, e, _, _ in live]
         sc._check(self.lib.sc_merkle_query_multi_dev(n, (ct.c_void_p * n)(*[t.tree._h for _, t, _, _, _ in live]), (ct.c_void_p * n)(*ptrs),
-                                                     (ct.c_uint64 * total)(*flat), (ct.c_uint64 * n)(*[len(idx) for _, _, _, idx, _ in live]),
-                                                     elems_out, paths_out))
-        values = sc.unpack(elems_out.raw, total)
+                                                     flat.ctypes.data_as(ct.POINTER(ct.c_uint64)), (ct.c_uint64 * n)(*counts),
+                                                     elems_out.ctypes.data_as(ct.c_void_p), paths_out.ctypes.data_as(ct.c_void_p)))
+        values = elems_out if raw_values else sc.unpack(elems_out.tobytes(), total)
         view = memoryview(paths_out)
         vo = po = 0
-        for (q, t, e, idx, keep), d in zip(live, depths):
-            k = len(idx)
+        for (q, t, e, idx, keep), d, k in zip(live, depths, counts):
             if raw_paths:
-                whole = np.frombuffer(view[po:po + 64 * k * d], dtype=np.uint8).reshape(k, 64 * d)
+                whole = paths_out[po:po + 64 * k * d].reshape(k, 64 * d)
                 paths = whole if keep is None or keep >= d else whole[:, :64 * keep]
             else:
                 paths = sc._path_lists(view, po, d, k, keep)
@@ -855,13 +860,14 @@ class ShardedFri:
         dist.all_gather(parts, t, group=self.group)
         return torch.stack(parts, dim=0)
 
-    def _gather_answers(self, layout, mine, sizes):
+    def _gather_answers(self, layout, mine, sizes, packed=False):
         """The owners' answers to the openings, merged with ONE fixed-shape tensor collective (no pickling, no object store).
         layout[r] = [(q, positions, ndigests)]: the runs rank r answers (one per request it owns something of), in the order it
         packs them -- every rank derives all of it from the public indices; `mine` = this rank's runs [(values, bottoms)] in that
         order, bottoms = uint8 array [openings][64 * ndigests]; sizes[q] = number of openings of request q.  Returns
         {q: (values, bottoms)}: a list and a uint8 array, both indexed by the position in the request.  No object per digest is
-        made here: the caller joins these path bottoms with the path tops first."""
+        made here: the caller joins these path bottoms with the path tops first.  packed: the values are uint8 arrays
+        [openings][16] (packed residues) on the way in and on the way out, and no integer object is made either."""
         import numpy as np
         import starkcore as sc
         G, g = self.world, self.rank
@@ -873,9 +879,13 @@ class ShardedFri:
                 return
             have = answers.get(q)
             if have is None:
-                have = answers[q] = ([None] * sizes[q], np.zeros((sizes[q], bottoms.shape[1]), dtype=np.uint8))
-            for pos, v in zip(positions, vals):
-                have[0][pos] = v
+                have = answers[q] = (np.zeros((sizes[q], 16), dtype=np.uint8) if packed else [None] * sizes[q],
+                                     np.zeros((sizes[q], bottoms.shape[1]), dtype=np.uint8))
+            if packed:
+                have[0][positions] = vals
+            else:
+                for pos, v in zip(positions, vals):
+                    have[0][pos] = v
             have[1][positions] = bottoms
 
         if G == 1:
@@ -889,7 +899,7 @@ class ShardedFri:
         for (q, positions, nd), (vals, bottoms) in zip(layout[g], mine):
             k = len(positions)
             block = np.empty((k, 2 + 8 * nd), dtype=np.int64)
-            block[:, :2] = np.frombuffer(sc.pack(vals), dtype=np.int64).reshape(k, 2)
+            block[:, :2] = np.ascontiguousarray(vals).view(np.int64) if packed else np.frombuffer(sc.pack(vals), dtype=np.int64).reshape(k, 2)
             if nd:
                 block[:, 2:] = np.ascontiguousarray(bottoms).view(np.int64)
             row[at:at + block.size] = block.reshape(-1)
@@ -911,7 +921,8 @@ class ShardedFri:
                 k = len(positions)
                 block = rows[r, at:at + k * (2 + 8 * nd)].reshape(k, 2 + 8 * nd)
                 at += block.size
-                vals = sc.unpack(np.ascontiguousarray(block[:, :2]).tobytes(), k)
+                vals = np.ascontiguousarray(block[:, :2])
+                vals = vals.view(np.uint8) if packed else sc.unpack(vals.tobytes(), k)
                 place(q, positions, vals, np.ascontiguousarray(block[:, 2:]).view(np.uint8))
         return answers
 
@@ -1015,10 +1026,10 @@ class ShardedFri:
             where.append(("sharded", len(asks)))
             asks.append((layer["local"], layer["slab"], [(i // R) * Rw + (i % R) % Rw for i in mine], sub_level))
             asks.append((layer["top"], None, [(i // R) * G + (i % R) // Rw for i in indices] if layer["C"] * G > 1 else []))
-        got = eng.query_many(asks, raw_paths=True)
+        got = eng.query_many(asks, raw_paths=True, raw_values=True)           # residues stay packed bytes from the device to the proof
         layout, mine, sizes = [[] for _ in range(G)], [], [len(indices) for _, indices in requests]
         for q, ((layer, indices), w) in enumerate(zip(requests, where)):
-            if w[0] == "local" or not indices:
+            if w[0] == "local" or not len(indices):
                 continue
             if G == 1:
                 layout[0].append((q, range(len(indices)), sub_level))
@@ -1032,7 +1043,7 @@ class ShardedFri:
                     layout[r].append((q, owners[r], sub_level))
             if owners[g]:
                 mine.append(got[w[1]])
-        answers = self._gather_answers(layout, mine, sizes) if any(layout) else {}
+        answers = self._gather_answers(layout, mine, sizes, packed=True) if any(layout) else {}
         out = []
         for q, ((layer, indices), w) in enumerate(zip(requests, where)):
             k = len(indices)
@@ -1041,12 +1052,12 @@ class ShardedFri:
                 depth = layer["length"].bit_length() - 1
                 paths = np.ascontiguousarray(paths).reshape(k, 64 * depth) if k and depth else np.zeros((k, 0), dtype=np.uint8)
             elif q not in answers:
-                vals, paths = [], np.zeros((0, 0), dtype=np.uint8)
+                vals, paths = np.zeros((0, 16), dtype=np.uint8), np.zeros((0, 0), dtype=np.uint8)
             else:
                 vals, bottoms = answers[q]
                 tops = got[w[1] + 1][1] if layer["C"] * G > 1 else None
                 paths = np.concatenate((bottoms, tops), axis=1) if tops is not None and tops.shape[0] == k and tops.shape[1] else bottoms
-            out.append((sc.pack(vals), np.ascontiguousarray(paths)))
+            out.append((np.ascontiguousarray(vals).tobytes(), np.ascontiguousarray(paths)))
         return out
 
     @staticmethod

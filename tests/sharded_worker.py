@@ -248,9 +248,9 @@ class OracleFriEngine:
         raw = po.C.coset_evaluate(coeffs, len(coeffs) // 16, offset, generator, order)
         return torch.from_numpy(np.frombuffer(raw, dtype=np.int64).reshape(order, 2).copy())
 
-    def query_many(self, requests, raw_paths=False):
+    def query_many(self, requests, raw_paths=False, raw_values=False):
         """[(tree, elems or None, indices[, keep])] -> [(values or None, paths cut to their first `keep` digests)] (the HIP engine
-        answers all of them in one library call)"""
+        answers all of them in one library call); raw_values: packed residues, a uint8 array [openings][16]"""
         out = []
         for req in requests:
             t, e, idx = req[:3]
@@ -259,7 +259,10 @@ class OracleFriEngine:
             if raw_paths:
                 width = 64 * len(paths[0]) if paths else 0
                 paths = np.frombuffer(b"".join(d for p in paths for d in p), dtype=np.uint8).reshape(len(paths), width)
-            out.append(((self.read(e, idx) if e is not None else None), paths))
+            values = self.read(e, idx) if e is not None else None
+            if raw_values and values is not None:
+                values = np.frombuffer(b"".join(v.to_bytes(16, "little") for v in values), dtype=np.uint8).reshape(len(values), 16)
+            out.append((values, paths))
         return out
 
     def read(self, elems, flat_indices):
