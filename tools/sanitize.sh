@@ -4,9 +4,14 @@
 #   cpu:  oracle/stark_oracle.c (gcc) and tests/emu/ntt_emu.cpp (g++; the kernels' round bodies, the planner, field.cuh on the
 #         host) under ASan + UBSan against their test suites; the HOST side of libstarkcore.so (hipcc -fsanitize=address,undefined:
 #         device code is not instrumented) against the host-only suites: transcript, proof pickler, ABI
-#   gpu:  the same ASan + UBSan library under the C-ABI parity tests, the Fri / FastStark host tests, the allocator leak check;
-#         a ThreadSanitizer build under tools/thread_stress.py (three prover threads in one process)
+#   gpu:  the same ASan + UBSan library under the C-ABI parity tests and the Fri / FastStark host tests, tools/thread_stress.py;
+#         a ThreadSanitizer build under tools/thread_stress.py (three prover threads in one process).
+#         What cannot run under the preloaded ASan runtime, and why (profiles/r04/sanitize_gpu_notes.txt): anything that initialises
+#         torch.cuda (torch's own dlopen of libcaffe2_nvrtc.so fails under ASan's dlopen interceptor: the sharded tests, the stream
+#         join test), and tools/leak_check.py, which imports torch first (ROCm's ASan intercepts hsa_amd_memory_pool_allocate and reports
+#         "out of memory" for a 4 MB allocation of the HIP RUNTIME itself, before the library is called) -- both run without ASan.
 set -u
+set -o pipefail
 REPO=$(cd "$(dirname "$0")/.." && pwd); cd $REPO
 MODE=${1:-cpu}; OUT=${2:-/tmp/sanitize}; mkdir -p $OUT
 LIBS=/tmp/sanitize_libs; mkdir -p $LIBS          # the instrumented libraries (tens of MB) stay out of $OUT, which holds the logs
@@ -34,12 +39,11 @@ if [ "$MODE" = cpu ]; then
 else
   echo "== libstarkcore.so host side under ASan + UBSan on the GPU"
   build_lib address,undefined $LIBS/libstarkcore_san.so || status=1
-  for t in "tests/test_gpu_cabi.py -k 'not full_size and not big and not tunings'" "tests/test_gpu_host.py" "tests/test_gpu_stark.py" "tests/test_gpu_geoseq.py -k 'not 1048'"; do
+  for t in "tests/test_gpu_cabi.py -k 'not full_size and not big and not tunings and not stream_handle'" "tests/test_gpu_host.py" "tests/test_gpu_stark.py" "tests/test_gpu_geoseq.py -k 'not 1048'"; do
     echo "-- pytest $t"
-    LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 1500 bash -c "python -m pytest $t -x -q -m gpu 2>&1 | tail -4" || status=1
+    LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 1500 bash -c "set -o pipefail; python -m pytest $t -x -q -m gpu 2>&1 | tail -4" || status=1
   done
-  # (the HIP runtime's own big host allocations exhaust ASan's allocator with the default 256 MB quarantine: keep it small here)
-  echo "-- tools/leak_check.py"; ASAN_OPTIONS=$ASAN_OPTIONS:quarantine_size_mb=8 LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 600 python tools/leak_check.py 2>&1 | grep -v "amdgpu.ids" | tail -6 || status=1
+  echo "-- tools/leak_check.py (plain library: see the header)"; timeout 600 python tools/leak_check.py 2>&1 | grep -v "amdgpu.ids" | tail -3 || status=1
   echo "-- tools/thread_stress.py 10 3 (ASan)"; LD_PRELOAD=$CLANG_RT STARKCORE_LIB=$LIBS/libstarkcore_san.so timeout 600 python tools/thread_stress.py 10 3 2>&1 | tail -3 || status=1
   if [ -n "$CLANG_TSAN" ]; then
     echo "== ThreadSanitizer build under three prover threads"
