@@ -7,7 +7,6 @@ instead of the reference's full rebuild per call.  The raw-digest variants (`com
 """
 from hashlib import blake2b
 
-import starkcore as _sc
 from starkcore import DeviceCodeword, MerkleTree
 
 

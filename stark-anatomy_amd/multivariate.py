@@ -195,7 +195,6 @@ class MPolynomial:
             return None
         if bound < MPolynomial.VALUE_DOMAIN_MIN_DEGREE and not any(on_device):
             return None
-        import ctypes
         import starkcore as _sc
         n = 1 << max(1, bound.bit_length())            # > bound
         root = field.primitive_nth_root(n)
