@@ -64,6 +64,10 @@ def test_fri_prove_2p22_against_oracle(sc):
     assert top == fr.sample_indices(replay.prover_fiat_shamir(), N // 2, 256, 40)
     assert len(ps.objects) == 15 + 1 + 14 * 40 * 4                                          # 14 query rounds x (40 triples + 120 paths)
     assert fr.verify(ps, []) is True                                                        # colinearity + 1 680 Merkle paths (hashlib)
+    # the proof's bytes come from the library's pickler working on a DESCRIPTION of the proof (csrc/proof_pickle.h); CPython's own
+    # pickle over the materialised objects -- 2 MB, ~25 000 objects, dozens of 64 KiB frames -- must give the same bytes
+    import pickle
+    assert pickle.dumps(list(ps.objects)) == ps.serialize()
 
 
 def test_stark_census_2p24_two_paths_and_oracle(sc):
@@ -124,5 +128,8 @@ def test_stark_prover_full_size_two_provers_one_proof(sc, log_fri):
     assert root2 == root
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest() and len(got) > 2_000_000
     assert one.verify(want, air, boundary, root) is True
+    # ... and CPython's pickle writes the same bytes for the object graph those bytes load as (sharing included)
+    import pickle
+    assert pickle.dumps(pickle.loads(want)) == want
     wrong = [(0, 0, boundary[0][2] + FieldElement(1, field))] + boundary[1:]
     assert one.verify(want, air, wrong, root) is False
