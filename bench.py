@@ -815,12 +815,8 @@ def synthetic_stark_instance(log_fri, s=40):
     field = Field.main()
     p = field.p
     T = (1 << k) - 4 * s
-    a, b = 3, 5
-    col_a, col_b = [], []
-    for _ in range(T):
-        col_a.append(a)
-        col_b.append(b)
-        a, b = b, (a * a + b) % p
+    from synth import synthetic_air_columns
+    col_a, col_b = synthetic_air_columns(T)
     pack = lambda col: b"".join(map(int.to_bytes, col, itertools.repeat(16), itertools.repeat("little")))
     v = MPolynomial.variables(5, field)                  # X, a, b, a', b'
     air = [v[3] - v[2], v[4] - v[1] * v[1] - v[2]]

@@ -6,7 +6,7 @@ runs this.  Output: small JSON fixtures next to this file.  Only DATA is written
 regenerated from seeds, outputs stored in full for small sizes and as SHA-256 of the packed
 16-byte-LE output for larger ones).  No reference source is copied.
 
-usage:  python tests/golden/make_golden.py [--big] [--fri-big]     (--big adds 2^18 / 2^20 NTT digests, --fri-big 2^14 and 2^16 Fri.prove runs; minutes)
+usage:  python tests/golden/make_golden.py [--big] [--fri-big] [--stark-synth [log_fri:s:seed ...]]     (--big adds 2^18 / 2^20 NTT digests, --fri-big 2^14 and 2^16 Fri.prove runs; minutes)
 """
 import hashlib
 import json
@@ -383,10 +383,58 @@ def gen_stark():
     dump("fast_stark.json", out)
 
 
+def gen_stark_synth(cases):
+    """The workload bench.py times for BASELINE configs[4] -- bench.synthetic_stark_instance: the 2-register AIR (a, b) -> (b, a*a + b),
+    T = 2^(log_fri - 4) - 4 s rows, expansion factor 4, s colinearity checks, security level 2 s -- proven by the REFERENCE's
+    FastStark (fast_stark.py:76-178) with a seeded os.urandom.  cases: [(log_fri, s, seed)].  Records are merged into
+    fast_stark_synth.json by (log_fri, s, seed), so the long sizes can be added one at a time (2^14: minutes; 2^16: about an hour)."""
+    import fast_stark as ref_fast_stark
+    import multivariate as ref_multivariate
+    path = os.path.join(HERE, "fast_stark_synth.json")
+    for log_fri, s_checks, seed in cases:
+        rng = random.Random(seed)
+        ref_fast_stark.os.urandom = lambda k, rng=rng: bytes(rng.getrandbits(8) for _ in range(k))
+        T = (1 << (log_fri - 4)) - 4 * s_checks
+        col_a, col_b = synth.synthetic_air_columns(T)
+        trace = [[fe(a), fe(b)] for a, b in zip(col_a, col_b)]
+        v = ref_multivariate.MPolynomial.variables(5, field)                  # X, a, b, a', b'
+        air = [v[3] - v[2], v[4] - v[1] * v[1] - v[2]]
+        boundary = [(0, 0, fe(col_a[0])), (0, 1, fe(col_b[0])), (T - 1, 1, fe(col_b[T - 1]))]
+        stark = ref_fast_stark.FastStark(field, 4, s_checks, 2 * s_checks, 2, T)
+        assert stark.fri_domain_length == 1 << log_fri, (stark.fri_domain_length, log_fri)
+        t0 = time.time()
+        tz, tzc, tzr = stark.preprocess()
+        t1 = time.time()
+        proof = stark.prove(trace, air, boundary, tz, tzc)
+        t2 = time.time()
+        ok = stark.verify(proof, air, boundary, tzr)
+        bad = stark.verify(proof, air, [(0, 0, fe(col_a[0])), (0, 1, fe(col_b[0])), (T - 1, 1, fe(col_b[T - 1] + 1))], tzr)
+        t3 = time.time()
+        ps = ref_ip.ProofStream().deserialize(proof)
+        rec = {"log_fri": log_fri, "num_colinearity_checks": s_checks, "urandom_seed": seed, "expansion_factor": 4, "security_level": 2 * s_checks,
+               "original_trace_length": T, "omicron_domain_length": stark.omicron_domain_length, "fri_domain_length": stark.fri_domain_length,
+               "zerofier_coeffs_sha256": sha_packed(tz.coefficients), "zerofier_root": tzr.hex(),
+               "proof_len": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "num_objects": len(ps.objects),
+               "first_roots": [o.hex() for o in ps.objects[:3]], "verifies": ok, "false_claim_verifies": bad,
+               "reference_seconds": {"preprocess": round(t1 - t0, 1), "prove": round(t2 - t1, 1), "verify_twice": round(t3 - t2, 1)}}
+        out = {"runs": []}
+        if os.path.exists(path):                  # read at merge time: a long size may have been running beside a short one
+            with open(path) as f:
+                out = json.load(f)
+        out["runs"] = [r for r in out["runs"] if (r["log_fri"], r["num_colinearity_checks"], r["urandom_seed"]) != (log_fri, s_checks, seed)] + [rec]
+        out["runs"].sort(key=lambda r: (r["log_fri"], r["num_colinearity_checks"], r["urandom_seed"]))
+        print("synthetic AIR, fri 2^%d s=%d seed %d: preprocess %.1fs prove %.1fs verify x2 %.1fs" % (log_fri, s_checks, seed, t1 - t0, t2 - t1, t3 - t2), ok, bad, flush=True)
+        dump("fast_stark_synth.json", out)
+
+
 if __name__ == "__main__":
     big = "--big" in sys.argv
     if "--fri-big" in sys.argv:
         gen_fri()                  # fri.json again, with the 2^14 proof (the other records are reproduced identically)
+    elif "--stark-synth" in sys.argv:
+        # --stark-synth [log_fri:s:seed ...]; default: the sizes that take minutes in all
+        given = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:] if ":" in a]
+        gen_stark_synth(given or [(10, 8, 21), (12, 40, 22), (14, 40, 23)])
     elif "--stark" in sys.argv:
         gen_stark()
     elif "--poly" in sys.argv:
