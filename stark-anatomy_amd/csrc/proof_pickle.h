@@ -8,7 +8,7 @@
 // proof stream holds -- from a compact description of that graph (the "ops" below), not from objects:
 //
 //   list (top level and nested)      ]  MEMOIZE  [ item APPEND | ( MARK items... APPENDS, in batches of 1000 ) ]
-//   bytes, fresh object              SHORT_BINBYTES / BINBYTES  MEMOIZE
+//   bytes, fresh object              SHORT_BINBYTES / BINBYTES  MEMOIZE   (>= 64 KiB: outside any frame, as _Pickler_write_bytes does)
 //   tuple of three                   items  TUPLE3  MEMOIZE
 //   algebra.FieldElement, first use  global (module and name strings memoized, STACK_GLOBAL, MEMOIZE)  )  NEWOBJ  MEMOIZE
 //                                    }  MEMOIZE  (  'value' int  'field' <Field object>  SETITEMS  BUILD
@@ -144,6 +144,17 @@ struct ProofPickler {
         // always a FRESH object: whether two equal bytes objects are one object is the interpreter's business (b"" is a
         // singleton, one-byte objects sometimes are) -- the describer hands a stream with repeated objects to pickle itself
         boundary();
+        if (len >= FRAME_TARGET) {
+            // _Pickler_write_bytes of _pickle.c: a payload of a frame's size or more is not framed -- the open frame is committed
+            // (dropped when it holds fewer than 4 bytes), opcode, length and data go out bare, and the MEMOIZE that follows
+            // opens the next frame
+            commit_frame();
+            put(0x42); put_u32((uint32_t)len);                                 // BINBYTES (the description's length is a u32)
+            put(data, len);
+            start_frame();
+            memoize();
+            return;
+        }
         if (len < 256) { put(0x43); put((uint8_t)len); }                       // SHORT_BINBYTES
         else { put(0x42); put_u32((uint32_t)len); }                            // BINBYTES
         put(data, len);

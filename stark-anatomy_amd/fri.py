@@ -7,6 +7,7 @@ round (fri.py:71) and the authentication paths of the query phase (fri.py:108-11
 that stay in HBM.  The Fiat-Shamir transcript (ip.py) stays on the host and is byte-identical, so alphas
 and query indices match the reference.
 """
+import pickle as _pickle
 from hashlib import blake2b
 
 from algebra import *
@@ -34,8 +35,8 @@ def library_transcript(proof_stream, rounds):
     (roots): that list has a fixed pickle layout.  The size test counts what the C side counts (3 bytes of pickle opcodes per prior
     item, 67 per root of this commit); the library still answers "unsupported" for anything else it does not take, and then the
     caller's Python loop runs."""
-    if type(proof_stream) is not ProofStream:
-        return None
+    if type(proof_stream) is not ProofStream or _pickle.DEFAULT_PROTOCOL != 4:
+        return None                                      # (csrc/transcript.h writes protocol 4, the default of CPython 3.8 - 3.13)
     prior = list(proof_stream.objects)
     if (len(prior) + rounds < 999 and all(type(o) is bytes and len(o) < 256 for o in prior) and len(set(map(id, prior))) == len(prior)
             and sum(len(o) + 3 for o in prior) + 67 * rounds < 60000):

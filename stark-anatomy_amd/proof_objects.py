@@ -304,8 +304,8 @@ def lazy_objects(proof_stream):
     """`proof_stream.objects` as a LazyProofObjects (swapped in on first use), or None when the stream is not a plain
     ip.ProofStream holding a plain list (a subclass may serialize differently; the reference's SignatureProofStream does)"""
     from ip import ProofStream
-    if type(proof_stream) is not ProofStream:
-        return None
+    if type(proof_stream) is not ProofStream or pickle.DEFAULT_PROTOCOL != 4:
+        return None                                        # (the library writes protocol 4, the default of CPython 3.8 - 3.13)
     objects = proof_stream.objects
     if isinstance(objects, LazyProofObjects):
         return objects

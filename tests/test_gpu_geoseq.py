@@ -3,6 +3,7 @@ sc_geodomain_*; reference code/ntt.py:66-130 as called on the trace domain {omic
 oracle's restatement of the reference recursion on seeded inputs, the general subproduct tree (itself pinned to reference goldens)
 at sizes the oracle cannot reach, and closed forms."""
 import ctypes
+import random
 
 import pytest
 
@@ -162,5 +163,21 @@ def test_agrees_with_the_subproduct_tree(sc, n, coset):
     if n <= 1 << 17:
         g = sc.DeviceVector.from_bytes(synth.synth_packed(8702, 2 * n + n // 2 + 3).tobytes())     # more coefficients than points: chunks
         assert dom.evaluate(g).to_bytes() == tree.evaluate(g).to_bytes()
+    # ... and the DEFINITIONS, by nothing but Python integers (both paths above share the transform kernels): at seeded positions of
+    # the progression the interpolant takes the given values, the zerofier vanishes, the evaluation of f is Horner's; off the domain
+    # the zerofier is the product of (y - x_i)  (ntt.py:66-130)
+    coeffs, zer = synth.unpack_ints(poly.to_bytes()), synth.unpack_ints(dom.zerofier().to_bytes())
+    assert len(coeffs) <= n and len(zer) == n + 1 and zer[n] == 1
+    f_ints, f_vals = synth.unpack_ints(f.to_bytes()), dom.evaluate(f)
+    rng = random.Random(8703 + n)
+    for j in (0, n - 1, rng.randrange(n)):
+        x = c * pow(q, j, P) % P
+        assert po.evaluate(coeffs, x) == synth.synth_ints(8700, 1, j)[0], j
+        assert po.evaluate(zer, x) == 0, j
+        assert po.evaluate(f_ints, x) == int.from_bytes(f_vals.to_bytes(j, 1), "little"), j
+    y, prod, x = synth.synth_ints(8704, 1)[0], 1, c
+    for _ in range(n):
+        prod, x = prod * (y - x) % P, x * q % P
+    assert po.evaluate(zer, y) == prod
     dom.free()
     tree.free()

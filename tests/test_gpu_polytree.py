@@ -135,6 +135,19 @@ def test_round_trips_on_arbitrary_points(sc, k):
     for i in (0, 1, k // 2, k - 1):
         assert got[i] == po.evaluate(fi, pi[i]), i
     assert tree.interpolate(vals).to_bytes() == f.to_bytes()
+    # the definitions in Python integers, for an interpolant that is NOT a round trip of the evaluation kernels: it takes the given
+    # values at its points and has fewer than k coefficients; the zerofier vanishes on the points and off them is prod (y - x_i)
+    given = synth.synth_ints(7502, k)
+    interpolant = synth.unpack_ints(tree.interpolate(sc.DeviceVector.from_bytes(synth.pack_ints(given))).to_bytes())
+    zer = synth.unpack_ints(z.to_bytes())
+    assert len(interpolant) <= k
+    for i in (0, k - 1, (7 * k) // 11):
+        assert po.evaluate(interpolant, pi[i]) == given[i], i
+        assert po.evaluate(zer, pi[i]) == 0, i
+    y, prod = synth.synth_ints(7503, 1)[0], 1
+    for x in pi:
+        prod = prod * (y - x) % P
+    assert po.evaluate(zer, y) == prod
     if k <= 1 << 17:
         # a polynomial with more coefficients than the padded domain is evaluated in chunks
         m = 2 * k + k // 2 + 3

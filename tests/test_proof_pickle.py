@@ -166,3 +166,25 @@ def test_proof_stream_without_lazy_objects_is_the_reference_stream():
     stream.push(b"root")
     stream.push([FieldElement(5, MAIN)])
     assert type(stream.objects) is list and stream.serialize() == pickle.dumps(stream.objects)
+
+
+@pytest.mark.parametrize("size", [65531, 65535, 65536, 65537, 70000, 262143, 262144, 300000])
+@pytest.mark.parametrize("around", [0, 1, 3])
+def test_bytes_objects_of_a_frame_or_more_go_out_unframed(size, around):
+    """_Pickler_write_bytes of _pickle.c: a bytes object of 64 KiB or more commits the open frame and is written outside any frame;
+    the library's pickler and a LazyProofObjects stream must write what CPython writes (a caller-pushed blob next to roots)."""
+    rng = random.Random(size + around)
+    objects = [rng.randbytes(64) for _ in range(around)] + [rng.randbytes(size)] + [rng.randbytes(64) for _ in range(around)]
+    expected = pickle.dumps(objects)
+    assert library_pickle(objects, [MAIN], rng) == expected
+    stream = ProofStream()
+    for o in objects:
+        stream.push(o)
+    lazy = po_.lazy_objects(stream)
+    assert lazy is not None
+    assert stream.serialize() == expected
+    import hashlib
+    assert stream.prover_fiat_shamir() == hashlib.shake_256(expected).digest(32)
+    # two blobs in a row, and one as the only item of a nested list
+    objects = [rng.randbytes(size), rng.randbytes(size), [rng.randbytes(size)], rng.randbytes(7)]
+    assert library_pickle(objects, [MAIN], random.Random(1)) == pickle.dumps(objects)
