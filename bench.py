@@ -448,8 +448,10 @@ def main():
         except Exception as e:       # noqa: BLE001  side measurements never invalidate the headline
             census = {"error": repr(e)[:300]}
         try:
-            # ... and configs[4] as a prover: ShardedFastStark.prove on the synthetic AIR (FRI domain 2^20; 2^14 on shared GPUs)
-            _, _, prover = stark_prove_measure(14 if shared_gpus else 20, 2, 1, rank, world, dev, dist, backend)
+            # ... and configs[4] as a prover at its stated size: ShardedFastStark.prove on the synthetic AIR, FRI domain 2^24 sharded
+            # over the ranks (2^14 when the ranks share GPUs: a functional run); the reference proves this workload byte for byte
+            # at 2^10 ... 2^16 (tests/golden/fast_stark_synth.json)
+            _, _, prover = stark_prove_measure(14 if shared_gpus else 24, 2, 1, rank, world, dev, dist, backend)
         except Exception as e:       # noqa: BLE001
             prover = {"error": repr(e)[:300]}
 
@@ -886,10 +888,10 @@ def stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend,
 
 def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shared_gpus):
     """--workload stark_prove: one step = one ShardedFastStark.prove from the trace to the serialized proof (FRI domain 2^log2n,
-    default 2^20; 2^16 when the ranks share GPUs); value = ms per proof (max over ranks)."""
+    default 2^24 = BASELINE configs[4]; 2^16 when the ranks share GPUs); value = ms per proof (max over ranks)."""
     import torch
     ngpu = torch.cuda.device_count()
-    log_fri = args.log2n or (16 if shared_gpus else 20)
+    log_fri = args.log2n or (16 if shared_gpus else 24)
     steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 1))
     elapsed, same_everywhere, rec = stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend, phases=True)
     if rank == 0:

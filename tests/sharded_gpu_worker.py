@@ -178,6 +178,48 @@ def stark_check(rank, world, dev):
         if not good:
             print("rank", rank, "STARK MISMATCH k", k, root == tzr, len(got), len(want), flush=True)
         ok &= good
+    ok &= stark_reference_goldens(rank, world, dev)
+    return ok
+
+
+def stark_reference_goldens(rank, world, dev, max_log_fri=14):
+    """The workload bench.py times for BASELINE configs[4] (bench.synthetic_stark_instance), as the REFERENCE's FastStark proved it
+    (tests/golden/fast_stark_synth.json, written by make_golden.py --stark-synth with the same seeded os.urandom): every rank must
+    end with those bytes, from the host-list trace and from device-resident columns."""
+    import hashlib
+    import json
+    import random
+    import bench
+    import fast_stark
+    from algebra import FieldElement
+    from ip import ProofStream
+    from sharded_stark import ShardedFastStark
+    golden = json.load(open(os.path.join(REPO, "tests", "golden", "fast_stark_synth.json")))
+    genuine, ok = fast_stark.os.urandom, True
+    try:
+        for rec in golden["runs"]:
+            log_fri, s = rec["log_fri"], rec["num_colinearity_checks"]
+            if log_fri > max_log_fri:
+                continue
+            field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+            stark = ShardedFastStark(field, 4, s, rec["security_level"], 2, T, rank, world, dev)
+            for resident in (False, True):
+                rng = random.Random(rec["urandom_seed"])
+                fast_stark.os.urandom = lambda k, rng=rng: bytes(rng.getrandbits(8) for _ in range(k))
+                tz, layer, root = stark.preprocess(device_resident=resident)
+                if resident:
+                    trace = fast_stark.DeviceTrace.from_packed(packed, field)
+                else:
+                    trace = [[FieldElement(a, field), FieldElement(b, field)] for a, b in zip(*synth.synthetic_air_columns(T))]
+                proof = stark.prove(trace, air, boundary, tz, layer)
+                objects = ProofStream().deserialize(proof).objects
+                good = (root.hex() == rec["zerofier_root"] and [o.hex() for o in objects[:3]] == rec["first_roots"] and len(objects) == rec["num_objects"]
+                        and len(proof) == rec["proof_len"] and hashlib.sha256(proof).hexdigest() == rec["proof_sha256"])
+                if not good:
+                    print("rank", rank, "REFERENCE GOLDEN MISMATCH fri 2^%d resident %s" % (log_fri, resident), root.hex() == rec["zerofier_root"], len(proof), rec["proof_len"], flush=True)
+                ok &= good
+    finally:
+        fast_stark.os.urandom = genuine
     return ok
 
 

@@ -133,3 +133,50 @@ def test_stark_prover_full_size_two_provers_one_proof(sc, log_fri):
     assert pickle.dumps(pickle.loads(want)) == want
     wrong = [(0, 0, boundary[0][2] + FieldElement(1, field))] + boundary[1:]
     assert one.verify(want, air, wrong, root) is False
+
+
+@pytest.mark.parametrize("world", [2])
+def test_stark_prover_full_size_two_ranks(sc, world):
+    """BASELINE configs[4] at its stated size WITH world > 1 (reference code/fast_stark.py:76-178): two processes, each driving the HIP
+    engine on its slabs of the 2^24 FRI domain (both on GPU 0, exchanging through gloo -- everything of the N > 1 prover except RCCL
+    itself), must each end with the byte string the single-GPU prover produces from the same seeded os.urandom stream."""
+    import os
+    import random
+    import socket
+    import subprocess
+    import sys
+    import bench
+    import fast_stark
+    from conftest import REPO
+    from fast_stark import DeviceTrace, FastStark
+    log_fri, s, seed = 24, 40, 5151
+    field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+    genuine = fast_stark.os.urandom
+    try:
+        fast_stark.os.urandom = random.Random(seed).randbytes
+        one = FastStark(field, 4, s, 2 * s, 2, T)
+        tz, tz_codeword, root = one.preprocess(device_resident=True)
+        want = one.prove(DeviceTrace.from_packed(packed, field), air, boundary, tz, tz_codeword)
+    finally:
+        fast_stark.os.urandom = genuine
+    want_sha = hashlib.sha256(want).hexdigest()
+    del tz, tz_codeword, one
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "tests", "stark_fullsize_worker.py"), str(log_fri), str(seed)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if "proof_sha256" in l]
+    assert len(lines) == world, r.stdout[-2000:]
+    for line in lines:
+        words = line.split()
+        assert words[words.index("proof_sha256") + 1] == want_sha, line
+        assert int(words[words.index("proof_len") + 1]) == len(want) > 2_000_000
+        assert words[words.index("zerofier_root") + 1] == root.hex()[:16]
+    out_dir = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out_dir):                       # kept as a record of the run (profiles/r05/)
+        with open(os.path.join(out_dir, "stark_prove_fri2p24_world%d_shared_gpu.txt" % world), "w") as f:
+            f.write("single-GPU prover (fast_stark.FastStark): proof_sha256 %s proof_len %d\n" % (want_sha, len(want)) + "\n".join(lines) + "\n")

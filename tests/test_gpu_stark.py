@@ -63,6 +63,47 @@ def test_fast_stark_seeded_golden_proofs(device_min, monkeypatch):
 
 
 @pytest.mark.parametrize("device_min", [32, 10 ** 9])
+def test_synthetic_air_reference_golden_proofs(device_min, monkeypatch):
+    """The workload bench.py TIMES for BASELINE configs[4] (bench.synthetic_stark_instance: 2-register AIR (a, b) -> (b, a*a + b),
+    T = 2^(log_fri - 4) - 4 s rows, expansion factor 4, s colinearity checks) as the REFERENCE's FastStark.prove proved it with the
+    same seeded os.urandom (tests/golden/fast_stark_synth.json, make_golden.py --stark-synth; code/fast_stark.py:76-178): FRI domains
+    2^10 ... 2^16, i.e. the multi-pass LDE plans, the progression interpolation, the value-domain transition quotients and the
+    library commit loop at sizes where they are the code that runs -- byte for byte, from host rows and from device-resident columns."""
+    import bench
+    import synth
+    monkeypatch.setattr(FastStark, "DEVICE_MIN", device_min)
+    genuine = fast_stark.os.urandom
+    try:
+        for rec in load_golden("fast_stark_synth.json")["runs"]:
+            log_fri, s = rec["log_fri"], rec["num_colinearity_checks"]
+            if device_min > 32 and log_fri > 14:
+                continue                                   # (the host-list data flow at 2^16: minutes of Python lists, nothing new)
+            field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+            assert T == rec["original_trace_length"]
+            stark = FastStark(field, rec["expansion_factor"], s, rec["security_level"], 2, T)
+            assert (stark.omicron_domain_length, stark.fri_domain_length) == (rec["omicron_domain_length"], rec["fri_domain_length"])
+            for resident in ([False, True] if device_min == 32 else [False]):
+                _seed_urandom(rec["urandom_seed"])
+                tz, tz_codeword, tz_root = stark.preprocess(device_resident=True) if resident else stark.preprocess()
+                assert tz_root.hex() == rec["zerofier_root"]
+                if resident:
+                    trace = fast_stark.DeviceTrace.from_packed(packed, field)
+                else:
+                    trace = [[FieldElement(a, field), FieldElement(b, field)] for a, b in zip(*synth.synthetic_air_columns(T))]
+                proof = stark.prove(trace, air, boundary, tz, tz_codeword)
+                ps = ProofStream().deserialize(proof)
+                assert [o.hex() for o in ps.objects[:3]] == rec["first_roots"], (log_fri, resident)
+                assert (len(ps.objects), len(proof)) == (rec["num_objects"], rec["proof_len"])
+                assert hashlib.sha256(proof).hexdigest() == rec["proof_sha256"], (log_fri, resident)      # byte-identical to the reference
+            if log_fri <= 12:
+                assert stark.verify(proof, air, boundary, tz_root) is True
+                wrong = boundary[:2] + [(T - 1, 1, boundary[2][2] + FieldElement(1, field))]
+                assert stark.verify(proof, air, wrong, tz_root) is False
+    finally:
+        fast_stark.os.urandom = genuine
+
+
+@pytest.mark.parametrize("device_min", [32, 10 ** 9])
 def test_fast_stark(device_min, monkeypatch):      # code/test_fast_stark.py:9-65, 3 trials, seeded
     monkeypatch.setattr(FastStark, "DEVICE_MIN", device_min)
     field = Field.main()
