@@ -1,5 +1,5 @@
 // ntt_plan.h -- host-side pass planning for the tiled NTT (digits, tile shapes, strides).
-// Plain C++ shared by the C-ABI library (starkcore.hip) and the CPU emulation used in tests.
+// Plain C++ shared by the C-ABI library (core.hip, fourstep.hip) and the CPU emulation used in tests.
 #pragma once
 #include "ntt_tile.cuh"
 

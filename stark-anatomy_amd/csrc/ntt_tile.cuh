@@ -2,7 +2,7 @@
 // the row axis (length-R decimation-in-frequency NTT per column) with the tile held in LDS.
 //
 // Replaces the recursive radix-2 of reference code/ntt.py:3-18.  The whole transform of length
-// n = N_1 * N_2 * ... * N_m (digits chosen by the host, ntt_plan in starkcore.hip) runs m such passes:
+// n = N_1 * N_2 * ... * N_m (digits chosen by the host, ntt_plan.h, driven from core.hip) runs m such passes:
 //
 //   x[j],  j = j_1*(N_2..N_m) + j_2*(N_3..N_m) + ... + j_m        (natural order in)
 //   X[k],  k = k_1 + N_1*k_2 + N_1*N_2*k_3 + ...                  (natural order out)

@@ -195,7 +195,7 @@ static int emu_batched_impl(const uint64_t* in, uint64_t* out, int kind, int log
     return d.npasses;
 }
 
-// the stages of sc_fourstep_* on one rank's buffers (csrc/starkcore.hip: fourstep_cols / fourstep_rows / fourstep_rows_finish)
+// the stages of sc_fourstep_* on one rank's buffers (csrc/fourstep.hip: fourstep_cols / fourstep_rows / fourstep_rows_finish)
 extern "C" int emu_fourstep_cols(const uint64_t* src, uint64_t* send, uint64_t* recv_diag, int logR, int logcw, const uint64_t* root_cols,
                                  const uint64_t* outer_root, int outer_logorder, uint64_t col_base, int ninv, uint32_t diag_lo, uint32_t diag_n,
                                  int max_tile_log, int loge, int min_tiles_log, int max_col_log, int max_digit_log) {

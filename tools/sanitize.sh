@@ -22,7 +22,7 @@ export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 build_lib() {   # $1 = sanitizer list, $2 = output
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=$1 -fno-omit-frame-pointer -shared-libsan \
-      -Wno-unused-value -Wno-unused-result -Wno-option-ignored -shared -o $2 $CSRC/starkcore.hip 2>&1 | grep -E "error" ; test -f $2
+      -Wno-unused-value -Wno-unused-result -Wno-option-ignored -shared -o $2 $CSRC/core.hip $CSRC/merkle_fri.hip $CSRC/polytree_geo.hip $CSRC/fourstep.hip 2>&1 | grep -E "error" ; test -f $2
 }
 status=0
 if [ "$MODE" = cpu ]; then
