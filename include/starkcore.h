@@ -279,6 +279,30 @@ int sc_fri_fold_commit_dev(const void* d_in, uint64_t N, const uint64_t alpha[2]
 int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
                       const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
                       sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream);
+/* Fri.prove (code/fri.py:115-130) in ONE call: the commit phase as above (fri.py:66-94), then -- without leaving the library --
+ * the last codeword in the clear (fri.py:91), the challenge SHAKE-256(pickle.dumps([prior..., roots..., last codeword])) of
+ * ip.py:18-25 (the FieldElement list pickled as CPython pickles it: csrc/proof_pickle.h), Fri.sample_indices (fri.py:36-51, :122;
+ * BLAKE2b of seed + counter zero bytes), the positions each round opens (fri.py:98-113, :124-128) and ONE kernel that gathers every
+ * opened element and authentication path of the proof.  `extra_count` further (tree, device vector) pairs of N leaves -- FastStark's
+ * committed codewords, fast_stark.py:154-175 -- are opened in the same launch at the sorted positions
+ * {i, i + extra_shift, i + N/2, i + extra_shift + N/2 (mod N)} over the top-level indices i (written to extra_indices_out, 4 *
+ * num_tests of them).  Openings per pair, in this order: codeword j of the commit phase (j < rounds): [a (num_tests), b = a + half
+ * (num_tests)] if j < rounds - 1, then [c = the previous round's a (num_tests)] if j > 0; every further pair: the sorted positions.
+ * `answers` (answers_bytes >= the sum below) = [opened elements, 16 bytes each, padded to a multiple of 256 bytes][paths, 64 * log2
+ * N_pair bytes per opening][the positions, u64 each], pairs concatenated.  A buffer of sc_host_alloc is written by the kernel itself
+ * across the bus (no staging copy); any other host pointer works through two copies.  Outputs of the commit phase as for
+ * sc_fri_commit_dev; last_codeword_out: 16 * (N >> (rounds - 1)) bytes; top_indices_out: num_tests.
+ * SC_ERR_UNSUPPORTED: a transcript or shape this entry does not serve (the caller runs the phases one by one). */
+int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds, uint32_t num_tests,
+                     const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
+                     uint64_t extra_count, const sc_merkle_t* const* extra_trees, const void* const* extra_vecs, uint64_t extra_shift,
+                     sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out,
+                     void* last_codeword_out, uint64_t* top_indices_out, uint64_t* extra_indices_out,
+                     void* answers, uint64_t answers_bytes, void* stream);
+/* pinned, device-visible host memory from a pool kept by the library (an allocation of megabytes costs hundreds of microseconds):
+ * what sc_fri_prove_dev's query kernel writes a proof's openings to */
+int sc_host_alloc(uint64_t bytes, void** out);
+int sc_host_free(void* p);
 /* the host-side pieces of that step on their own (no GPU needed; tests pin them to hashlib / pickle):
  * SHAKE-256 (FIPS 202); Field.sample = big-endian integer of the bytes mod p; pickle.dumps of a list of `count` byte strings
  * (*out_len = bytes needed, copied into out when out_cap suffices) */
@@ -301,6 +325,11 @@ int sc_sample_urandom_dev(uint64_t count, uint32_t width, void* d_out, void* str
  * calls this at the top of a proof; the kernel randomness is drawn while the GPU works on the trace) */
 int sc_urandom_prefetch(uint64_t count, uint32_t width);
 int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]);
+/* ... and of sc_fri_prove_dev's index sampling: BLAKE2b-512 (RFC 7693, unkeyed) of a message of any length; Fri.sample_indices
+ * (fri.py:36-51) for a power-of-two `size`: `number` indices below size, pairwise distinct modulo reduced_size, candidate k = the
+ * big-endian integer of blake2b(seed + k zero bytes) mod size (SC_ERR_UNSUPPORTED where the reference's assertion fails) */
+int sc_blake2b(const void* in, uint64_t len, uint8_t out[64]);
+int sc_fri_sample_indices(const void* seed, uint64_t seed_len, uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out);
 int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len);
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */
 int sc_merkle_open_batch(const sc_merkle_t* tree, const uint64_t* indices, uint64_t k, uint8_t* paths_out /* k*64*log2 N */);

@@ -118,6 +118,7 @@ struct Ctx {
     int wave_local = 1;      // wave-level fences instead of workgroup barriers once a tile's exchanges stay inside one wave
     unsigned long long* trace = nullptr;   // diagnostics: phase stamps of the next fixed-shape pass launches (sc_debug_trace)
     int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)
+    int fri_tail = -1;       // the persistent tail kernel of Fri.commit (csrc/fri_tail.cuh): -1 = environment STARKCORE_FRI_TAIL (default on), 0 / 1
     uint8_t* root_slots = nullptr;        // pinned host memory: roots of asynchronously built Merkle trees in flight
     uint64_t root_seq = 0;
     std::vector<int> free_root_slots;

@@ -736,6 +736,7 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "tw_on_load") g.tuning.tw_on_load = value;
     else if (k == "prune") g.tuning.prune = value;
     else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);
+    else if (k == "fri_tail") g.fri_tail = value ? 1 : 0;
     else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
     return SC_OK;
 }

@@ -503,27 +503,59 @@ struct QueryTrees {
     uint64_t total_threads;
     int count;
 };
+// Done (optional): the answers may go STRAIGHT to pinned host memory (elems_out / paths_out are then host pointers: the stores
+// cross the bus as they are made, no staging buffer and no copy engine behind the kernel); the workgroup that finishes last -- a
+// ticket counter in device memory -- writes `seq` to the host word the caller polls, behind everybody's system-scope fence.
+struct QueryDone {
+    unsigned* ticket = nullptr;             // device counter, zero before the launch; reset by the last workgroup
+    volatile uint64_t* host_flag = nullptr;
+    uint64_t seq = 0;
+};
 __global__ void __launch_bounds__(256) merkle_query_multi_kernel(QueryTrees Q, const uint64_t* __restrict__ indices, Fe* __restrict__ elems_out,
-                                                                 uint64_t* __restrict__ paths_out) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Q.total_threads) return;
+                                                                 uint64_t* __restrict__ paths_out, const QueryDone done = QueryDone()) {
+    const uint64_t t_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t_raw < Q.total_threads;
+    const uint64_t t = live ? t_raw : Q.total_threads - 1;
     int w = 0;
     for (int i = 1; i < Q.count; ++i) if (t >= Q.t[i].thread_off) w = i;
     const QueryTree& T = Q.t[w];
     const uint64_t local = t - T.thread_off;
     const uint64_t q = local / T.per_query;
     const uint32_t r = (uint32_t)(local % T.per_query);
-    const uint64_t idx = indices[T.idx_off + q];
-    if (r == T.per_query - 1) {
-        elems_out[T.idx_off + q] = T.elems[idx];
-        return;
+    // the 4 logN + 1 threads of an opening share one index; it may live in host memory (uncached across the bus): the first lane of
+    // every run of equal openings in the wave loads it, the others take it from that lane
+    const uint64_t qn = T.idx_off + q;                        // the opening's number: non-decreasing along the lanes
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t below = __shfl_up(qn, 1);
+    const bool leader = lane == 0 || below != qn;
+    const uint64_t leaders = __ballot(leader);
+    const uint64_t mine = leader ? indices[qn] : 0ull;
+    const int src = 63 - __builtin_clzll(leaders & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull)));
+    const uint64_t idx = __shfl(mine, src);
+    if (live) {
+        if (r == T.per_query - 1) {
+            elems_out[T.idx_off + q] = T.elems[idx];
+        } else {
+            const uint32_t quarter = r & 3, l = r >> 2;
+            const uint64_t off = (l == 0) ? 0 : (2 * T.N - (T.N >> (l - 1)));
+            const uint64_t node = (idx >> l) ^ 1ull;
+            const ulonglong2* s = reinterpret_cast<const ulonglong2*>(T.levels + 8 * (off + node));
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(paths_out + 8 * (T.path_off + q * T.logN + l));
+            o[quarter] = s[quarter];
+        }
     }
-    const uint32_t quarter = r & 3, l = r >> 2;
-    const uint64_t off = (l == 0) ? 0 : (2 * T.N - (T.N >> (l - 1)));
-    const uint64_t node = (idx >> l) ^ 1ull;
-    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(T.levels + 8 * (off + node));
-    ulonglong2* o = reinterpret_cast<ulonglong2*>(paths_out + 8 * (T.path_off + q * T.logN + l));
-    o[quarter] = s[quarter];
+    if (done.host_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned arrived = atomicAdd(done.ticket, 1u);
+            if (arrived == gridDim.x - 1) {
+                *done.ticket = 0;
+                __threadfence_system();
+                done.host_flag[0] = done.seq;
+            }
+        }
+    }
 }
 
 #endif  // __HIPCC__

@@ -2,6 +2,7 @@
 // Fiat-Shamir step of code/ip.py:18-25 on the host side of the library, and the openings of the query phase.
 #include "core.h"
 #include "merkle.cuh"
+#include "fri_tail.cuh"
 #include "transcript.h"
 #include "proof_pickle.h"
 
@@ -213,8 +214,9 @@ void root_poll_unlocked(std::unique_lock<std::mutex>& lk, const sc_merkle* t) {
     lk.lock();
 }
 
-// everything of a fold but its launch: the power tables of omega^-1 and c = alpha / (2 * offset)
-int fold_prepare(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st, FoldIn* f) {
+// what a fold of an N-element codeword on offset * <omega> needs besides its challenge: the power tables of 1 / omega (N / 2
+// exponents) and 1 / (2 offset) in Montgomery form
+int fold_constants(uint64_t N, Fe offset, Fe omega, hipStream_t st, PowTables** pw_out, Fe* i2o_m_out) {
     if (N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2");
     if (fe_is_zero(offset) || fe_is_zero(omega)) return fail(SC_ERR_DIV_ZERO, "divide by zero");
     // omega^-1 power tables; c = alpha / (2 * offset).  Consecutive rounds of Fri.commit square omega and offset (fri.py:86-87):
@@ -239,8 +241,15 @@ int fold_prepare(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* 
     prev_omega_m = omega_m; prev_offset_m = offset_m; prev_winv_m = winv_m; prev_i2o_m = i2o_m;
     have_prev = true;
     Fe winv = from_mont(winv_m);
+    SCCHK(get_pow(winv, N / 2, st, pw_out));
+    *i2o_m_out = i2o_m;
+    return SC_OK;
+}
+// everything of a fold but its launch: the power tables of omega^-1 and c = alpha / (2 * offset)
+int fold_prepare(const Fe* d_in, uint64_t N, Fe alpha, Fe offset, Fe omega, Fe* d_out, hipStream_t st, FoldIn* f) {
     PowTables* pw;
-    SCCHK(get_pow(winv, N / 2, st, &pw));
+    Fe i2o_m;
+    SCCHK(fold_constants(N, offset, omega, st, &pw, &i2o_m));
     f->in = d_in; f->out = d_out; f->lo = pw->lo; f->hi = pw->hi;
     f->c_m = mont_mul(to_mont(alpha), i2o_m);     // alpha~ * (2 offset)^-1~ / R = c~
     return SC_OK;
@@ -360,6 +369,17 @@ int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]) {
     out[0] = v.lo; out[1] = v.hi;
     return SC_OK;
 }
+int sc_blake2b(const void* in, uint64_t len, uint8_t out[64]) {
+    if ((!in && len) || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    blake2b_512((const uint8_t*)in, (size_t)len, out);
+    return SC_OK;
+}
+int sc_fri_sample_indices(const void* seed, uint64_t seed_len, uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out) {
+    if ((!seed && seed_len) || (!out && number)) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (!fri_sample_indices((const uint8_t*)seed, (size_t)seed_len, size, reduced_size, number, out))
+        return fail(SC_ERR_UNSUPPORTED, "cannot sample more indices than available in last codeword (or size not a power of two)");
+    return SC_OK;
+}
 // pickle.dumps of a list of `count` bytes objects (lens[i] < 256 bytes each, concatenated in `data`): the transcript prefix of
 // ip.py:18-19 for a proof stream that holds nothing but digests.  *out_len = bytes needed; copied when out_cap suffices.
 int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len) {
@@ -399,10 +419,163 @@ int sc_pickle_proof(const void* ops, uint64_t ops_len, const void* moduli, uint3
 // root arriving and the next launch.  omega and offset are squared from round to round (fri.py:86-87).
 // Out: trees_out[r] (rounds trees; [0] is over d_codeword), vecs_out[r] (rounds - 1 folded codewords, library-owned),
 // roots_out (64 * rounds bytes), alphas_out (2 u64 per fold).
-int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
-                      const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
-                      sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream) {
-    std::unique_lock<std::mutex> lk(g_mu);
+// ---- the rounds of the commit phase from 2^16 elements down as ONE persistent launch (csrc/fri_tail.cuh)
+namespace {
+std::vector<TailCtl*> g_tail_ctl_free;
+std::vector<TailHost*> g_tail_host_free;
+uint64_t g_tail_seq = 0;
+int tail_blocks_get(TailCtl** c, TailHost** h) {
+    if (g_tail_ctl_free.empty()) {
+        TailCtl* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, sizeof(TailCtl)));
+        HIPCHK(hipMemset(d, 0, sizeof(TailCtl)));
+        g_tail_ctl_free.push_back(d);
+    }
+    if (g_tail_host_free.empty()) {
+        TailHost* p = nullptr;
+        HIPCHK(hipHostMalloc((void**)&p, sizeof(TailHost), hipHostMallocCoherent | hipHostMallocMapped));
+        memset((void*)p, 0, sizeof(TailHost));
+        g_tail_host_free.push_back(p);
+    }
+    *c = g_tail_ctl_free.back(); g_tail_ctl_free.pop_back();
+    *h = g_tail_host_free.back(); g_tail_host_free.pop_back();
+    return SC_OK;
+}
+constexpr int TAIL_NOT_TAKEN = 1;
+}  // namespace
+
+// Codewords `first` .. rounds - 1 of the commit phase (trees, roots, the folds between them) by fri_tail_kernel; `cur` = codeword
+// first - 1 (n elements, its root already in the transcript `items`), alpha0 = the challenge of the fold that makes codeword `first`
+// (into vecs_out[first - 1], allocated by the caller).  The host thread stays in the loop for the Fiat-Shamir step only: per round
+// it polls the root's pinned slot, hashes the transcript and writes the next challenge to the pinned word the kernel polls.
+// SC_OK: trees_out / vecs_out / roots_out / alphas_out filled to the end (and *last_there set when `last_host` got the last codeword);
+// TAIL_NOT_TAKEN: the shape is not the kernel's, or a wait inside it timed out -- nothing the caller holds has changed.
+static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint64_t n, Fe alpha0, Fe off, Fe om, uint32_t first, uint32_t rounds,
+                           std::vector<uint8_t>& items, uint64_t prior_count, sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out,
+                           uint64_t* alphas_out, hipStream_t st, Fe* last_host, bool* last_there) {
+    if (g.fri_tail < 0) { const char* e = getenv("STARKCORE_FRI_TAIL"); g.fri_tail = (e && atoi(e) == 0) ? 0 : 1; }      // (sc_set_tuning("fri_tail") overrides)
+    const uint32_t R = rounds - first;
+    const uint64_t n0 = n / 2;
+    if (!g.fri_tail || R < 1 || R >= (uint32_t)TAIL_MAX_ROUNDS || n0 > (1ull << TAIL_MAX_LOG) || (n0 >> (R - 1)) < 1) return TAIL_NOT_TAKEN;
+    PowTables* pw;
+    Fe i2o;
+    SCCHK(fold_constants(n, off, om, st, &pw, &i2o));
+    TailCtl* ctl;
+    TailHost* host;
+    SCCHK(tail_blocks_get(&ctl, &host));
+    TailParams P;
+    memset((void*)&P, 0, sizeof P);
+    P.in0 = cur; P.log_n0 = (uint32_t)ilog2(n0); P.rounds = R; P.alpha0 = alpha0; P.pw_lo = pw->lo; P.pw_hi = pw->hi;
+    P.ctl = ctl; P.host = host; P.seq = ++g_tail_seq;
+    static const bool tracing = getenv("STARKCORE_FRI_TIMING") != nullptr;
+    P.trace = tracing ? 1 : 0;
+    std::vector<double> host_us;                           // tracing: when each root was seen and each challenge written (host clock)
+    const auto t_launch = std::chrono::steady_clock::now();
+    auto host_stamp = [&] { if (tracing) host_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count()); };
+    std::vector<Fe*> new_vecs;             // codewords first + 1 ..: allocated here
+    std::vector<uint64_t*> new_levels;
+    const size_t items_before = items.size();
+    auto give_back = [&](bool clean) {
+        for (size_t k = 0; k < new_vecs.size(); ++k) pool_free(new_vecs[k], ((n0 >> (k + 1)) ? (n0 >> (k + 1)) : 1) * sizeof(Fe));
+        for (size_t k = 0; k < new_levels.size(); ++k) pool_free(new_levels[k], (2 * (n0 >> k) - 1) * 64);
+        items.resize(items_before);
+        if (clean) g_tail_ctl_free.push_back(ctl);
+        else if (hipMemset(ctl, 0, sizeof(TailCtl)) == hipSuccess) g_tail_ctl_free.push_back(ctl);      // counters of an aborted call
+        g_tail_host_free.push_back(host);
+    };
+    Fe i2o_k = i2o;
+    for (uint32_t k = 0; k < R; ++k) {
+        const uint64_t nk = n0 >> k;
+        Fe* out = nullptr;
+        if (k == 0) out = vecs_out[first - 1]->d;
+        else {
+            if (pool_alloc((void**)&out, nk * sizeof(Fe)) != hipSuccess) { give_back(true); return fail(SC_ERR_HIP, "out of device memory"); }
+            new_vecs.push_back(out);
+        }
+        uint64_t* levels = nullptr;
+        if (pool_alloc((void**)&levels, (2 * nk - 1) * 64) != hipSuccess) { give_back(true); return fail(SC_ERR_HIP, "out of device memory"); }
+        new_levels.push_back(levels);
+        P.rd[k].out = out; P.rd[k].levels = levels; P.rd[k].i2o_m = i2o_k;
+        const Fe sq = mont_mul(i2o_k, i2o_k);          // the next codeword's offset is this one's squared (fri.py:87): 1/(2 o^2) = 2 (1/(2 o))^2
+        i2o_k = fe_add(sq, sq);
+    }
+    uint32_t nwg = 1;                                          // the widest round's workgroups (a workgroup leaves when no later round needs it)
+    for (uint32_t k = 0; k < R; ++k) nwg = std::max(nwg, tail_workgroups(P.log_n0 - k));
+    hipLaunchKernelGGL(fri_tail_kernel, dim3(nwg), dim3(256), 0, st, P);
+    if (hipGetLastError() != hipSuccess) { give_back(true); return TAIL_NOT_TAKEN; }
+    std::vector<uint8_t> bytes;
+    bool aborted = false;
+    for (uint32_t k = 0; k < R && !aborted; ++k) {
+        volatile uint64_t* slot = host->root[k];
+        bool landed = false;
+        lk.unlock();
+        for (long spin = 0; spin < SPIN_POLLS; ++spin) {
+            if (__atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == P.seq) { landed = true; break; }
+            if ((spin & 1023) == 1023 && __atomic_load_n(&host->abort_flag[0], __ATOMIC_ACQUIRE) == P.seq) break;
+        }
+        lk.lock();
+        if (!landed) {
+            (void)hipStreamSynchronize(st);                    // the kernel gives up on its own (TAIL_SPIN_LIMIT)
+            (void)hipGetLastError();
+            landed = __atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == P.seq && __atomic_load_n(&host->abort_flag[0], __ATOMIC_ACQUIRE) != P.seq;
+            if (!landed) { aborted = true; break; }
+        }
+        const uint32_t r = first + k;
+        host_stamp();
+        memcpy(roots_out + 64 * r, (const void*)slot, 64);
+        if (k + 1 == R) break;
+        transcript_item(items, roots_out + 64 * r, 64);
+        if (!transcript_bytes(items, (size_t)(prior_count + r + 1), bytes)) { aborted = true; break; }
+        uint8_t digest[32];
+        shake256(bytes.data(), bytes.size(), digest, 32);
+        const Fe alpha = sample_field(digest, 32);
+        alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
+        host->alpha[k + 1][0] = alpha.lo;
+        host->alpha[k + 1][1] = alpha.hi;
+        __atomic_store_n(&host->alpha[k + 1][2], P.seq, __ATOMIC_RELEASE);
+        host_stamp();
+    }
+    if (aborted) {
+        (void)hipStreamSynchronize(st);                        // (a kernel still waiting for a challenge that will not come times out)
+        (void)hipGetLastError();
+        give_back(false);
+        return TAIL_NOT_TAKEN;
+    }
+    if (tracing) {
+        // device stamps are a 100 MHz counter: 10 ns each
+        fprintf(stderr, "fri_tail_kernel n0=2^%u, %u rounds (%u workgroups); per round, us: leaves | subtree | barrier | top levels + root out | challenge back || host: root seen, challenge written (since launch)\n", P.log_n0, R, nwg);
+        for (uint32_t k = 0; k < R; ++k) {
+            const volatile uint64_t* sp = host->stamps[k];
+            auto d = [&](int a, int b) { return (double)(sp[b] - sp[a]) / 100.0; };
+            const bool multi = tail_workgroups(P.log_n0 - k) > 1;
+            fprintf(stderr, "  2^%-2u  %6.1f | %6.1f | %6.1f | %6.1f | %6.1f || %8.1f %8.1f   (round start at %.1f)\n", P.log_n0 - k, d(0, 1), d(1, 2), multi ? d(2, 3) : 0.0, multi ? d(3, 4) : d(2, 4),
+                    k + 1 < R ? d(4, 5) : 0.0, host_us.size() > 2 * k ? host_us[2 * k] : 0.0, host_us.size() > 2 * k + 1 ? host_us[2 * k + 1] : 0.0, (double)(sp[0] - host->stamps[0][0]) / 100.0);
+        }
+    }
+    const uint64_t n_last = n0 >> (R - 1);
+    if (last_host && last_there && n_last <= TAIL_LAST_MAX) {
+        bool there = false;
+        for (long spin = 0; spin < SPIN_POLLS && !there; ++spin) there = __atomic_load_n(&host->last_flag[0], __ATOMIC_ACQUIRE) == P.seq;
+        if (there) { memcpy(last_host, (const void*)host->last, n_last * sizeof(Fe)); *last_there = true; }
+    }
+    for (uint32_t k = 0; k < R; ++k) {
+        const uint64_t nk = n0 >> k;
+        if (k > 0) vecs_out[first + k - 1] = new sc_vec{new_vecs[k - 1], nk};
+        sc_merkle* t = new sc_merkle{new_levels[k], nk, ilog2(nk)};
+        memcpy(t->root, roots_out + 64 * (first + k), 64);
+        t->have_root = true;
+        t->st = st;
+        trees_out[first + k] = t;
+    }
+    g_tail_ctl_free.push_back(ctl);
+    g_tail_host_free.push_back(host);
+    return SC_OK;
+}
+
+static int fri_commit_locked(std::unique_lock<std::mutex>& lk, const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
+                             const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
+                             sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream,
+                             Fe* last_host = nullptr, bool* last_there = nullptr) {
     SCCHK(ensure_init());
     if (!d_codeword || !trees_out || !roots_out || (rounds > 1 && (!vecs_out || !alphas_out)) || rounds < 1) return fail(SC_ERR_BAD_ARG, "null argument");
     if (N < 2 || !is_pow2(N) || rounds > 60 || (N >> (rounds - 1)) < 1) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
@@ -452,6 +625,12 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
         shake256(bytes.data(), bytes.size(), digest, 32);
         const Fe alpha = sample_field(digest, 32);
         alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
+        if (n / 2 <= (1ull << TAIL_MAX_LOG)) {
+            // from here on every round is latency: the rest of the commit phase is one persistent launch (csrc/fri_tail.cuh)
+            rc = fri_tail_rounds(lk, cur, n, alpha, off, om, r + 1, rounds, items, prior_count, vecs_out, trees_out, roots_out, alphas_out, st, last_host, last_there);
+            if (rc == SC_OK) return SC_OK;
+            if (rc != TAIL_NOT_TAKEN) return undo(rc);
+        }
         rc = fold_and_build(cur, n, alpha, off, om, nxt->d, &trees_out[r + 1], st);
         if (rc != SC_OK) return undo(rc);
         ++made_trees;
@@ -459,6 +638,234 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
         n /= 2;
         om = fe_mul(om, om);
         off = fe_mul(off, off);
+    }
+    return SC_OK;
+}
+int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
+                      const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
+                      sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream) {
+    std::unique_lock<std::mutex> lk(g_mu);
+    return fri_commit_locked(lk, d_codeword, N, offset, omega, rounds, prior_data, prior_lens, prior_count, vecs_out, trees_out, roots_out, alphas_out, stream);
+}
+
+// ---- pinned, device-visible host memory from a pool (hipHostMalloc of megabytes costs hundreds of microseconds; a proof's openings
+// are 2-3 MB).  What sc_fri_prove_dev writes its answers to: the query kernel stores them across the bus itself.
+namespace {
+std::multimap<size_t, void*> g_host_pool;               // free buffers by (rounded) size
+std::map<void*, size_t> g_host_live;                    // buffers handed out
+unsigned* g_query_ticket = nullptr;                     // device counter of merkle_query_multi_kernel's completion protocol
+uint64_t* g_query_flag = nullptr;                       // pinned word the last workgroup writes the call's sequence number to
+uint64_t g_query_seq = 0;
+size_t host_pool_size(size_t bytes) { size_t b = 4096; while (b < bytes) b <<= 1; return b; }
+}  // namespace
+int sc_host_alloc(uint64_t bytes, void** out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!out) return fail(SC_ERR_BAD_ARG, "null argument");
+    const size_t want = host_pool_size((size_t)bytes);
+    auto it = g_host_pool.find(want);
+    void* p = nullptr;
+    if (it != g_host_pool.end()) { p = it->second; g_host_pool.erase(it); }
+    else HIPCHK(hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped));
+    g_host_live[p] = want;
+    *out = p;
+    return SC_OK;
+}
+int sc_host_free(void* p) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!p) return SC_OK;
+    auto it = g_host_live.find(p);
+    if (it == g_host_live.end()) return fail(SC_ERR_BAD_ARG, "not a buffer of sc_host_alloc");
+    g_host_pool.emplace(it->second, p);
+    g_host_live.erase(it);
+    return SC_OK;
+}
+
+// Fri.prove (fri.py:115-130) in ONE call -- see include/starkcore.h.  The commit phase is sc_fri_commit_dev's; then, without
+// leaving the library: the last codeword comes to the host, the transcript [prior digests..., roots..., [last codeword]] is
+// pickled (csrc/proof_pickle.h) and hashed (SHAKE-256, ip.py:18-25), the top-level indices are sampled (fri.py:36-51, :122), the
+// positions every round opens are derived from them (fri.py:124-128: a, b = a + half of the round, c = a of the previous round;
+// each codeword's positions in the order a..., b..., c...), the caller's further (tree, vector) pairs get the sorted positions
+// {i, i + shift, i + N/2, i + shift + N/2 mod N} (fast_stark.py:154-158), and ONE kernel gathers every element and path.
+// `answers`: [elements 16 B each, padded to 256 B][paths][indices u64]; a buffer of sc_host_alloc is written by the kernel
+// directly (no staging, no copy engine; the last workgroup flags completion in a pinned word the host polls), any other host
+// pointer is served through device scratch and two copies.
+int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds, uint32_t num_tests,
+                     const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
+                     uint64_t extra_count, const sc_merkle_t* const* extra_trees, const void* const* extra_vecs, uint64_t extra_shift,
+                     sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out,
+                     void* last_codeword_out, uint64_t* top_indices_out, uint64_t* extra_indices_out,
+                     void* answers, uint64_t answers_bytes, void* stream) {
+    std::unique_lock<std::mutex> lk(g_mu);
+    if (!last_codeword_out || !top_indices_out || !answers || (extra_count && (!extra_trees || !extra_vecs || !extra_indices_out)) || !num_tests)
+        return fail(SC_ERR_BAD_ARG, "null argument");
+    if (rounds < 1 || rounds > 60 || N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
+    const uint64_t n_last = N >> (rounds - 1);
+    const uint32_t s = num_tests;
+    if (n_last < 1 || s > n_last || rounds + extra_count > QUERY_MAX_TREES) return fail(SC_ERR_UNSUPPORTED, "shape not served by the one-call prover");
+    for (uint64_t t = 0; t < extra_count; ++t)
+        if (!extra_trees[t] || !extra_vecs[t] || extra_trees[t]->N != N) return fail(SC_ERR_BAD_ARG, "further codewords must have the domain's length");
+    // sizes first: nothing is enqueued for a call that cannot be answered
+    uint64_t total = 0;
+    size_t path_bytes = 0;
+    for (uint32_t j = 0; j < rounds; ++j) {
+        const uint64_t k = (j + 1 < rounds ? 2ull * s : 0) + (j > 0 ? s : 0);
+        total += k;
+        path_bytes += k * 64 * (size_t)ilog2(N >> j);
+    }
+    total += extra_count * 4ull * s;
+    path_bytes += extra_count * 4ull * s * 64 * (size_t)ilog2(N);
+    const size_t el_bytes = (total * sizeof(Fe) + 255) & ~(size_t)255;
+    if (answers_bytes < el_bytes + path_bytes + total * 8) return fail(SC_ERR_BAD_ARG, "answer buffer too small");
+    // STARKCORE_FRI_TIMING=1: the call's phases on stderr (host clock, microseconds) -- tools/fri_prove_timing.py
+    static const bool timing = getenv("STARKCORE_FRI_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point tp[8];
+    auto stamp = [&](int i) { if (timing) tp[i] = std::chrono::steady_clock::now(); };
+    stamp(0);
+    bool last_there = false;       // the persistent tail kernel hands the last codeword over with its roots
+    int rc = fri_commit_locked(lk, d_codeword, N, offset, omega, rounds, prior_data, prior_lens, prior_count, vecs_out, trees_out, roots_out, alphas_out, stream,
+                               (Fe*)last_codeword_out, &last_there);
+    if (rc != SC_OK) return rc;
+    stamp(1);
+    hipStream_t st = pick_stream(stream);
+    auto undo = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        for (uint32_t i = 0; i < rounds; ++i) { sc_merkle* t = trees_out[i]; if (!t) continue; pool_free(t->d_levels, (2 * t->N - 1) * 64); delete t; trees_out[i] = nullptr; }
+        for (uint32_t i = 0; i + 1 < rounds; ++i) { if (!vecs_out[i]) continue; pool_free(vecs_out[i]->d, (vecs_out[i]->n ? vecs_out[i]->n : 1) * sizeof(Fe)); delete vecs_out[i]; vecs_out[i] = nullptr; }
+        return code;
+    };
+    // the last codeword in the clear (fri.py:91): its tree is built, so the fold that made it has run
+    const Fe* d_last = rounds > 1 ? vecs_out[rounds - 2]->d : (const Fe*)d_codeword;
+    if (!last_there && (hipMemcpyAsync(last_codeword_out, d_last, n_last * sizeof(Fe), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+        return undo(fail(SC_ERR_HIP, "copy of the last codeword failed"));
+    stamp(2);
+    // transcript: [prior..., roots..., [FieldElement(v) for v in last codeword]]
+    std::vector<uint8_t> ops;
+    auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) ops.push_back((uint8_t)(v >> (8 * i))); };
+    ops.reserve(16 + 72 * (prior_count + rounds) + 29 * n_last);
+    ops.push_back('L'); put32((uint32_t)(prior_count + rounds + 1));
+    {
+        const uint8_t* p = (const uint8_t*)prior_data;
+        for (uint64_t i = 0; i < prior_count; ++i) { ops.push_back('B'); put32(prior_lens[i]); ops.insert(ops.end(), p, p + prior_lens[i]); p += prior_lens[i]; }
+    }
+    for (uint32_t r = 0; r < rounds; ++r) { ops.push_back('B'); put32(64); ops.insert(ops.end(), roots_out + 64 * r, roots_out + 64 * r + 64); }
+    ops.push_back('L'); put32((uint32_t)n_last);
+    for (uint64_t i = 0; i < n_last; ++i) {
+        ops.push_back('E'); put32(0);
+        for (int b = 0; b < 8; ++b) ops.push_back((uint8_t)(i >> (8 * b)));
+        const uint8_t* v = (const uint8_t*)last_codeword_out + 16 * i;
+        ops.insert(ops.end(), v, v + 16);
+    }
+    uint8_t modulus[17] = {0};
+    { const uint64_t plo = P_LO, phi = P_HI; memcpy(modulus, &plo, 8); memcpy(modulus + 8, &phi, 8); }
+    ProofPickler pk;
+    pk.moduli = modulus; pk.nfields = 1; pk.modulus_bytes = 17;
+    if (!pk.run(ops.data(), ops.size())) return undo(fail(SC_ERR_UNSUPPORTED, "transcript not described"));
+    uint8_t seed[32];
+    shake256(pk.base, pk.used, seed, 32);
+    stamp(3);
+    if (!fri_sample_indices(seed, 32, N / 2, n_last, s, top_indices_out)) return undo(fail(SC_ERR_UNSUPPORTED, "cannot sample that many indices"));
+    stamp(7);
+    // positions: written where the kernel reads them (behind the answers)
+    uint8_t* const base = (uint8_t*)answers;
+    uint64_t* idx = (uint64_t*)(base + el_bytes + path_bytes);
+    std::vector<uint64_t> cur(top_indices_out, top_indices_out + s), prev;
+    uint64_t at = 0;
+    for (uint32_t j = 0; j < rounds; ++j) {
+        const uint64_t half = (N >> j) / 2;
+        if (j + 1 < rounds) {
+            for (uint32_t t = 0; t < s; ++t) cur[t] %= half;
+            for (uint32_t t = 0; t < s; ++t) idx[at++] = cur[t];
+            for (uint32_t t = 0; t < s; ++t) idx[at++] = cur[t] + half;
+        }
+        if (j > 0) for (uint32_t t = 0; t < s; ++t) idx[at++] = prev[t];
+        prev = cur;
+    }
+    if (extra_count) {
+        std::vector<uint64_t> quad;
+        quad.reserve(4 * s);
+        for (uint32_t t = 0; t < s; ++t) quad.push_back(top_indices_out[t]);
+        for (uint32_t t = 0; t < s; ++t) quad.push_back((top_indices_out[t] + extra_shift) % N);
+        for (uint32_t t = 0; t < 2 * s; ++t) quad.push_back((quad[t] + N / 2) % N);
+        std::sort(quad.begin(), quad.end());
+        memcpy(extra_indices_out, quad.data(), 4ull * s * 8);
+        for (uint64_t e = 0; e < extra_count; ++e) { memcpy(idx + at, quad.data(), 4ull * s * 8); at += 4ull * s; }
+    }
+    stamp(4);
+    // one launch for every opening of the proof
+    const bool direct = g_host_live.count(answers) != 0;
+    Fe* d_el; uint64_t* d_paths; const uint64_t* d_idx;
+    if (direct) {
+        d_el = (Fe*)base; d_paths = (uint64_t*)(base + el_bytes); d_idx = idx;
+        if (!g_query_ticket) {
+            if (hipMalloc((void**)&g_query_ticket, 256) != hipSuccess || hipMemset(g_query_ticket, 0, 256) != hipSuccess ||
+                hipHostMalloc((void**)&g_query_flag, 256, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+                return undo(fail(SC_ERR_HIP, "completion flag of the query kernel"));
+            g_query_flag[0] = 0;
+        }
+    } else {
+        void* buf;
+        rc = scratch(5, el_bytes + path_bytes + total * 8 + 256, &buf);
+        if (rc != SC_OK) return undo(rc);
+        d_el = (Fe*)buf; d_paths = (uint64_t*)((char*)buf + el_bytes); d_idx = (const uint64_t*)((char*)buf + el_bytes + path_bytes);
+        if (hipMemcpyAsync((void*)d_idx, idx, total * 8, hipMemcpyHostToDevice, st) != hipSuccess) return undo(fail(SC_ERR_HIP, "index upload"));
+    }
+    QueryTrees Q;
+    Q.count = 0;
+    Q.total_threads = 0;
+    uint64_t off = 0, poff = 0;
+    for (uint64_t t = 0; t < rounds + extra_count; ++t) {
+        const bool own = t < rounds;
+        const sc_merkle* tree = own ? trees_out[t] : extra_trees[t - rounds];
+        const uint64_t k = own ? ((t + 1 < rounds ? 2ull * s : 0) + (t > 0 ? s : 0)) : 4ull * s;
+        if (!k) continue;
+        QueryTree& T = Q.t[Q.count++];
+        T.levels = tree->d_levels;
+        T.elems = own ? (t == 0 ? (const Fe*)d_codeword : vecs_out[t - 1]->d) : (const Fe*)extra_vecs[t - rounds];
+        T.N = tree->N;
+        T.logN = (uint32_t)tree->logN;
+        T.per_query = 4 * T.logN + 1;
+        T.thread_off = Q.total_threads;
+        T.idx_off = off;
+        T.path_off = poff;
+        Q.total_threads += k * T.per_query;
+        off += k;
+        poff += k * (uint64_t)tree->logN;
+    }
+    QueryDone done;
+    const uint64_t seq = ++g_query_seq;
+    if (direct) { done.ticket = g_query_ticket; done.host_flag = g_query_flag; done.seq = seq; }
+    hipLaunchKernelGGL(merkle_query_multi_kernel, dim3((unsigned)((Q.total_threads + 255) / 256)), dim3(256), 0, st, Q, d_idx, d_el, d_paths, done);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return undo(fail(SC_ERR_HIP, hipGetErrorString(e)));
+    stamp(5);
+    if (direct) {
+        volatile uint64_t* flag = g_query_flag;
+        bool landed = false;
+        for (long spin = 0; spin < SPIN_POLLS; ++spin) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { landed = true; break; }
+            if ((spin & 4095) == 4095) {
+                e = hipStreamQuery(st);
+                if (e != hipErrorNotReady) break;
+                (void)hipGetLastError();
+            }
+        }
+        if (!landed) {
+            (void)hipGetLastError();
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess || __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return undo(fail(SC_ERR_HIP, "the query kernel did not complete"));
+        }
+    } else {
+        if (hipMemcpyAsync(base, d_el, total * sizeof(Fe), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            (path_bytes && hipMemcpyAsync(base + el_bytes, d_paths, path_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return undo(fail(SC_ERR_HIP, "copy of the openings failed"));
+    }
+    if (timing) {
+        stamp(6);
+        auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };
+        fprintf(stderr, "sc_fri_prove_dev N=2^%d: commit %.1f | last codeword to host %.1f | pickle + shake %.1f | sample indices %.1f | positions %.1f | launch %.1f | "
+                        "wait for the openings (%s) %.1f | total %.1f us\n", ilog2(N), us(0, 1), us(1, 2), us(2, 3), us(3, 7), us(7, 4), us(4, 5), direct ? "pinned" : "staged", us(5, 6), us(0, 6));
     }
     return SC_OK;
 }

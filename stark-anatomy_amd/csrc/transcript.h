@@ -72,6 +72,80 @@ inline void shake256(const uint8_t* in, size_t len, uint8_t* out, size_t outlen)
     }
 }
 
+
+// BLAKE2b-512, unkeyed, of a message of any length (RFC 7693) on the host: Fri.sample_indices hashes `seed + bytes(counter)` with it
+// (code/fri.py:36-51).  tests/test_host_cpu.py compares it with hashlib.blake2b.
+inline uint64_t b2_rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+inline void blake2b_compress(uint64_t h[8], const uint8_t block[128], uint64_t t, bool last) {
+    static const uint64_t IV[8] = {0x6A09E667F3BCC908ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull, 0xA54FF53A5F1D36F1ull,
+                                   0x510E527FADE682D1ull, 0x9B05688C2B3E6C1Full, 0x1F83D9ABFB41BD6Bull, 0x5BE0CD19137E2179ull};
+    static const uint8_t SIGMA[12][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+                                          {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+                                          {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+                                          {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+                                          {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+                                          {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+    uint64_t m[16], v[16];
+    for (int i = 0; i < 16; ++i) memcpy(&m[i], block + 8 * i, 8);
+    for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = IV[i]; }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+    auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+        v[a] = v[a] + v[b] + x; v[d] = b2_rotr(v[d] ^ v[a], 32);
+        v[c] = v[c] + v[d];     v[b] = b2_rotr(v[b] ^ v[c], 24);
+        v[a] = v[a] + v[b] + y; v[d] = b2_rotr(v[d] ^ v[a], 16);
+        v[c] = v[c] + v[d];     v[b] = b2_rotr(v[b] ^ v[c], 63);
+    };
+    for (int r = 0; r < 12; ++r) {
+        const uint8_t* s = SIGMA[r];
+        G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+        G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+        G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+        G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+inline void blake2b_512(const uint8_t* in, size_t len, uint8_t out[64]) {
+    uint64_t h[8] = {0x6A09E667F3BCC908ull ^ 0x01010040ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull, 0xA54FF53A5F1D36F1ull,
+                     0x510E527FADE682D1ull, 0x9B05688C2B3E6C1Full, 0x1F83D9ABFB41BD6Bull, 0x5BE0CD19137E2179ull};
+    uint64_t t = 0;
+    while (len > 128) {                    // the last block (also a full one) is compressed with the final flag
+        t += 128;
+        blake2b_compress(h, in, t, false);
+        in += 128;
+        len -= 128;
+    }
+    uint8_t block[128];
+    memset(block, 0, 128);
+    memcpy(block, in, len);
+    blake2b_compress(h, block, t + len, true);
+    memcpy(out, h, 64);
+}
+
+// Fri.sample_indices (code/fri.py:36-51) for a power-of-two `size`: `number` indices below `size`, pairwise distinct modulo
+// `reduced_size`, candidate k = the big-endian integer of blake2b(seed + k zero bytes) mod size.  false: not enough room
+// (fri.py:37-38 assert; the caller lets the reference's assertion speak).
+inline bool fri_sample_indices(const uint8_t* seed, size_t seed_len, uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out) {
+    if (number > reduced_size || !size || (size & (size - 1)) || !reduced_size) return false;
+    std::vector<uint8_t> msg(seed, seed + seed_len);
+    std::vector<uint64_t> residues;
+    uint32_t have = 0;
+    while (have < number) {
+        uint8_t d[64];
+        blake2b_512(msg.data(), msg.size(), d);
+        msg.push_back(0);                   // bytes(counter) is `counter` zero bytes (fri.py:44)
+        uint64_t low = 0;
+        for (int i = 0; i < 8; ++i) low = (low << 8) | d[56 + i];      // the integer's low 64 bits: size is a power of two <= 2^63
+        const uint64_t index = low & (size - 1), res = index % reduced_size;
+        bool seen = false;
+        for (uint64_t r : residues) if (r == res) { seen = true; break; }
+        if (seen) continue;
+        residues.push_back(res);
+        out[have++] = index;
+    }
+    return true;
+}
+
 constexpr size_t TRANSCRIPT_MAX_ITEMS = 999;        // one APPENDS batch
 constexpr size_t TRANSCRIPT_MAX_BYTES = 60000;      // one frame (the pickler starts a new one at 64 KiB)
 

@@ -333,7 +333,7 @@ class FastStark:
             return quadrupled_indices
         together = None
         if all(_po.eligible(codeword) for codeword in committed) and type(proof_stream) is ProofStream:
-            together = AlsoOpen(lambda indices: (committed, [opened_positions(indices)] * len(committed)))
+            together = AlsoOpen(lambda indices: (committed, [opened_positions(indices)] * len(committed)), codewords=committed, shift=self.expansion_factor)
         indices = self.fri.prove(combined_codeword, proof_stream, together) if together is not None else self.fri.prove(combined_codeword, proof_stream)
 
         quadrupled_indices = opened_positions(indices)

@@ -22,10 +22,14 @@ from starkcore import DeviceCodeword, DeviceVector, query_codewords
 
 class AlsoOpen:
     """Openings a caller wants together with the query phase: `requests(top_level_indices)` -> (codewords, index lists); `answers`
-    = [(packed residues, paths array)] per codeword once the query phase has fetched them, or None if it took another route"""
+    = [(packed residues, paths array)] per codeword once the query phase has fetched them, or None if it took another route.
+    codewords / shift (optional): the same request as data -- device codewords of the domain's length, all opened at the sorted
+    positions {i, i + shift, i + N/2, i + shift + N/2 (mod N)} over the top-level indices i (fast_stark.py:154-158) -- which lets
+    the library derive the positions itself and serve Fri.prove in one call (sc_fri_prove_dev)"""
 
-    def __init__(self, requests):
+    def __init__(self, requests, codewords=None, shift=None):
         self.requests, self.answers = requests, None
+        self.codewords, self.shift = codewords, shift
 
 
 def library_transcript(proof_stream, rounds):
@@ -93,6 +97,15 @@ class Fri:
             x = x * self.omega
         return points
 
+    def _check_omega_order(self, length):
+        """fri.py:68 asserts omega_r^(N_r - 1) == omega_r^-1, i.e. omega_r^(N_r) == 1, in every round; omega_r = omega^(2^r) and
+        N_r = N / 2^r, so every round's condition is omega^N == 1: checked once per (omega, length) -- a power and an inversion in
+        Python integers are 0.1 ms, a twentieth of a 2^22 proof"""
+        key = (self.omega.value, length)
+        if getattr(self, "_order_checked", None) != key:
+            assert(self.omega ^ (length - 1) == self.omega.inverse()), "error in commit: omega does not have the right order!"
+            self._order_checked = key
+
     def _on_device(self, codeword):
         if isinstance(codeword, DeviceCodeword):
             return codeword
@@ -106,9 +119,7 @@ class Fri:
         and only the Fiat-Shamir step sits between a root arriving and the next launch."""
         codeword = self._on_device(codeword)
         rounds = self.num_rounds()
-        # fri.py:68 asserts omega_r^(N_r - 1) == omega_r^-1, i.e. omega_r^(N_r) == 1, in every round; omega_r = omega^(2^r) and
-        # N_r = N / 2^r, so every round's condition is omega^N == 1: checked once, before anything is enqueued
-        assert(self.omega ^ (len(codeword) - 1) == self.omega.inverse()), "error in commit: omega does not have the right order!"
+        self._check_omega_order(len(codeword))             # (before anything is enqueued)
         codewords = None
         if len(codeword) >= 2 and codeword._tree is None and library_transcript(proof_stream, rounds) is not None:
             codewords = self._commit_in_library(codeword, proof_stream, rounds)
@@ -191,9 +202,93 @@ class Fri:
         """also_open (optional, an AlsoOpen): further device codewords to open at positions that depend on the sampled indices --
         FastStark's committed codewords (fast_stark.py:154-175) -- fetched in the SAME device round trip as the query phase"""
         assert(self.domain_length == len(codeword)), "initial codeword length does not match length of initial codeword"
+        top_level_indices = self._prove_in_library(codeword, proof_stream, also_open)
+        if top_level_indices is not None:
+            return top_level_indices
         codewords = self.commit(codeword, proof_stream)
         top_level_indices = self.sample_indices(proof_stream.prover_fiat_shamir(), len(codewords[0]) // 2, len(codewords[-1]), self.num_colinearity_tests)
         self._query_all(codewords, top_level_indices, proof_stream, also_open)
+        return top_level_indices
+
+    def _prove_in_library(self, codeword, proof_stream, also_open):
+        """fri.py:115-130 as ONE library call (sc_fri_prove_dev): commit phase, the challenge over the transcript with the last
+        codeword, the sampled indices, and one kernel that writes every opening of the proof into pinned host memory.  What comes
+        back is pushed as the reference pushes it -- roots, the last codeword, per round s triples and 3 s paths -- in described
+        form (proof_objects); None when the stream or the codewords are not of the kind the library serves (the phases then run
+        one by one, with the same bytes)."""
+        import ctypes
+        import numpy as np
+        rounds, s = self.num_rounds(), self.num_colinearity_tests
+        N = self.domain_length
+        if not (isinstance(codeword, DeviceCodeword) and _po.eligible(codeword) and codeword._tree is None and N >= 2 and N & (N - 1) == 0):
+            return None
+        if self.field.p != Field.P_MAIN or s > (N >> (rounds - 1)) or s < 1 or library_transcript(proof_stream, rounds) is None:
+            return None
+        extra = []
+        if also_open is not None:
+            extra = also_open.codewords
+            if extra is None or also_open.shift is None or not all(isinstance(cw, DeviceCodeword) and _po.eligible(cw) and len(cw) == N for cw in extra):
+                return None
+        if rounds + len(extra) > 32:
+            return None
+        self._check_omega_order(N)
+        prior = list(proof_stream.objects)
+        k, ne = len(prior), len(extra)
+        vecs = (ctypes.c_void_p * max(1, rounds - 1))()
+        trees = (ctypes.c_void_p * rounds)()
+        roots = ctypes.create_string_buffer(64 * rounds)
+        alphas = (ctypes.c_uint64 * max(2, 2 * (rounds - 1)))()
+        n_last = N >> (rounds - 1)
+        last_raw = ctypes.create_string_buffer(16 * n_last)
+        top = (ctypes.c_uint64 * s)()
+        quad = (ctypes.c_uint64 * (4 * s))()
+        # openings per pair (see include/starkcore.h): codeword j: 2 s of its own round (j < rounds - 1) + s for the round before (j > 0)
+        counts = [(2 * s if j + 1 < rounds else 0) + (s if j > 0 else 0) for j in range(rounds)] + [4 * s] * ne
+        depths = [(N >> j).bit_length() - 1 for j in range(rounds)] + [N.bit_length() - 1] * ne
+        total = sum(counts)
+        el_bytes = (16 * total + 255) & ~255
+        path_bytes = sum(64 * c * d for c, d in zip(counts, depths))
+        answers = _sc.HostBuffer(el_bytes + path_bytes + 8 * total)
+        extra_trees = [cw.tree() for cw in extra]
+        rc = _sc.lib().sc_fri_prove_dev(codeword.vec.ptr, N, _sc.fe_bytes(self.offset.value), _sc.fe_bytes(self.omega.value), rounds, s,
+                                        b"".join(prior), (ctypes.c_uint32 * max(1, k))(*map(len, prior)), k,
+                                        ne, (ctypes.c_void_p * max(1, ne))(*[t._h for t in extra_trees]),
+                                        (ctypes.c_void_p * max(1, ne))(*[cw.vec.ptr for cw in extra]), int(also_open.shift) if ne else 0,
+                                        vecs, trees, roots, alphas, last_raw, top, quad, answers.ptr, answers.nbytes, None)
+        if rc == _sc.SC_ERR_UNSUPPORTED:
+            return None
+        _sc._check(rc)
+        # the commit phase's objects (fri.py:71, :91)
+        codewords, cur, raw = [], codeword, roots.raw
+        for r in range(rounds):
+            n = N >> r
+            if r > 0:
+                cur = DeviceCodeword(DeviceVector.adopt(vecs[r - 1], n), self.field)
+            root = raw[64 * r:64 * r + 64]
+            cur._tree = _sc.MerkleTree(ctypes.c_void_p(trees[r]), root, n)
+            proof_stream.push(root)
+            codewords.append(cur)
+        lazy = _po.lazy_objects(proof_stream)
+        lazy.add(_po.ElementList(codewords[-1], last_raw.raw))
+        # the query phase's objects (fri.py:104-113), round by round, from the packed answers
+        top_level_indices = list(top)
+        data = answers.array
+        positions = data[el_bytes + path_bytes:el_bytes + path_bytes + 8 * total].view(np.uint64)      # as the library derived them
+        values, paths, where, vo, po = [], [], [], 0, el_bytes
+        for c, d in zip(counts, depths):
+            values.append(data[16 * vo:16 * (vo + c)])
+            paths.append(data[po:po + 64 * c * d].reshape(c, 64 * d))
+            where.append(positions[vo:vo + c])
+            vo += c
+            po += 64 * c * d
+        for i in range(rounds - 1):
+            c_at = 2 * s if i + 2 < rounds else 0
+            lazy.add(_po.FriRound(codewords[i], codewords[i + 1], where[i][:s], where[i][s:2 * s], where[i + 1][c_at:c_at + s],
+                                  values[i][:16 * s], values[i][16 * s:32 * s], values[i + 1][16 * c_at:16 * (c_at + s)],
+                                  paths[i][:s], paths[i][s:2 * s], paths[i + 1][c_at:c_at + s]))
+        if also_open is not None:
+            also_open.answers = list(zip(values[rounds:], paths[rounds:]))
+            also_open.positions = list(quad)
         return top_level_indices
 
     def _query_all(self, codewords, top_level_indices, proof_stream, also_open=None):

@@ -172,7 +172,7 @@ class FriRound:
 
     def materialize(self):
         s = self.s
-        ent = [holder._entries(list(idx), _sc.unpack(bytes(val), s)) for holder, idx, val in zip((self.cur, self.cur, self.nxt), self.idx, self.val)]
+        ent = [holder._entries(np.asarray(idx).tolist(), _sc.unpack(bytes(val), s)) for holder, idx, val in zip((self.cur, self.cur, self.nxt), self.idx, self.val)]
         lists = [_sc._path_lists(memoryview(np.ascontiguousarray(p)).cast("B"), 0, p.shape[1] // 64, s) for p in self.paths]
         return list(zip(*ent)) + [path for trio in zip(*lists) for path in trio]
 

@@ -94,9 +94,15 @@ SIGNATURES = {
     "sc_merkle_root": (_int, [_vp, _vp]),
     "sc_fri_fold_commit_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
     "sc_fri_commit_dev": (_int, [_vp, _u64, _vp, _vp, ctypes.c_uint32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "sc_fri_prove_dev": (_int, [_vp, _u64, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _u64, _vp]),
+    "sc_host_alloc": (_int, [_u64, _vp]),
+    "sc_host_free": (_int, [_vp]),
     "sc_shake256": (_int, [_vp, _u64, _vp, _u64]),
     "sc_pickle_proof": (_int, [_vp, _u64, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _u64, ctypes.POINTER(_u64)]),
     "sc_field_sample": (_int, [_vp, _u64, _vp]),
+    "sc_blake2b": (_int, [_vp, _u64, _vp]),
+    "sc_fri_sample_indices": (_int, [_vp, _u64, _u64, _u64, ctypes.c_uint32, _vp]),
     "sc_transcript_bytes": (_int, [_vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_u64)]),
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),
     "sc_merkle_open_batch": (_int, [_vp, _vp, _u64, _vp]),
@@ -341,6 +347,36 @@ class DeviceVector:
             self.free()
         except Exception:
             pass
+
+
+class _HostMemory:
+    """one sc_host_alloc'ed block; goes back to the library's pool when the last reference dies"""
+
+    def __init__(self, nbytes):
+        p = _vp()
+        _check(lib().sc_host_alloc(max(int(nbytes), 1), ctypes.byref(p)))
+        self.ptr = p
+
+    def __del__(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p is not None and _lib is not None:
+            _lib.sc_host_free(p)
+
+
+class HostBuffer:
+    """Pinned, device-visible host memory from the library's pool (sc_host_alloc): what sc_fri_prove_dev's query kernel writes a
+    proof's openings to.  `array` is a uint8 numpy view; views of it keep the memory alive, and it goes back to the pool when the
+    last of them dies -- by reference counting (array -> ctypes block -> _HostMemory, no cycle): a block that waited for the cycle
+    collector would make the next proof allocate a fresh one (hipHostMalloc of megabytes: 0.1 ms)."""
+
+    def __init__(self, nbytes):
+        import numpy as np
+        self.nbytes = int(nbytes)
+        memory = _HostMemory(self.nbytes)
+        self.ptr = memory.ptr
+        raw = (ctypes.c_uint8 * max(self.nbytes, 1)).from_address(memory.ptr.value)
+        raw._memory = memory                                # numpy keeps `raw` as the array's base; `raw` keeps the block
+        self.array = np.frombuffer(raw, dtype=np.uint8, count=self.nbytes)
 
 
 def query_codewords(codewords, requests):

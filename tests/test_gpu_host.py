@@ -242,51 +242,108 @@ def test_fri_prove_synthetic_goldens():
             assert fr.prove(cw.tolist(), ps2) == top and ps2.serialize() == ser
 
 
-def test_fri_commit_in_library_and_in_python_agree(monkeypatch):
-    """Fri.commit has two forms of its round loop: sc_fri_commit_dev (trees, Fiat-Shamir step and folds in one library call, taken
-    when the proof stream holds only digests) and the per-round loop with the Fiat-Shamir step in Python.  Both must produce the
+def test_fri_prove_in_one_call_commit_in_library_and_in_python_agree(monkeypatch):
+    """Fri.prove has three forms: sc_fri_prove_dev (commit phase, index sampling and every opening in ONE library call, taken when
+    the proof stream holds only digests), Fri.commit through sc_fri_commit_dev (trees, Fiat-Shamir step and folds in one call) with
+    the query phase driven from Python, and the per-round loop with the Fiat-Shamir step in Python.  All must produce the
     reference's proof: the same golden hash, byte-identical streams also after digests pushed beforehand (FastStark pushes its
     commitments before FRI), and a stream that holds something else takes the Python loop and still verifies."""
     import starkcore as sc
-    calls = []
-    real = Fri._commit_in_library
+    calls, one_calls = [], []
+    real, real_one = Fri._commit_in_library, Fri._prove_in_library
     monkeypatch.setattr(Fri, "_commit_in_library", lambda self, *a: (calls.append(1), real(self, *a))[1])
+
+    def counted_one_call(self, *a):
+        out = real_one(self, *a)
+        if out is not None:
+            one_calls.append(1)
+        return out
+    monkeypatch.setattr(Fri, "_prove_in_library", counted_one_call)
     rec = [r for r in load_golden("fri.json")["prove_synth"] if r["logN"] == 12][0]
     N = 1 << rec["logN"]
     om = field.primitive_nth_root(N)
     poly = Polynomial([FieldElement(v, field) for v in synth.synth_ints(rec["coeff_seed"], N // 4)])
     fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
 
-    def prove(prior, force_python=False):
+    def prove(prior, form="one call"):
         cw = fast_coset_evaluate_device(poly, field.generator(), om, N)
         ps = ProofStream()
         for o in prior:
             ps.push(o)
-        if force_python:
-            with monkeypatch.context() as m:
+        with monkeypatch.context() as m:
+            if form != "one call":
+                m.setattr(Fri, "_prove_in_library", lambda self, *a: None)
+            if form == "python":
                 m.setattr(Fri, "_commit_in_library", lambda self, codeword, proof_stream, rounds: self._commit_rounds(codeword, proof_stream, rounds))
-                top = fr.prove(cw, ps)
-        else:
             top = fr.prove(cw, ps)
         return top, ps
     top, ps = prove([])
-    assert calls and top == rec["top_level_indices"] and hashlib.sha256(ps.serialize()).hexdigest() == rec["serialized_sha256"]
-    top2, ps2 = prove([], force_python=True)
+    assert one_calls and not calls and top == rec["top_level_indices"] and hashlib.sha256(ps.serialize()).hexdigest() == rec["serialized_sha256"]
+    top1, ps1 = prove([], form="commit in library")
+    assert calls and top1 == top and ps1.serialize() == ps.serialize()
+    top2, ps2 = prove([], form="python")
     assert top2 == top and ps2.serialize() == ps.serialize()
+    # what a verifier reads back from the one-call proof is the reference's object graph
+    back = ProofStream().deserialize(ps.serialize())
+    assert fr.verify(back, []) is True
+    assert [type(o) for o in ps.objects] == [type(o) for o in ps2.objects] and list(ps.objects) == list(ps2.objects)
     prior = [bytes([i]) * 64 for i in range(3)] + [b"short", b""]
-    n_calls = len(calls)
+    n_calls, n_one = len(calls), len(one_calls)
     top3, ps3 = prove(prior)
-    top4, ps4 = prove(prior, force_python=True)
-    assert len(calls) == n_calls + 1 and top3 == top4 and ps3.serialize() == ps4.serialize() and top3 != top
+    top3b, ps3b = prove(prior, form="commit in library")
+    top4, ps4 = prove(prior, form="python")
+    assert len(calls) == n_calls + 1 and len(one_calls) == n_one + 1 and top3 == top3b == top4 and ps3.serialize() == ps3b.serialize() == ps4.serialize() and top3 != top
     # the same object twice is a pickle memo hit, a list is not a digest: neither has the fixed layout -> the Python loop
     same = b"r" * 64
     for odd in ([same, same], [[1, 2, 3]], [b"x" * 300]):
-        n_calls = len(calls)
+        n_calls, n_one = len(calls), len(one_calls)
         top5, ps5 = prove(odd)
-        assert len(calls) == n_calls
+        assert len(calls) == n_calls and len(one_calls) == n_one
         for _ in odd:
             ps5.pull()
         assert fr.verify(ps5, []) is True
+
+
+def test_fri_commit_persistent_tail_kernel_equals_the_per_round_launches():
+    """csrc/fri_tail.cuh: from 2^16 elements down the commit phase is ONE persistent launch (fold, leaf hashes, tree and root of every
+    remaining round inside it, the host only answering each root with the next challenge).  Same roots, same folded codewords, same
+    trees (every authentication path the query phase opens) and the same proof bytes as the per-round launches (sc_set_tuning
+    fri_tail 0), at every size class: one workgroup only (<= 64 leaves), four lanes per leaf (<= 2^14), one lane per leaf (2^15,
+    2^16: 128 then 256 workgroups -- fewer workgroups in the round BEFORE the widest one), and a domain whose first rounds are the
+    classic ones (2^18).  The last codeword comes back through the kernel's pinned block; the oracle folds one round independently."""
+    import starkcore as sc
+    from oracle import py_oracle as po
+    for logN, s in [(5, 2), (7, 4), (9, 8), (12, 17), (15, 40), (16, 40), (17, 40), (18, 40)]:
+        N = 1 << logN
+        om = field.primitive_nth_root(N)
+        coeffs = synth.synth_packed(6100 + logN, N // 4).tobytes()
+        fr = Fri(field.generator(), om, N, 4, s)
+        proofs = []
+        for tail in (1, 0):
+            sc.set_tuning("fri_tail", tail)
+            try:
+                vec = sc.DeviceVector(N)
+                src = sc.DeviceVector.from_bytes(coeffs)
+                sc._check(sc.lib().sc_coset_evaluate_dev(src.ptr, N // 4, sc.fe_bytes(field.generator().value), sc.fe_bytes(om.value), N, vec.ptr, None))
+                ps = ProofStream()
+                top = fr.prove(sc.DeviceCodeword(vec, field), ps)
+                proofs.append((top, ps.serialize()))
+            finally:
+                sc.set_tuning("fri_tail", 1)
+        assert proofs[0][0] == proofs[1][0], logN
+        assert proofs[0][1] == proofs[1][1], logN
+        back = ProofStream().deserialize(proofs[0][1])
+        assert fr.verify(back, []) is True, logN
+        # the first fold against the oracle, through the first two roots of the proof
+        objects = ProofStream().deserialize(proofs[0][1]).objects
+        cw0 = po.C.coset_evaluate(coeffs, N // 4, po.GENERATOR, om.value, N)
+        assert objects[0] == po.C.merkle_commit(cw0, N)
+        if fr.num_rounds() > 1:
+            ps = ProofStream()
+            ps.push(objects[0])
+            alpha = field.sample(ps.prover_fiat_shamir())
+            cw1 = po.C.fold(cw0, N, alpha.value, po.GENERATOR, om.value)
+            assert objects[1] == po.C.merkle_commit(cw1, N // 2), logN
 
 
 def test_fri_commit_with_a_proof_stream_subclass_and_a_long_transcript(monkeypatch):
@@ -297,8 +354,15 @@ def test_fri_commit_with_a_proof_stream_subclass_and_a_long_transcript(monkeypat
     of raising."""
     from hashlib import shake_256
     calls = []
-    real = Fri._commit_in_library
+    real, real_one = Fri._commit_in_library, Fri._prove_in_library
     monkeypatch.setattr(Fri, "_commit_in_library", lambda self, *a: (calls.append(1), real(self, *a))[1])
+
+    def counted_one_call(self, *a):                                   # (the one-call form hashes the transcript in the library as well)
+        out = real_one(self, *a)
+        if out is not None:
+            calls.append(1)
+        return out
+    monkeypatch.setattr(Fri, "_prove_in_library", counted_one_call)
 
     class PrefixedProofStream(ProofStream):
         def __init__(self, document):
@@ -354,9 +418,9 @@ def test_a_kept_proof_stream_does_not_keep_the_codewords(monkeypatch):
     poly = Polynomial([FieldElement(v, field) for v in synth.synth_ints(rec["coeff_seed"], N // 4)])
     fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
     cw = fast_coset_evaluate_device(poly, field.generator(), om, N)
-    seen = []
-    real = Fri.commit
-    monkeypatch.setattr(Fri, "commit", lambda self, *a, **k: (lambda out: (seen.extend(weakref.ref(c) for c in out), out)[1])(real(self, *a, **k)))
+    seen = [weakref.ref(cw)]
+    real = sc.DeviceCodeword.__init__                      # every folded codeword the prover makes (whichever form of Fri.prove runs)
+    monkeypatch.setattr(sc.DeviceCodeword, "__init__", lambda self, *a, **k: (real(self, *a, **k), seen.append(weakref.ref(self)))[0])
     ps = ProofStream()
     top = fr.prove(cw, ps)
     assert top == rec["top_level_indices"] and len(seen) == fr.num_rounds()

@@ -291,3 +291,31 @@ def test_library_fiat_shamir_step_matches_pickle_and_hashlib():
             assert got[0] | (got[1] << 64) == field.sample(ps.prover_fiat_shamir()).value
             checked += 1
     assert checked >= 10
+
+
+def test_library_index_sampling_matches_hashlib_and_the_reference_loop():
+    """sc_fri_prove_dev samples the query indices inside the library (fri.py:36-51, :122): its host-side pieces -- BLAKE2b-512 of
+    any length against hashlib, Fri.sample_indices against this package's restatement of the reference loop (itself pinned to the
+    reference's golden top_level_indices in tests/golden/fri.json) -- need no GPU."""
+    import ctypes
+    import random
+    from hashlib import blake2b
+    import starkcore
+    lib = starkcore.lib()
+    rng = random.Random(12)
+    for length in (0, 1, 31, 32, 64, 127, 128, 129, 255, 256, 257, 1000):
+        data = rng.randbytes(length)
+        out = ctypes.create_string_buffer(64)
+        assert lib.sc_blake2b(data, length, out) == 0
+        assert out.raw == blake2b(data).digest(), length
+    fri = Fri(field.generator(), field.primitive_nth_root(1 << 12), 1 << 12, 4, 8)
+    for size, reduced, number in [(1 << 11, 1 << 4, 8), (1 << 21, 1 << 8, 40), (1 << 23, 1 << 8, 40), (1 << 5, 1 << 3, 8), (1 << 9, 64, 64), (1 << 62, 1 << 7, 17), (2, 2, 2), (4, 1, 1)]:
+        for trial in range(3):
+            seed = rng.randbytes(32)
+            got = (ctypes.c_uint64 * number)()
+            assert lib.sc_fri_sample_indices(seed, 32, size, reduced, number, got) == 0
+            assert list(got) == fri.sample_indices(seed, size, reduced, number), (size, reduced, number)
+    # the reference's assertion (more indices than the last codeword has entries), a size that is not a power of two
+    got = (ctypes.c_uint64 * 9)()
+    assert lib.sc_fri_sample_indices(b"s" * 32, 32, 1 << 10, 8, 9, got) == starkcore.SC_ERR_UNSUPPORTED
+    assert lib.sc_fri_sample_indices(b"s" * 32, 32, 1000, 8, 4, got) == starkcore.SC_ERR_UNSUPPORTED
