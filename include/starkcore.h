@@ -291,7 +291,9 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
  * `answers` (answers_bytes >= the sum below) = [opened elements, 16 bytes each, padded to a multiple of 256 bytes][paths, 64 * log2
  * N_pair bytes per opening][the positions, u64 each], pairs concatenated.  A buffer of sc_host_alloc is written by the kernel itself
  * across the bus (no staging copy); any other host pointer works through two copies.  Outputs of the commit phase as for
- * sc_fri_commit_dev; last_codeword_out: 16 * (N >> (rounds - 1)) bytes; top_indices_out: num_tests.
+ * sc_fri_commit_dev -- or vecs_out = trees_out = NULL (alphas_out may be NULL as well): nothing reads the folded codewords and
+ * their trees once the openings are on the host, and the library then hands their memory back before it returns;
+ * last_codeword_out: 16 * (N >> (rounds - 1)) bytes; top_indices_out: num_tests.
  * SC_ERR_UNSUPPORTED: a transcript or shape this entry does not serve (the caller runs the phases one by one). */
 int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds, uint32_t num_tests,
                      const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,

@@ -699,6 +699,19 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     std::unique_lock<std::mutex> lk(g_mu);
     if (!last_codeword_out || !top_indices_out || !answers || (extra_count && (!extra_trees || !extra_vecs || !extra_indices_out)) || !num_tests)
         return fail(SC_ERR_BAD_ARG, "null argument");
+    // vecs_out == trees_out == NULL: nobody wants the folded codewords and their trees once the openings are on the host -- the
+    // library keeps them to itself and hands the memory back before it returns (no handle crosses the boundary)
+    std::vector<sc_vec_t*> own_vecs;
+    std::vector<sc_merkle_t*> own_trees;
+    std::vector<uint64_t> own_alphas;
+    const bool keep_state = vecs_out != nullptr || trees_out != nullptr;
+    if (!keep_state) {
+        own_vecs.assign(rounds > 1 ? rounds - 1 : 1, nullptr);
+        own_trees.assign(rounds, nullptr);
+        vecs_out = own_vecs.data();
+        trees_out = own_trees.data();
+    }
+    if (!alphas_out) { own_alphas.assign(2 * (rounds > 1 ? rounds - 1 : 1), 0); alphas_out = own_alphas.data(); }
     if (rounds < 1 || rounds > 60 || N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
     const uint64_t n_last = N >> (rounds - 1);
     const uint32_t s = num_tests;
@@ -728,10 +741,13 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     if (rc != SC_OK) return rc;
     stamp(1);
     hipStream_t st = pick_stream(stream);
-    auto undo = [&](int code) {
-        (void)hipStreamSynchronize(st);
+    auto free_state = [&] {
         for (uint32_t i = 0; i < rounds; ++i) { sc_merkle* t = trees_out[i]; if (!t) continue; pool_free(t->d_levels, (2 * t->N - 1) * 64); delete t; trees_out[i] = nullptr; }
         for (uint32_t i = 0; i + 1 < rounds; ++i) { if (!vecs_out[i]) continue; pool_free(vecs_out[i]->d, (vecs_out[i]->n ? vecs_out[i]->n : 1) * sizeof(Fe)); delete vecs_out[i]; vecs_out[i] = nullptr; }
+    };
+    auto undo = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        free_state();
         return code;
     };
     // the last codeword in the clear (fri.py:91): its tree is built, so the fold that made it has run
@@ -861,6 +877,7 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
             hipStreamSynchronize(st) != hipSuccess)
             return undo(fail(SC_ERR_HIP, "copy of the openings failed"));
     }
+    if (!keep_state) free_state();                            // (every kernel that read them has completed: the openings were waited for)
     if (timing) {
         stamp(6);
         auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };

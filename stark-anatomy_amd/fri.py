@@ -234,10 +234,7 @@ class Fri:
         self._check_omega_order(N)
         prior = list(proof_stream.objects)
         k, ne = len(prior), len(extra)
-        vecs = (ctypes.c_void_p * max(1, rounds - 1))()
-        trees = (ctypes.c_void_p * rounds)()
         roots = ctypes.create_string_buffer(64 * rounds)
-        alphas = (ctypes.c_uint64 * max(2, 2 * (rounds - 1)))()
         n_last = N >> (rounds - 1)
         last_raw = ctypes.create_string_buffer(16 * n_last)
         top = (ctypes.c_uint64 * s)()
@@ -250,46 +247,39 @@ class Fri:
         path_bytes = sum(64 * c * d for c, d in zip(counts, depths))
         answers = _sc.HostBuffer(el_bytes + path_bytes + 8 * total)
         extra_trees = [cw.tree() for cw in extra]
+        # no handle of the commit phase comes back (vecs_out = trees_out = NULL): nothing reads the folded codewords or their trees
+        # once the openings are on the host, and the library hands their memory back before it returns
         rc = _sc.lib().sc_fri_prove_dev(codeword.vec.ptr, N, _sc.fe_bytes(self.offset.value), _sc.fe_bytes(self.omega.value), rounds, s,
                                         b"".join(prior), (ctypes.c_uint32 * max(1, k))(*map(len, prior)), k,
                                         ne, (ctypes.c_void_p * max(1, ne))(*[t._h for t in extra_trees]),
                                         (ctypes.c_void_p * max(1, ne))(*[cw.vec.ptr for cw in extra]), int(also_open.shift) if ne else 0,
-                                        vecs, trees, roots, alphas, last_raw, top, quad, answers.ptr, answers.nbytes, None)
+                                        None, None, roots, None, last_raw, top, quad, answers.ptr, answers.nbytes, None)
         if rc == _sc.SC_ERR_UNSUPPORTED:
             return None
         _sc._check(rc)
-        # the commit phase's objects (fri.py:71, :91)
-        codewords, cur, raw = [], codeword, roots.raw
+        # the commit phase's objects (fri.py:71, :91): the roots, then the last codeword in the clear
+        raw = roots.raw
         for r in range(rounds):
-            n = N >> r
-            if r > 0:
-                cur = DeviceCodeword(DeviceVector.adopt(vecs[r - 1], n), self.field)
-            root = raw[64 * r:64 * r + 64]
-            cur._tree = _sc.MerkleTree(ctypes.c_void_p(trees[r]), root, n)
-            proof_stream.push(root)
-            codewords.append(cur)
+            proof_stream.push(raw[64 * r:64 * r + 64])
+        holders = [_po.entries_of(codeword)] + [_po.DetachedEntries(self.field) for _ in range(rounds - 1)]
         lazy = _po.lazy_objects(proof_stream)
-        lazy.add(_po.ElementList(codewords[-1], last_raw.raw))
-        # the query phase's objects (fri.py:104-113), round by round, from the packed answers
-        top_level_indices = list(top)
+        lazy.add(_po.ElementList(holders[-1], last_raw.raw))
+        # the query phase's objects (fri.py:104-113): described by the answers as they lie in the pinned buffer
         data = answers.array
-        positions = data[el_bytes + path_bytes:el_bytes + path_bytes + 8 * total].view(np.uint64)      # as the library derived them
-        values, paths, where, vo, po = [], [], [], 0, el_bytes
-        for c, d in zip(counts, depths):
-            values.append(data[16 * vo:16 * (vo + c)])
-            paths.append(data[po:po + 64 * c * d].reshape(c, 64 * d))
-            where.append(positions[vo:vo + c])
-            vo += c
-            po += 64 * c * d
-        for i in range(rounds - 1):
-            c_at = 2 * s if i + 2 < rounds else 0
-            lazy.add(_po.FriRound(codewords[i], codewords[i + 1], where[i][:s], where[i][s:2 * s], where[i + 1][c_at:c_at + s],
-                                  values[i][:16 * s], values[i][16 * s:32 * s], values[i + 1][16 * c_at:16 * (c_at + s)],
-                                  paths[i][:s], paths[i][s:2 * s], paths[i + 1][c_at:c_at + s]))
+        own = sum(counts[:rounds])                               # openings of the commit phase's codewords; the caller's come behind them
+        own_paths = sum(64 * c * d for c, d in zip(counts[:rounds], depths[:rounds]))
+        if rounds > 1:
+            positions = data[el_bytes + path_bytes:el_bytes + path_bytes + 8 * own].view(np.uint64)
+            lazy.add(_po.FriQueryPhase(holders, s, counts[:rounds], depths[:rounds], data[:16 * own], data[el_bytes:el_bytes + own_paths], positions))
         if also_open is not None:
-            also_open.answers = list(zip(values[rounds:], paths[rounds:]))
+            vo, po, fetched = own, el_bytes + own_paths, []
+            for c, d in zip(counts[rounds:], depths[rounds:]):
+                fetched.append((data[16 * vo:16 * (vo + c)], data[po:po + 64 * c * d].reshape(c, 64 * d)))
+                vo += c
+                po += 64 * c * d
+            also_open.answers = fetched
             also_open.positions = list(quad)
-        return top_level_indices
+        return list(top)
 
     def _query_all(self, codewords, top_level_indices, proof_stream, also_open=None):
         """The query phase of fri.py:124-128 with ONE device round trip for all rounds: everything a codeword has to open

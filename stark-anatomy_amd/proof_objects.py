@@ -91,6 +91,19 @@ class _Entries:
         return [own[i] for i in indices]
 
 
+class DetachedEntries(_Entries):
+    """the holder of a codeword that never had a Python object: the folded codewords of a Fri.prove that ran as one library call
+    (sc_fri_prove_dev) are freed before the call returns; what the stream describes of them are residues the device handed over"""
+
+    def __init__(self, field):
+        _codeword_uid.counter += 1
+        self.field, self._uid, self._own = field, _codeword_uid.counter, {}
+
+    @staticmethod
+    def _alive():
+        return None
+
+
 def entries_of(codeword):
     """the holder a segment keeps instead of the codeword itself (holders that are not device codewords -- the sharded prover's
     layer caches -- are kept as they are: they hold no device memory)"""
@@ -175,6 +188,45 @@ class FriRound:
         ent = [holder._entries(np.asarray(idx).tolist(), _sc.unpack(bytes(val), s)) for holder, idx, val in zip((self.cur, self.cur, self.nxt), self.idx, self.val)]
         lists = [_sc._path_lists(memoryview(np.ascontiguousarray(p)).cast("B"), 0, p.shape[1] // 64, s) for p in self.paths]
         return list(zip(*ent)) + [path for trio in zip(*lists) for path in trio]
+
+
+class FriQueryPhase:
+    """every round of the query phase at once (fri.py:124-128), as sc_fri_prove_dev answered it: views of one pinned buffer, cut
+    into rounds only when somebody serializes or reads the stream.
+    holders[j]: codeword j's entry holder; counts / depths: openings and path depth per codeword, in the buffer's order ([a, b] of
+    its own round, then [c] of the round before); elems / paths: uint8 views of the opened residues (16 bytes each) and of the
+    authentication paths of those codewords, codeword after codeword; positions: the opened indices (uint64 view), likewise."""
+
+    def __init__(self, holders, s, counts, depths, elems, paths, positions):
+        self.holders, self.s, self.counts, self.depths = holders, s, counts, depths
+        self.elems, self.paths, self.positions = elems, paths, positions
+        self.count = 4 * s * (len(holders) - 1)
+        self._rounds = None
+
+    def rounds(self):
+        if self._rounds is None:
+            s = self.s
+            values, paths, where, vo, po = [], [], [], 0, 0
+            for c, d in zip(self.counts, self.depths):
+                values.append(self.elems[16 * vo:16 * (vo + c)])
+                paths.append(self.paths[po:po + 64 * c * d].reshape(c, 64 * d))
+                where.append(self.positions[vo:vo + c])
+                vo += c
+                po += 64 * c * d
+            k = len(self.holders)
+            self._rounds = []
+            for i in range(k - 1):
+                c_at = 2 * s if i + 2 < k else 0
+                self._rounds.append(FriRound(self.holders[i], self.holders[i + 1], where[i][:s], where[i][s:2 * s], where[i + 1][c_at:c_at + s],
+                                             values[i][:16 * s], values[i][16 * s:32 * s], values[i + 1][16 * c_at:16 * (c_at + s)],
+                                             paths[i][:s], paths[i][s:2 * s], paths[i + 1][c_at:c_at + s]))
+        return self._rounds
+
+    def ops(self, ctx):
+        return b"".join(r.ops(ctx) for r in self.rounds())
+
+    def materialize(self):
+        return [obj for r in self.rounds() for obj in r.materialize()]
 
 
 class Openings:

@@ -188,3 +188,69 @@ def test_bytes_objects_of_a_frame_or_more_go_out_unframed(size, around):
     # two blobs in a row, and one as the only item of a nested list
     objects = [rng.randbytes(size), rng.randbytes(size), [rng.randbytes(size)], rng.randbytes(7)]
     assert library_pickle(objects, [MAIN], random.Random(1)) == pickle.dumps(objects)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_query_phase_segment_from_the_one_call_provers_buffer(seed):
+    """proof_objects.FriQueryPhase + DetachedEntries: the whole query phase described from ONE buffer in sc_fri_prove_dev's layout
+    (opened elements padded to 256 bytes, paths, positions; per codeword [a, b] of its own round then [c] of the round before) must
+    pickle like the per-round segments and like the objects -- including the sharing between a round's c entries and the next
+    round's a / b entries and the last codeword (pickle memoises by identity, fri.py:91, :104-105)."""
+    rng = random.Random(100 + seed)
+    field = MAIN
+    s, rounds = rng.choice([2, 5, 40]), rng.choice([2, 3, 7])            # `rounds` codewords, rounds - 1 folds
+    sizes = [(128 if s > 20 else 16) << (rounds - 1 - r) for r in range(rounds)]
+    cws = [FakeCodeword(n, field, rng) for n in sizes]
+    top = rng.sample(range(sizes[0] // 2), s)
+    counts = [(2 * s if j + 1 < rounds else 0) + (s if j > 0 else 0) for j in range(rounds)]
+    depths = [n.bit_length() - 1 for n in sizes]
+    positions, idx, prev = [], list(top), None
+    for j in range(rounds):
+        half = sizes[j] // 2
+        here = []
+        if j + 1 < rounds:
+            idx = [i % half for i in idx]
+            here += idx + [i + half for i in idx]
+        if j > 0:
+            here += prev
+        prev = idx
+        positions.append(here)
+    total = sum(counts)
+    el_bytes = (16 * total + 255) & ~255
+    elems = b"".join(cw.raw(p) for cw, p in zip(cws, positions))
+    path_arrays = [rng.randbytes(64 * d * c) for c, d in zip(counts, depths)]
+    extra_bytes = 64 * rng.choice([0, 3, 40])               # the paths of a caller's further codewords lie between the two (fast_stark.py:154-175)
+    buf = np.frombuffer(elems + bytes(el_bytes - len(elems)) + b"".join(path_arrays) + rng.randbytes(extra_bytes)
+                        + np.asarray([i for p in positions for i in p], dtype=np.uint64).tobytes(), dtype=np.uint8)
+
+    def stream(kind):
+        ps = ProofStream()
+        for _ in range(rounds):
+            ps.push(rng.randbytes(64))
+        lazy = po_.lazy_objects(ps)
+        if kind == "one buffer":
+            holders = [cws[0]] + [po_.DetachedEntries(field) for _ in range(rounds - 1)]
+        else:
+            holders = cws
+        lazy.add(po_.ElementList(holders[-1], cws[-1].raw(range(sizes[-1]))))
+        if kind == "one buffer":
+            own_paths = sum(64 * c * d for c, d in zip(counts, depths))
+            lazy.add(po_.FriQueryPhase(holders, s, counts, depths, buf[:16 * total], buf[el_bytes:el_bytes + own_paths],
+                                       buf[el_bytes + own_paths + extra_bytes:el_bytes + own_paths + extra_bytes + 8 * total].view(np.uint64)))
+        else:
+            paths = [np.frombuffer(raw, dtype=np.uint8).reshape(c, 64 * d) for raw, c, d in zip(path_arrays, counts, depths)]
+            for i in range(rounds - 1):
+                a, half = positions[i][:s], sizes[i] // 2
+                c_at = 2 * s if i + 2 < rounds else 0
+                lazy.add(po_.FriRound(cws[i], cws[i + 1], a, [x + half for x in a], a, cws[i].raw(a), cws[i].raw([x + half for x in a]), cws[i + 1].raw(a),
+                                      paths[i][:s], paths[i][s:2 * s], paths[i + 1][c_at:c_at + s]))
+        return ps
+    rng_state = rng.getstate()
+    one = stream("one buffer")
+    rng.setstate(rng_state)
+    per_round = stream("per round")
+    got = one.serialize()
+    assert got == per_round.serialize()
+    assert got == pickle.dumps(list(per_round.objects))
+    assert pickle.dumps(list(one.objects)) == got           # materialised from detached holders: the same sharing
+    assert len(one.objects) == rounds + 1 + 4 * s * (rounds - 1)
