@@ -19,6 +19,7 @@
 #include <thread>
 #include <sys/random.h>
 #include <deque>
+#include <functional>
 #include <future>
 #include <map>
 #include <mutex>

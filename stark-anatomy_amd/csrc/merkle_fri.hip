@@ -452,7 +452,7 @@ constexpr int TAIL_NOT_TAKEN = 1;
 // TAIL_NOT_TAKEN: the shape is not the kernel's, or a wait inside it timed out -- nothing the caller holds has changed.
 static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint64_t n, Fe alpha0, Fe off, Fe om, uint32_t first, uint32_t rounds,
                            std::vector<uint8_t>& items, uint64_t prior_count, sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out,
-                           uint64_t* alphas_out, hipStream_t st, Fe* last_host, bool* last_there) {
+                           uint64_t* alphas_out, hipStream_t st, Fe* last_host, bool* last_there, const std::function<void()>* on_last) {
     if (g.fri_tail < 0) { const char* e = getenv("STARKCORE_FRI_TAIL"); g.fri_tail = (e && atoi(e) == 0) ? 0 : 1; }      // (sc_set_tuning("fri_tail") overrides)
     const uint32_t R = rounds - first;
     const uint64_t n0 = n / 2;
@@ -503,11 +503,28 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
     for (uint32_t k = 0; k < R; ++k) nwg = std::max(nwg, tail_workgroups(P.log_n0 - k));
     hipLaunchKernelGGL(fri_tail_kernel, dim3(nwg), dim3(256), 0, st, P);
     if (hipGetLastError() != hipSuccess) { give_back(true); return TAIL_NOT_TAKEN; }
-    std::vector<uint8_t> bytes;
     bool aborted = false;
     for (uint32_t k = 0; k < R && !aborted; ++k) {
         volatile uint64_t* slot = host->root[k];
         bool landed = false;
+        PendingChallenge pending;                              // what the next challenge's hash can absorb before the root is there
+        if (k + 1 < R && !pending.prepare(items, (size_t)(prior_count + first + k + 1))) { aborted = true; break; }
+        if (k + 1 == R && last_host && last_there && (n0 >> (R - 1)) <= TAIL_LAST_MAX) {
+            // the last codeword leaves the kernel BEFORE its tree is hashed: whatever the caller does with it (sc_fri_prove_dev
+            // pickles it into the transcript) happens while the device builds that tree
+            lk.unlock();
+            bool there = false;
+            for (long spin = 0; spin < SPIN_POLLS && !there; ++spin) {
+                there = __atomic_load_n(&host->last_flag[0], __ATOMIC_ACQUIRE) == P.seq;
+                if (!there && (spin & 1023) == 1023 && __atomic_load_n(&host->abort_flag[0], __ATOMIC_ACQUIRE) == P.seq) break;
+            }
+            lk.lock();
+            if (there) {
+                memcpy(last_host, (const void*)host->last, (n0 >> (R - 1)) * sizeof(Fe));
+                *last_there = true;
+                if (on_last) (*on_last)();
+            }
+        }
         lk.unlock();
         for (long spin = 0; spin < SPIN_POLLS; ++spin) {
             if (__atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) == P.seq) { landed = true; break; }
@@ -524,10 +541,9 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
         host_stamp();
         memcpy(roots_out + 64 * r, (const void*)slot, 64);
         if (k + 1 == R) break;
-        transcript_item(items, roots_out + 64 * r, 64);
-        if (!transcript_bytes(items, (size_t)(prior_count + r + 1), bytes)) { aborted = true; break; }
         uint8_t digest[32];
-        shake256(bytes.data(), bytes.size(), digest, 32);
+        pending.finish(roots_out + 64 * r, digest, 32);
+        transcript_item(items, roots_out + 64 * r, 64);
         const Fe alpha = sample_field(digest, 32);
         alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
         host->alpha[k + 1][0] = alpha.lo;
@@ -552,12 +568,6 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
                     k + 1 < R ? d(4, 5) : 0.0, host_us.size() > 2 * k ? host_us[2 * k] : 0.0, host_us.size() > 2 * k + 1 ? host_us[2 * k + 1] : 0.0, (double)(sp[0] - host->stamps[0][0]) / 100.0);
         }
     }
-    const uint64_t n_last = n0 >> (R - 1);
-    if (last_host && last_there && n_last <= TAIL_LAST_MAX) {
-        bool there = false;
-        for (long spin = 0; spin < SPIN_POLLS && !there; ++spin) there = __atomic_load_n(&host->last_flag[0], __ATOMIC_ACQUIRE) == P.seq;
-        if (there) { memcpy(last_host, (const void*)host->last, n_last * sizeof(Fe)); *last_there = true; }
-    }
     for (uint32_t k = 0; k < R; ++k) {
         const uint64_t nk = n0 >> k;
         if (k > 0) vecs_out[first + k - 1] = new sc_vec{new_vecs[k - 1], nk};
@@ -575,12 +585,12 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
 static int fri_commit_locked(std::unique_lock<std::mutex>& lk, const void* d_codeword, uint64_t N, const uint64_t offset[2], const uint64_t omega[2], uint32_t rounds,
                              const void* prior_data, const uint32_t* prior_lens, uint64_t prior_count,
                              sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out, uint64_t* alphas_out, void* stream,
-                             Fe* last_host = nullptr, bool* last_there = nullptr) {
+                             Fe* last_host = nullptr, bool* last_there = nullptr, const std::function<void()>* on_last = nullptr) {
     SCCHK(ensure_init());
     if (!d_codeword || !trees_out || !roots_out || (rounds > 1 && (!vecs_out || !alphas_out)) || rounds < 1) return fail(SC_ERR_BAD_ARG, "null argument");
     if (N < 2 || !is_pow2(N) || rounds > 60 || (N >> (rounds - 1)) < 1) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
     if (prior_count + rounds > TRANSCRIPT_MAX_ITEMS) return fail(SC_ERR_UNSUPPORTED, "transcript too long for the fixed layout");
-    std::vector<uint8_t> items, bytes;
+    std::vector<uint8_t> items;
     {
         const uint8_t* p = (const uint8_t*)prior_data;
         for (uint64_t i = 0; i < prior_count; ++i) {
@@ -614,20 +624,22 @@ static int fri_commit_locked(std::unique_lock<std::mutex>& lk, const void* d_cod
             vecs_out[r] = nxt;
             ++made_vecs;
         }
+        // ... and the part of the challenge's hash that does not need it either (csrc/transcript.h: PendingChallenge)
+        PendingChallenge pending;
+        if (r + 1 < rounds && !pending.prepare(items, (size_t)(prior_count + r + 1))) return undo(fail(SC_ERR_UNSUPPORTED, "transcript too large for the fixed layout"));
         root_poll_unlocked(lk, trees_out[r]);
         rc = merkle_root_wait(trees_out[r]);
         if (rc != SC_OK) return undo(rc);
         memcpy(roots_out + 64 * r, trees_out[r]->root, 64);
         if (r + 1 == rounds) break;
-        transcript_item(items, trees_out[r]->root, 64);
-        if (!transcript_bytes(items, (size_t)(prior_count + r + 1), bytes)) return undo(fail(SC_ERR_UNSUPPORTED, "transcript too large for the fixed layout"));
         uint8_t digest[32];
-        shake256(bytes.data(), bytes.size(), digest, 32);
+        pending.finish(trees_out[r]->root, digest, 32);
+        transcript_item(items, trees_out[r]->root, 64);
         const Fe alpha = sample_field(digest, 32);
         alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
         if (n / 2 <= (1ull << TAIL_MAX_LOG)) {
             // from here on every round is latency: the rest of the commit phase is one persistent launch (csrc/fri_tail.cuh)
-            rc = fri_tail_rounds(lk, cur, n, alpha, off, om, r + 1, rounds, items, prior_count, vecs_out, trees_out, roots_out, alphas_out, st, last_host, last_there);
+            rc = fri_tail_rounds(lk, cur, n, alpha, off, om, r + 1, rounds, items, prior_count, vecs_out, trees_out, roots_out, alphas_out, st, last_host, last_there, on_last);
             if (rc == SC_OK) return SC_OK;
             if (rc != TAIL_NOT_TAKEN) return undo(rc);
         }
@@ -735,9 +747,39 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     std::chrono::steady_clock::time_point tp[8];
     auto stamp = [&](int i) { if (timing) tp[i] = std::chrono::steady_clock::now(); };
     stamp(0);
+    // the transcript the indices are sampled from: [prior..., roots..., [FieldElement(v) for v in last codeword]] (fri.py:91, :122).
+    // Its pickle depends on the LENGTHS of the byte strings only, so it is written as soon as the last codeword is known -- the
+    // persistent tail kernel hands it over before it hashes the last tree -- with the roots that are still missing left blank.
+    ProofPickler pk;
+    std::vector<size_t> bytes_at;
+    uint8_t modulus[17] = {0};
+    { const uint64_t plo = P_LO, phi = P_HI; memcpy(modulus, &plo, 8); memcpy(modulus + 8, &phi, 8); }
+    pk.moduli = modulus; pk.nfields = 1; pk.modulus_bytes = 17;
+    pk.bytes_at = &bytes_at;
+    bool pickled = false, pickle_ok = false;
+    auto pickle_transcript = [&] {
+        std::vector<uint8_t> ops;
+        auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) ops.push_back((uint8_t)(v >> (8 * i))); };
+        ops.reserve(16 + 72 * (prior_count + rounds) + 29 * n_last);
+        ops.push_back('L'); put32((uint32_t)(prior_count + rounds + 1));
+        const uint8_t* p = (const uint8_t*)prior_data;
+        for (uint64_t i = 0; i < prior_count; ++i) { ops.push_back('B'); put32(prior_lens[i]); ops.insert(ops.end(), p, p + prior_lens[i]); p += prior_lens[i]; }
+        for (uint32_t r = 0; r < rounds; ++r) { ops.push_back('B'); put32(64); ops.insert(ops.end(), roots_out + 64 * r, roots_out + 64 * r + 64); }
+        ops.push_back('L'); put32((uint32_t)n_last);
+        for (uint64_t i = 0; i < n_last; ++i) {
+            ops.push_back('E'); put32(0);
+            for (int b = 0; b < 8; ++b) ops.push_back((uint8_t)(i >> (8 * b)));
+            const uint8_t* v = (const uint8_t*)last_codeword_out + 16 * i;
+            ops.insert(ops.end(), v, v + 16);
+        }
+        bytes_at.clear();
+        pickle_ok = pk.run(ops.data(), ops.size()) && bytes_at.size() == prior_count + rounds;
+        pickled = true;
+    };
+    const std::function<void()> on_last = pickle_transcript;
     bool last_there = false;       // the persistent tail kernel hands the last codeword over with its roots
     int rc = fri_commit_locked(lk, d_codeword, N, offset, omega, rounds, prior_data, prior_lens, prior_count, vecs_out, trees_out, roots_out, alphas_out, stream,
-                               (Fe*)last_codeword_out, &last_there);
+                               (Fe*)last_codeword_out, &last_there, &on_last);
     if (rc != SC_OK) return rc;
     stamp(1);
     hipStream_t st = pick_stream(stream);
@@ -755,28 +797,13 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     if (!last_there && (hipMemcpyAsync(last_codeword_out, d_last, n_last * sizeof(Fe), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
         return undo(fail(SC_ERR_HIP, "copy of the last codeword failed"));
     stamp(2);
-    // transcript: [prior..., roots..., [FieldElement(v) for v in last codeword]]
-    std::vector<uint8_t> ops;
-    auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) ops.push_back((uint8_t)(v >> (8 * i))); };
-    ops.reserve(16 + 72 * (prior_count + rounds) + 29 * n_last);
-    ops.push_back('L'); put32((uint32_t)(prior_count + rounds + 1));
-    {
-        const uint8_t* p = (const uint8_t*)prior_data;
-        for (uint64_t i = 0; i < prior_count; ++i) { ops.push_back('B'); put32(prior_lens[i]); ops.insert(ops.end(), p, p + prior_lens[i]); p += prior_lens[i]; }
+    if (pickled && pickle_ok) {
+        // written while the last tree was being hashed: only the roots that were not there yet go in now
+        for (uint32_t r = 0; r < rounds; ++r) memcpy(pk.base + bytes_at[prior_count + r], roots_out + 64 * r, 64);
+    } else {
+        pickle_transcript();
+        if (!pickle_ok) return undo(fail(SC_ERR_UNSUPPORTED, "transcript not described"));
     }
-    for (uint32_t r = 0; r < rounds; ++r) { ops.push_back('B'); put32(64); ops.insert(ops.end(), roots_out + 64 * r, roots_out + 64 * r + 64); }
-    ops.push_back('L'); put32((uint32_t)n_last);
-    for (uint64_t i = 0; i < n_last; ++i) {
-        ops.push_back('E'); put32(0);
-        for (int b = 0; b < 8; ++b) ops.push_back((uint8_t)(i >> (8 * b)));
-        const uint8_t* v = (const uint8_t*)last_codeword_out + 16 * i;
-        ops.insert(ops.end(), v, v + 16);
-    }
-    uint8_t modulus[17] = {0};
-    { const uint64_t plo = P_LO, phi = P_HI; memcpy(modulus, &plo, 8); memcpy(modulus + 8, &phi, 8); }
-    ProofPickler pk;
-    pk.moduli = modulus; pk.nfields = 1; pk.modulus_bytes = 17;
-    if (!pk.run(ops.data(), ops.size())) return undo(fail(SC_ERR_UNSUPPORTED, "transcript not described"));
     uint8_t seed[32];
     shake256(pk.base, pk.used, seed, 32);
     stamp(3);

@@ -52,6 +52,7 @@ struct ProofPickler {
     const uint8_t* moduli = nullptr;                       // table of field moduli, `modulus_bytes` each, little-endian
     uint32_t nfields = 0, modulus_bytes = 0;
     bool bad = false;
+    std::vector<size_t>* bytes_at = nullptr;               // optional: where each bytes object's data starts in the output (a caller that patches one in later)
 
     static constexpr size_t FRAME_HEADER = 9, FRAME_TARGET = 64 * 1024, FRAME_MIN = 4;
 
@@ -150,6 +151,7 @@ struct ProofPickler {
             // opens the next frame
             commit_frame();
             put(0x42); put_u32((uint32_t)len);                                 // BINBYTES (the description's length is a u32)
+            if (bytes_at) bytes_at->push_back(used);
             put(data, len);
             start_frame();
             memoize();
@@ -157,6 +159,7 @@ struct ProofPickler {
         }
         if (len < 256) { put(0x43); put((uint8_t)len); }                       // SHORT_BINBYTES
         else { put(0x42); put_u32((uint32_t)len); }                            // BINBYTES
+        if (bytes_at) bytes_at->push_back(used);
         put(data, len);
         memoize();
     }
