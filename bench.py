@@ -493,10 +493,20 @@ def main():
                                  "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor (13 of 17.5 us at 2^20), see DESIGN.md 3.1"},
         }
         if sharded:
+            # the N > 1 line prices a rank's WHOLE transform (column stage, corner turn, row stage), not one launch of one kernel: no
+            # per-launch PMC figures belong here (they are the single-GPU kernel's, in the N = 1 line and profiles/); what bounds this
+            # number is in stages_us -- the two compute stages run the same ntt_pass_kernel at its VALU issue rate, the rest is the
+            # exchange and waiting for the slowest peer
+            del out["roofline"]["traffic"], out["roofline"]["valu_insts_per_launch"]
+            out["roofline"]["traffic"] = None
+            out["roofline"]["note"] = ("per rank and transform: 32 B/element algorithmic over the whole sharded transform (cols + corner turn + rows); the stages' own times are "
+                                       "in stages_us (compute stages = ntt_pass_kernel launches, priced per launch in the N = 1 line; the exchange moves "
+                                       "all_to_all_bytes_sent_per_rank_per_step / 2 bytes per transform over xGMI)")
             out["config"]["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
             out["config"]["world_size"] = world
             out["config"]["corner_turn"] = corner_turn
             out["config"]["corner_turn_probes"] = corner_probes
+            out["config"]["corner_turn_setup"] = list(getattr(eng, "corner_turn_setup", []))
             out["config"]["split"] = "n1 = 2^%d x n2 = 2^%d" % (eng.n1.bit_length() - 1, eng.n2.bit_length() - 1)
             out["config"]["node"] = node_facts(dev)
             out["roofline"]["stages_us"] = stages
@@ -612,7 +622,7 @@ def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4, o
             if kw.get("native_exchange"):
                 eng.stages.native = True
             if kw.get("direct_store") and not eng.direct_store:
-                raise RuntimeError("the peers' regions could not be mapped")
+                raise RuntimeError("the peers' regions could not be mapped (%s)" % "; ".join(eng.corner_turn_setup))
             x = eng.synthetic_input(seed=1)
             y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
             z = torch.empty_like(x)
@@ -668,6 +678,8 @@ def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4, o
             continue
         candidates.append((sec, label, step, eng, (x, y, z), kw))
         probes.append({"form": label, "available": True, "correct": True, "ms_per_pair": sec * 1e3})
+        if kw.get("direct_store"):
+            probes[-1]["setup"] = list(eng.corner_turn_setup)       # which kind of region came up (fine-grained first, then coarse-grained)
         if kw.get("direct_store"):
             probes[-1]["receive_region_memory"] = eng.stages.region_kind()
     if not candidates:

@@ -41,6 +41,7 @@ extern "C" {
 #define SC_ERR_BAD_ARG (-6)
 #define SC_ERR_UNSUPPORTED (-7)
 #define SC_ERR_NOT_INIT (-8)
+#define SC_ERR_TIMEOUT (-9)          /* a peer never arrived at a flag barrier of the direct-store corner turn: sticky until the plan's peers are set again */
 
 typedef struct sc_vec sc_vec_t;        /* device-resident vector of field elements */
 typedef struct sc_merkle sc_merkle_t;  /* device-resident BLAKE2b Merkle tree (all levels kept) */
@@ -150,11 +151,16 @@ int sc_fourstep_run_dev(const sc_fourstep_t* plan, int inverse, const void* d_sr
  * rank's flag at every peer and waits for theirs (system-scope atomics), and the row stage reads the rank's own receive buffer.
  * Consecutive transforms alternate between the two receive buffers, so a peer's next column stage never overwrites what a row
  * stage is still reading.  Every rank must run the same transforms in the same order.  A barrier that waits ~2 s for a peer
- * gives up (sc_fourstep_direct_status reports the epoch); the transform's output is then undefined.
+ * gives up and writes the transform's number to a pinned word of the plan: that transform's output is undefined, and from then on
+ * the failure is STICKY -- sc_fourstep_direct_status reports the number (no copy, no wait) and every later
+ * sc_fourstep_run_direct_dev returns SC_ERR_TIMEOUT until sc_fourstep_set_peers is called again (the peers' buffers are out of
+ * step; the caller re-creates the set-up or goes back to the collective exchange).
  * The region is FINE-GRAINED device memory (hipExtMallocWithFlags, as RCCL's peer-written buffers are): peers write into it
- * while this GPU's kernels poll and read it.  STARKCORE_IPC_COARSE=1 selects plain hipMalloc instead (A/B on real peers);
+ * while this GPU's kernels poll and read it.  sc_ipc_region_create_ex chooses: kind 1 fine-grained (coarse-grained when the
+ * runtime cannot export one), 0 coarse-grained = plain hipMalloc, -1 the default (fine-grained unless STARKCORE_IPC_COARSE=1);
  * sc_ipc_region_kind: 1 fine-grained, 0 coarse-grained, -1 no region created yet. */
 int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]);
+int sc_ipc_region_create_ex(uint64_t bytes, int kind, void** d_region, uint8_t handle_out[64]);
 int sc_ipc_region_kind(int* fine_grained);
 int sc_ipc_region_open(const uint8_t handle[64], void** d_region);
 int sc_ipc_region_close(void* d_region);        /* a region opened from a peer's handle */

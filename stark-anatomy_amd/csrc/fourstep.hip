@@ -197,6 +197,9 @@ struct sc_fourstep {
     bool peers_set = false;
     uint8_t* region[SC_MAX_BLOCKS] = {};
     uint64_t epoch = 0;
+    // pinned host word the flag barrier writes the epoch to when it gives up waiting for a peer: read for free at the top of every
+    // later transform, which then FAILS (the buffers hold a transform that never completed) until the plan is set up again
+    volatile uint64_t* timed_out = nullptr;
 };
 constexpr size_t FOURSTEP_FLAG_BYTES = 4096;
 
@@ -358,6 +361,7 @@ int sc_fourstep_create_ex(int log2n, const uint64_t root[2], int rank, int world
 }
 int sc_fourstep_free(sc_fourstep_t* plan) {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (plan && plan->timed_out) { (void)hipDeviceSynchronize(); (void)hipHostFree((void*)plan->timed_out); }
     delete plan;
     return SC_OK;
 }
@@ -390,7 +394,11 @@ int sc_fourstep_rows_finish_dev(const sc_fourstep_t* plan, int inverse, void* d_
 }
 
 // ---- direct-store corner turn: peers' receive buffers mapped through HIP IPC, the column stage stores across xGMI itself
-struct IpcFlags { uint64_t* of[SC_MAX_BLOCKS]; };      // of[h]: rank h's flag array (entry g = the last epoch rank g has finished writing)
+struct IpcFlags {
+    uint64_t* of[SC_MAX_BLOCKS];        // of[h]: rank h's flag array (entry g = the last epoch rank g has finished writing)
+    volatile uint64_t* host_timed_out;  // this rank's pinned status word
+    uint64_t spin_limit;                // polls of s_sleep 16 before the wait gives up (2^22: about two seconds)
+};
 
 // One workgroup, one lane per peer: tell peer t that this rank's column stage of transform `epoch` is complete (the stage is the
 // PREVIOUS kernel on this stream: its stores are released at its end; the fence below orders the flag behind them once more),
@@ -405,14 +413,21 @@ __global__ void __launch_bounds__(64) ipc_barrier_kernel(IpcFlags flags, int ran
         uint64_t spins = 0;
         while (__hip_atomic_load(&flags.of[rank][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1ull << 22)) { __hip_atomic_store(&flags.of[rank][SC_MAX_BLOCKS], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if (++spins > flags.spin_limit) {
+                __hip_atomic_store(&flags.of[rank][SC_MAX_BLOCKS], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (flags.host_timed_out && *flags.host_timed_out == 0) *flags.host_timed_out = epoch;
+                break;
+            }
         }
     }
     __threadfence_system();
 }
 
 static int g_ipc_fine_grained = -1;      // the kind of the last region created: 1 fine-grained, 0 coarse-grained, -1 none yet
-int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]) {
+int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]) { return sc_ipc_region_create_ex(bytes, -1, d_region, handle_out); }
+// kind: 1 fine-grained (coarse-grained if the runtime cannot export one), 0 coarse-grained, -1 the default (fine-grained unless
+// STARKCORE_IPC_COARSE=1).  STARKCORE_TEST_FINE_EXPORT_FAILS=1 (tests) makes the fine-grained export fail as a runtime without it would.
+int sc_ipc_region_create_ex(uint64_t bytes, int kind, void** d_region, uint8_t handle_out[64]) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!bytes || !d_region || !handle_out) return fail(SC_ERR_BAD_ARG, "null argument");
@@ -423,14 +438,15 @@ int sc_ipc_region_create(uint64_t bytes, void** d_region, uint8_t handle_out[64]
     // STARKCORE_IPC_COARSE=1 selects plain hipMalloc (for an A/B on a node with several GPUs); a runtime that cannot export a
     // fine-grained allocation falls back to it as well.  sc_ipc_region_kind() tells which one the last region got.
     const char* coarse_env = getenv("STARKCORE_IPC_COARSE");
-    const bool want_fine = !(coarse_env && coarse_env[0] == '1');
+    const char* fail_env = getenv("STARKCORE_TEST_FINE_EXPORT_FAILS");
+    const bool want_fine = kind < 0 ? !(coarse_env && coarse_env[0] == '1') : kind == 1;
     void* p = nullptr;
     hipIpcMemHandle_t h;
     hipError_t e = hipErrorUnknown;
     if (want_fine) {
         e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
         if (e == hipSuccess) e = hipMemset(p, 0, bytes);
-        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+        if (e == hipSuccess) e = (fail_env && fail_env[0] == '1') ? hipErrorInvalidValue : hipIpcGetMemHandle(&h, p);
         if (e != hipSuccess) { if (p) (void)hipFree(p); p = nullptr; (void)hipGetLastError(); }
         else g_ipc_fine_grained = 1;
     }
@@ -488,6 +504,12 @@ int sc_fourstep_set_peers(sc_fourstep_t* plan, void* const* regions) {
         if (!regions[h]) return fail(SC_ERR_BAD_ARG, "a rank's region is missing");
         plan->region[h] = (uint8_t*)regions[h];
     }
+    if (!plan->timed_out) {
+        uint64_t* w = nullptr;
+        HIPCHK(hipHostMalloc((void**)&w, 64, hipHostMallocCoherent | hipHostMallocMapped));
+        plan->timed_out = w;
+    }
+    *plan->timed_out = 0;
     plan->peers_set = true;
     plan->epoch = 0;
     return SC_OK;
@@ -500,6 +522,9 @@ int sc_fourstep_run_direct_dev(sc_fourstep_t* plan, int inverse, const void* d_s
     SCCHK(ensure_init());
     if (!plan || !d_src || !d_dst) return fail(SC_ERR_BAD_ARG, "null argument");
     if (!plan->peers_set) return fail(SC_ERR_BAD_ARG, "sc_fourstep_set_peers has not been called");
+    if (plan->timed_out && *plan->timed_out)
+        return fail(SC_ERR_TIMEOUT, "a peer never arrived at the flag barrier of direct-store transform " + std::to_string((unsigned long long)*plan->timed_out) +
+                                    ": that transform's output is invalid and the receive buffers are out of step -- set the plan's peers up again (or use the collective exchange)");
     hipStream_t st = pick_stream(stream);
     const int dirn = inverse ? 1 : 0;
     const sc_fourstep::Dir& d = plan->dir[dirn];
@@ -518,6 +543,9 @@ int sc_fourstep_run_direct_dev(sc_fourstep_t* plan, int inverse, const void* d_s
     if (G > 1) {
         IpcFlags fl;
         for (uint64_t h = 0; h < SC_MAX_BLOCKS; ++h) fl.of[h] = h < G ? (uint64_t*)plan->region[h] : nullptr;
+        fl.host_timed_out = plan->timed_out;
+        static const char* spin_env = getenv("STARKCORE_IPC_BARRIER_SPINS");            // (tests shorten the two seconds)
+        fl.spin_limit = spin_env && atoll(spin_env) > 0 ? (uint64_t)atoll(spin_env) : (1ull << 22);
         hipLaunchKernelGGL(ipc_barrier_kernel, dim3(1), dim3(64), 0, st, fl, plan->rank, plan->world, plan->epoch + 1);
         HIPCHK(hipGetLastError());
     }
@@ -530,7 +558,7 @@ int sc_fourstep_run_direct_dev(sc_fourstep_t* plan, int inverse, const void* d_s
 int sc_fourstep_direct_status(const sc_fourstep_t* plan, uint64_t* timed_out_epoch) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!plan || !timed_out_epoch || !plan->peers_set) return fail(SC_ERR_BAD_ARG, "no direct-store set-up");
-    HIPCHK(hipMemcpy(timed_out_epoch, plan->region[plan->rank] + SC_MAX_BLOCKS * sizeof(uint64_t), sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *timed_out_epoch = plan->timed_out ? *plan->timed_out : 0;        // (a pinned word the barrier kernel writes: no copy, no wait)
     return SC_OK;
 }
 

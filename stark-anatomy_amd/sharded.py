@@ -122,6 +122,12 @@ class _Works:
         return True
 
 
+class DirectStoreTimeout(RuntimeError):
+    """a flag barrier of the direct-store corner turn gave up waiting for a peer: the transform that was running has no valid output
+    and the ranks' receive buffers are out of step.  ShardedNtt.fall_back_to_exchange() (collective) puts every rank on the
+    collective exchange; the caller then repeats the transform."""
+
+
 class HipFourstep:
     """A rank's share of the sharded transform as ONE library object (sc_fourstep_t, include/starkcore.h): roots, stage shapes,
     the outer-twiddle table and the kernel plans are fixed once; a stage is one ctypes call with pointers only."""
@@ -142,34 +148,46 @@ class HipFourstep:
         self.sc._check(self.lib.sc_fourstep_shape(self._h, 0, self.ct.byref(rows), None))
         return int(rows.value)
 
-    def setup_direct(self, device, group=None):
+    def setup_direct(self, device, group=None, kind=-1):
         """The direct-store corner turn (sc_fourstep_run_direct_dev): this rank's receive region is created and exported (HIP IPC),
         the 64-byte handles travel once through torch.distributed, every peer's region is mapped.  Collective.  Returns True when
-        it is up on EVERY rank."""
+        it is up on EVERY rank; on failure everything this attempt made is released again (the caller may try another kind).
+        kind: 1 fine-grained device memory, 0 coarse-grained, -1 the library's default (sc_ipc_region_create_ex).
+        STARKCORE_TEST_OPEN_FAILS_KIND=<0|1> (tests): mapping a peer's region of that kind fails, as a runtime that cannot import
+        it would."""
+        import os
         ct, sc, lib = self.ct, self.sc, self.lib
         G, g = self.world, self.rank
         size = ct.c_uint64()
         sc._check(lib.sc_fourstep_region_bytes(self._h, ct.byref(size)))
         region, handle = ct.c_void_p(), ct.create_string_buffer(64)
-        ok = 1 if lib.sc_ipc_region_create(size.value, ct.byref(region), handle) == 0 else 0
+        ok = 1 if lib.sc_ipc_region_create_ex(size.value, int(kind), ct.byref(region), handle) == 0 else 0
+        got = -1
         if ok:
             self._own_region = region
+            v = ct.c_int(-1)
+            lib.sc_ipc_region_kind(ct.byref(v))
+            got = int(v.value)
+        self.direct_kinds = [got]
         regions = [None] * G
         regions[g] = region.value
         if G > 1:
             on_dev = dist.get_backend(group) == "nccl"
-            mine = torch.tensor([ok] + list(handle.raw), dtype=torch.int32)
+            mine = torch.tensor([ok, got] + list(handle.raw), dtype=torch.int32)
             mine = mine.to(device) if on_dev else mine
             parts = [torch.empty_like(mine) for _ in range(G)]
             dist.all_gather(parts, mine, group=group)
             parts = [t.cpu() for t in parts]
             ok = int(all(int(t[0]) == 1 for t in parts))
+            self.direct_kinds = [int(t[1]) for t in parts]
+            failing = os.environ.get("STARKCORE_TEST_OPEN_FAILS_KIND")
             if ok:
                 for h in range(G):
                     if h == g:
                         continue
                     peer = ct.c_void_p()
-                    if lib.sc_ipc_region_open(bytes(int(v) & 255 for v in parts[h][1:].tolist()), ct.byref(peer)) != 0:
+                    refused = failing is not None and int(parts[h][1]) == int(failing)
+                    if refused or lib.sc_ipc_region_open(bytes(int(v) & 255 for v in parts[h][2:].tolist()), ct.byref(peer)) != 0:
                         ok = 0
                         break
                     self._peer_regions.append(peer)
@@ -181,6 +199,8 @@ class HipFourstep:
         if ok:
             sc._check(lib.sc_fourstep_set_peers(self._h, (ct.c_void_p * G)(*regions)))
             self.direct = True
+        else:
+            self.release_direct()
         return bool(ok)
 
     def region_kind(self):
@@ -190,10 +210,15 @@ class HipFourstep:
         return {1: "fine-grained", 0: "coarse-grained"}.get(int(v.value), "none")
 
     def run_direct(self, inverse, src, dst):
-        self.sc._check(self.lib.sc_fourstep_run_direct_dev(self._h, inverse, src.data_ptr(), dst.data_ptr(), self.sptr))
+        rc = self.lib.sc_fourstep_run_direct_dev(self._h, inverse, src.data_ptr(), dst.data_ptr(), self.sptr)
+        if rc == self.sc.SC_ERR_TIMEOUT:
+            raise DirectStoreTimeout(self.lib.sc_last_error().decode())
+        self.sc._check(rc)
 
     def direct_timed_out(self):
-        """0, or the epoch of the first flag barrier that gave up waiting for a peer (call after synchronising the stream)"""
+        """0, or the number of the first transform whose flag barrier gave up waiting for a peer (a pinned word the barrier kernel
+        writes: no copy, no wait -- meaningful for transforms the stream has finished).  Sticky: once it is set, run_direct raises
+        DirectStoreTimeout until the set-up is made again."""
         v = self.ct.c_uint64()
         self.sc._check(self.lib.sc_fourstep_direct_status(self._h, self.ct.byref(v)))
         return int(v.value)
@@ -311,9 +336,21 @@ class ShardedNtt:
         # the corner turn as the column stage's own stores into the peers' receive buffers (HIP IPC; no collective): set up
         # collectively here, used by _transform when it came up on every rank
         self.direct_store = False
+        self.corner_turn_setup = []                # what was tried for the corner turn, in order, and how it went (bench: corner_turn_probes)
         if direct_store:
             assert self.stages is not None and hasattr(self.stages, "setup_direct"), "the direct-store corner turn needs the HIP stage object"
-            self.direct_store = self.stages.setup_direct(device, group)
+            # peers store into a region of this GPU while its kernels poll and read it: fine-grained device memory first (what RCCL
+            # uses for the same purpose); a runtime that cannot export or import that kind gets coarse-grained memory; when neither
+            # comes up on EVERY rank the transform keeps the collective exchange (RCCL)
+            for kind, name in ((1, "fine-grained"), (0, "coarse-grained")):
+                up = self.stages.setup_direct(device, group, kind)
+                kinds = sorted(set({1: "fine-grained", 0: "coarse-grained"}.get(k, "none") for k in getattr(self.stages, "direct_kinds", [])))
+                self.corner_turn_setup.append("direct store, %s regions requested: %s" % (name, ("up on every rank (regions: %s)" % ", ".join(kinds)) if up else "did not come up on every rank"))
+                if up:
+                    self.direct_store = True
+                    break
+            if not self.direct_store:
+                self.corner_turn_setup.append("collective exchange (no direct-store set-up came up)")
         self._bufs = {}
         self._a2a_single = True
         self.bytes_exchanged = 0                   # bytes this rank has sent through the corner turn so far
@@ -344,6 +381,28 @@ class ShardedNtt:
         for r in range(R):
             out[r] = synth.synth_packed(seed, w, start=r * C + self.rank * w)
         return torch.from_numpy(out.view(np.int64)).to(self.device)
+
+    def fall_back_to_exchange(self):
+        """COLLECTIVE.  After a DirectStoreTimeout on any rank (or a non-zero stages.direct_timed_out()): every rank leaves the
+        direct-store form and uses the collective exchange from now on; the caller repeats the transform that failed.  Returns
+        whether any rank had seen a timeout."""
+        if not getattr(self.stages, "direct", False) and not self.direct_store:
+            return False
+        if self.stream is not None:
+            self.stream.synchronize()
+        else:
+            torch.cuda.synchronize()
+        seen = 1 if (getattr(self.stages, "direct", False) and self.stages.direct_timed_out()) else 0
+        if self.world > 1:
+            on_dev = dist.get_backend(self.group) == "nccl"
+            flag = torch.tensor([seen], dtype=torch.int32)
+            flag = flag.to(self.device) if on_dev else flag
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            seen = int(flag.item())
+        self.stages.release_direct()
+        self.direct_store = False
+        self.corner_turn_setup.append("direct store abandoned (%s): collective exchange from here on" % ("a flag barrier timed out" if seen else "at the caller's request"))
+        return bool(seen)
 
     # -- the transform ---------------------------------------------------------------------------
     def _transform(self, src, dst, inverse):

@@ -21,6 +21,7 @@ SC_ERR_ROOT_ORDER = -3
 SC_ERR_ROOT_NOT_PRIMITIVE = -4
 SC_ERR_DIV_ZERO = -5
 SC_ERR_UNSUPPORTED = -7
+SC_ERR_TIMEOUT = -9
 
 # every symbol include/starkcore.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -55,6 +56,7 @@ SIGNATURES = {
     "sc_fourstep_create": (_int, [_int, _vp, _int, _int, ctypes.POINTER(_vp)]),
     "sc_fourstep_create_ex": (_int, [_int, _vp, _int, _int, _int, ctypes.POINTER(_vp)]),
     "sc_ipc_region_create": (_int, [_u64, ctypes.POINTER(_vp), _vp]),
+    "sc_ipc_region_create_ex": (_int, [_u64, _int, ctypes.POINTER(_vp), _vp]),
     "sc_ipc_region_open": (_int, [_vp, ctypes.POINTER(_vp)]),
     "sc_ipc_region_kind": (_int, [ctypes.POINTER(_int)]),
     "sc_ipc_region_close": (_int, [_vp]),

@@ -280,5 +280,75 @@ def fri_check(rank, world, dev):
     return ok
 
 
+def direct_faults_main():
+    """tests/test_gpu_sharded.py::test_direct_store_faults_end_in_a_correct_transform: what the environment makes fail, the set-up
+    must survive -- a fine-grained export that fails, peers that cannot import one kind of region, no kind at all, a peer that is
+    late for a flag barrier -- every time ending in a transform equal to the oracle's through the next form in line."""
+    import time
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    case = sys.argv[2]
+    os.environ["STARKCORE_DEVICE"] = "0"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import starkcore as sc
+    sc.init(0)
+    from sharded import ShardedNtt, DirectStoreTimeout, gather_natural
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log2n = 14
+    n = 1 << log2n
+    root = po.primitive_nth_root(n)
+    want = po.C.ntt(root, synth.synth_packed(3, n).tobytes(), n)
+    eng = ShardedNtt(log2n, root, rank, world, dev, direct_store=True)
+    x = eng.synthetic_input(seed=3)
+    y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
+    z = torch.empty_like(x)
+
+    def correct():
+        eng.forward(x, y)
+        eng.inverse(y, z)
+        torch.cuda.synchronize()
+        return gather_natural(y.cpu(), eng.n2, eng.n1, world).numpy().tobytes() == want and torch.equal(z, x)
+    setup = "; ".join(eng.corner_turn_setup)
+    ok = True
+    if case == "fine_export_fails":              # STARKCORE_TEST_FINE_EXPORT_FAILS=1: the region silently becomes coarse-grained
+        ok &= eng.direct_store and eng.stages.region_kind() == "coarse-grained" and correct() and eng.stages.direct_timed_out() == 0
+    elif case == "fine_import_fails":            # STARKCORE_TEST_OPEN_FAILS_KIND=1: first attempt down on every rank, the coarse-grained one up
+        ok &= eng.direct_store and "fine-grained regions requested: did not come up" in setup and "coarse-grained regions requested: up" in setup
+        ok &= eng.stages.region_kind() == "coarse-grained" and correct() and eng.stages.direct_timed_out() == 0
+    elif case == "nothing_imports":              # neither kind can be mapped: the collective exchange carries the corner turn
+        ok &= (not eng.direct_store) and "collective exchange" in setup and correct()
+    elif case == "late_peer":                    # STARKCORE_IPC_BARRIER_SPINS small: a rank that is late by a second misses the barrier
+        ok &= eng.direct_store and correct()
+        dist.barrier()
+        if rank == 1:
+            time.sleep(1.5)
+        try:
+            eng.forward(x, y)
+            torch.cuda.synchronize()
+        except DirectStoreTimeout:
+            pass
+        if rank != 1:
+            ok &= eng.stages.direct_timed_out() != 0
+            try:                                 # sticky: the plan refuses every later transform
+                eng.forward(x, y)
+                ok = False
+            except DirectStoreTimeout as e:
+                ok &= "never arrived" in str(e)
+        ok &= eng.fall_back_to_exchange() is True           # collective: every rank leaves the direct-store form
+        ok &= (not eng.direct_store) and correct()
+    else:
+        ok = False
+    if not ok:
+        print("rank", rank, "case", case, "FAILED; set-up:", setup, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+    print("rank", rank, "ok")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "direct_faults":
+        direct_faults_main()
+    else:
+        main()

@@ -196,6 +196,33 @@ def test_ranks_share_one_gpu(world):
     assert r.stdout.count("ok") == world
 
 
+@pytest.mark.parametrize("case,env", [("fine_export_fails", {"STARKCORE_TEST_FINE_EXPORT_FAILS": "1"}),
+                                      ("fine_import_fails", {"STARKCORE_TEST_OPEN_FAILS_KIND": "1"}),
+                                      ("nothing_imports", {"STARKCORE_TEST_OPEN_FAILS_KIND": "0", "STARKCORE_TEST_FINE_EXPORT_FAILS": "1"}),
+                                      ("late_peer", {"STARKCORE_IPC_BARRIER_SPINS": "20000"})])
+def test_direct_store_faults_end_in_a_correct_transform(case, env):
+    """the direct-store corner turn must be impossible to ignore when it fails and easy to survive.  Two
+    processes on GPU 0 (real HIP IPC handles); the environment makes one thing fail per case: the fine-grained export (the region
+    becomes coarse-grained), the import of fine-grained regions on the peers (second attempt: coarse-grained), every import (the
+    collective exchange), a peer that is 1.5 s late for a flag barrier that waits ~50 ms (the barrier's rank sees the time-out in its
+    pinned status word, every later direct-store transform of the plan raises DirectStoreTimeout -- sticky --, a collective
+    fall_back_to_exchange puts both ranks on the exchange).  Every case ends in a transform equal to the oracle's."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    full = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", **env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "tests", "sharded_gpu_worker.py"), "direct_faults", case]
+    r = subprocess.run(cmd, env=full, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
+
+
 def test_sharded_fast_stark_one_rank(sc):
     """sharded_stark.ShardedFastStark at world 1 (no process group): the same proof bytes as fast_stark.FastStark.prove from the
     same random bytes (worlds of 2 and 4 ranks: test_ranks_share_one_gpu)."""
