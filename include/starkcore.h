@@ -60,8 +60,11 @@ int sc_stream(void** stream_out);
 int sc_stream_join(void* other_stream);
 /* tuning knobs for experiments (defaults are the measured optimum; -1 = choose by size where applicable): key in
  * {"max_tile_log","loge","max_col_log","min_tiles_log","single_pass_max_log","max_digit_log","direct_tw_max_log",
- *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune"}.  Plans are re-derived on the next call; results
- * never depend on the tuning. */
+ *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune","fri_tail"}.  Plans are re-derived on the next
+ * call; results never depend on the tuning.  Two keys manage the device-memory pool instead (freed vectors and trees are kept
+ * on exact-size free lists, by default up to a quarter of the device's memory divided by the processes sharing the device;
+ * environment STARKCORE_POOL_CAP_MB): "pool_cap_mb" = what the lists may keep from now on, "pool_trim" = hand everything on them
+ * back to the device now (a caller whose own allocator -- torch's -- ran out of memory). */
 int sc_set_tuning(const char* key, int value);
 /* kernel launches (passes over the vector) one sc_ntt_dev of length n takes at the current tuning: 1 up to 2^11, 2 up to 2^20,
  * 3 up to 2^24, 4 beyond (0: n is not a power of two >= 2).  bench.py derives the algorithmic bytes per launch from it. */
@@ -79,6 +82,9 @@ int sc_field_selftest(int op, const void* a, const void* b, void* out, uint64_t 
 /* ---- device vectors ----------------------------------------------------------------------- */
 int sc_vec_alloc(uint64_t n, sc_vec_t** out);
 int sc_vec_free(sc_vec_t* v);
+/* a handle over device memory the CALLER owns (n field elements at d_elems, e.g. a torch tensor's storage): no copy; the memory must
+ * outlive the handle and every call enqueued with it; sc_vec_free releases the handle only */
+int sc_vec_wrap(void* d_elems, uint64_t n, sc_vec_t** out);
 uint64_t sc_vec_len(const sc_vec_t* v);
 void* sc_vec_ptr(sc_vec_t* v);         /* raw device pointer */
 int sc_vec_zero(sc_vec_t* v);                                   /* all elements = 0 (library stream) */

@@ -38,6 +38,7 @@ using namespace sc;
 struct sc_vec {
     Fe* d;
     uint64_t n;
+    bool owned = true;    // false: a view of memory somebody else owns (sc_vec_wrap: a torch tensor's storage) -- sc_vec_free leaves it alone
 };
 struct sc_merkle {
     uint64_t* d_levels;   // (2N-1) digests of 8 x u64

@@ -343,6 +343,10 @@ int ensure_init() {
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g.num_cus = cus; }
     { size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) g_pool_cap = total_b / 4; else (void)hipGetLastError(); }
+    // several processes on one device (torchrun with more ranks than GPUs: the shared-GPU functional runs) share that quarter;
+    // STARKCORE_POOL_CAP_MB sets the cap outright (0: nothing is kept), sc_set_tuning("pool_cap_mb" / "pool_trim") at run time
+    if (const char* lws = getenv("LOCAL_WORLD_SIZE")) { const int per_dev = (atoi(lws) + n - 1) / n; if (per_dev > 1) g_pool_cap /= (size_t)per_dev; }
+    if (const char* cap = getenv("STARKCORE_POOL_CAP_MB")) g_pool_cap = (size_t)atoll(cap) << 20;
     g.device = dev;
     g.init = true;
     return SC_OK;
@@ -737,6 +741,10 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "prune") g.tuning.prune = value;
     else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "fri_tail") g.fri_tail = value ? 1 : 0;
+    else if (k == "pool_cap_mb") g_pool_cap = (size_t)(value < 0 ? 0 : value) << 20;       // what the free lists may keep from now on
+    else if (k == "pool_trim") {                                                            // give everything in the free lists back to the device now
+        if (g.init) { (void)hipDeviceSynchronize(); reap_pending(true); pool_clear(); }
+    }
     else return fail(SC_ERR_BAD_ARG, "unknown tuning key " + k);
     return SC_OK;
 }
@@ -766,8 +774,17 @@ int sc_vec_alloc(uint64_t n, sc_vec_t** out) {
 int sc_vec_free(sc_vec_t* v) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!v) return SC_OK;
-    release_after_streams(v->d, (v->n ? v->n : 1) * sizeof(Fe));
+    if (v->owned) release_after_streams(v->d, (v->n ? v->n : 1) * sizeof(Fe));
     delete v;
+    return SC_OK;
+}
+// a vector handle over device memory the CALLER owns (a torch tensor's storage): no copy in, no copy out; the memory must outlive
+// the handle and every call enqueued with it
+int sc_vec_wrap(void* d_elems, uint64_t n, sc_vec_t** out) {
+    if (!d_elems || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    sc_vec* v = new sc_vec{(Fe*)d_elems, n};
+    v->owned = false;
+    *out = v;
     return SC_OK;
 }
 uint64_t sc_vec_len(const sc_vec_t* v) { return v ? v->n : 0; }

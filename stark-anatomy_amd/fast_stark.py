@@ -233,11 +233,26 @@ class FastStark:
         # bytes(i) is i zero bytes (fast_stark.py:74)
         return [self.field.sample(blake2b(randomness + bytes(i)).digest()) for i in range(0, number)]
 
+    # a list here turns on the per-phase breakdown: after each phase of prove() the device is waited for and (phase, seconds since
+    # the previous mark) is appended -- measurement only (tools/stark_phase_compare.py); the phases are sharded_stark's
+    phase_log = None
+
+    def _mark(self, phase):
+        if self.phase_log is None:
+            return
+        import time
+        _sc.synchronize()
+        now = time.perf_counter()
+        if phase is not None:
+            self.phase_log.append((phase, now - self._phase_t0))
+        self._phase_t0 = now
+
     # -- prover (fast_stark.py:76-178) -------------------------------------------------------------
     def prove(self, trace, transition_constraints, boundary, transition_zerofier, transition_zerofier_codeword, proof_stream=None):
         if proof_stream == None:
             proof_stream = ProofStream()
         field, registers = self.field, range(self.num_registers)
+        self._mark(None)
 
         # randomizer rows appended to the trace (draw order: row by row, register by register); one concatenation instead of one
         # per row -- the caller's list is not touched either way
@@ -262,6 +277,7 @@ class FastStark:
             # the combination.  The host keeps what byte parity ties to it: os.urandom draws, Fiat-Shamir, the proof stream.
             trace_domain = self._trace_domain(trace_rows)
             trace_polynomials = [DevicePolynomial.from_codeword(fast_interpolate_device(trace_domain, column)) for column in columns]
+            self._mark("trace interpolation")
             zerofiers_dev = [DevicePolynomial.from_polynomial(z, field) for z in zerofiers]
             boundary_quotients = [coset_divide_device(trace_polynomials[s].minus(interpolants[s]), zerofiers_dev[s], self.generator, self.omicron,
                                                       self.omicron_domain_length, exact=True) for s in registers]
@@ -274,11 +290,13 @@ class FastStark:
             boundary_quotients = [(trace_polynomials[s] - interpolants[s]) / zerofiers[s] for s in registers]
             lde = self._lde
 
+        self._mark("boundary quotients (division)")
         # commit to their low-degree extensions
         boundary_quotient_codewords = []
         for s in registers:
             boundary_quotient_codewords.append(lde(boundary_quotients[s]))
             proof_stream.push(Merkle.commit(boundary_quotient_codewords[s]))
+        self._mark("boundary quotient LDEs + commitments")
 
         # transition polynomials: AIR evaluated symbolically in (X, trace(X), trace(omicron X)), then quotients
         x = Polynomial([field.zero(), field.one()])
@@ -289,6 +307,7 @@ class FastStark:
             transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
             transition_quotients = [fast_coset_divide(tp, transition_zerofier, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
 
+        self._mark("AIR substitution + transition quotients (value domain)")
         # randomizer polynomial
         max_degree = self.max_degree(transition_constraints)
         if on_device:
@@ -296,8 +315,10 @@ class FastStark:
             randomizer_polynomial = random_polynomial(max_degree + 1, field)
         else:
             randomizer_polynomial = Polynomial([field.sample(os.urandom(17)) for i in range(max_degree + 1)])
+        self._mark("randomizer polynomial: os.urandom / getrandom draws and Field.sample")
         randomizer_codeword = lde(randomizer_polynomial)
         proof_stream.push(Merkle.commit(randomizer_codeword))
+        self._mark("randomizer polynomial: LDE, commitment")
 
         # Fiat-Shamir weights: 1 randomizer + 2 per transition quotient + 2 per boundary quotient
         weights = self.sample_weights(1 + 2 * len(transition_quotients) + 2 * len(boundary_quotients), proof_stream.prover_fiat_shamir())
@@ -313,6 +334,7 @@ class FastStark:
             shifted.append((boundary_quotients[i], max_degree - bq_bounds[i]))
         if on_device:
             combined_codeword = self._combine_on_device(shifted, weights, max_degree)
+            self._mark("weights, degree checks, nonlinear combination + its LDE")
         else:
             terms = []
             for poly, shift in shifted:
@@ -335,6 +357,7 @@ class FastStark:
         if all(_po.eligible(codeword) for codeword in committed) and type(proof_stream) is ProofStream:
             together = AlsoOpen(lambda indices: (committed, [opened_positions(indices)] * len(committed)), codewords=committed, shift=self.expansion_factor)
         indices = self.fri.prove(combined_codeword, proof_stream, together) if together is not None else self.fri.prove(combined_codeword, proof_stream)
+        self._mark("FRI: commit + query phases, openings fetched with them")
 
         quadrupled_indices = opened_positions(indices)
         lazy = _po.lazy_objects(proof_stream) if all(_po.eligible(codeword) for codeword in committed) else None
@@ -351,7 +374,10 @@ class FastStark:
             for codeword in committed:
                 self._open_all(codeword, quadrupled_indices, proof_stream)
 
-        return proof_stream.serialize()
+        self._mark("openings of the committed codewords")
+        proof = proof_stream.serialize()
+        self._mark("proof serialization (host pickle)")
+        return proof
 
     def _transition_quotients_on_device(self, constraints, point, tz_dev):
         """fast_stark.py:107-113 -- `a.evaluate_symbolic(point)` divided by the transition zerofier -- without ever building the

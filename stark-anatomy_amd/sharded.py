@@ -891,6 +891,8 @@ class ShardedFri:
     # throughput-bound and sharding pays.
     LOCAL_TAIL = 1 << 16
 
+    one_rank_local = False      # (set per instance below; subclasses with their own constructor keep every round sharded)
+
     def __init__(self, fri, R, rank, world, device, engine=None, group=None, local_tail=None):
         """local_tail: once a round's codeword is this short it is gathered on every rank and the remaining rounds run locally
         (replicated): such rounds are bound by launch and hashing latency on any number of ranks, a collective per round only
@@ -900,6 +902,10 @@ class ShardedFri:
         self.Rw = self.R // world
         self.engine = engine if engine is not None else HipFriEngine(device)
         self.local_tail = self.LOCAL_TAIL if local_tail is None else int(local_tail)
+        # ONE rank (and no explicit local_tail, which asks for the slab rounds): the "slab" is the whole codeword in natural order --
+        # one tree per commitment instead of a subtree plus a tree over its sub-roots, no sub-root level copied out, nothing
+        # gathered, and the whole commit phase is one library call.  What a rank pays for the sharded layout when nobody shares it.
+        self.one_rank_local = world == 1 and local_tail is None
 
     # -- collectives ------------------------------------------------------------------------------
     def _all_gather(self, t):
@@ -1002,6 +1008,12 @@ class ShardedFri:
     def _commit_sharded(self, slab, C, local=None):
         """local: the rank's subtree over `slab` if the fold that produced the slab has built it already (fold_slab_tree)"""
         eng, G, Rw = self.engine, self.world, self.Rw
+        if self.one_rank_local and hasattr(eng, "query_many"):
+            # one rank: its "slab" is the whole codeword in natural order and its subtree the whole tree -- ONE tree, no sub-root
+            # level copied out, no gather, no second tree above it (a quarter of a world-1 proof's commitments otherwise)
+            full = slab.reshape(C * self.R, 2)
+            tree = local if local is not None else eng.tree(full)
+            return {"kind": "local", "vec": full, "tree": tree, "root": tree.root, "length": C * self.R, "cache": {}}
         if local is None:
             local = eng.tree(slab, need_root=False)
         sub_level = Rw.bit_length() - 1
@@ -1158,11 +1170,18 @@ class ShardedFri:
         assert tuple(slab.shape) == (C, Rw, 2), "slab must be this rank's [C][R/G] columns"
         omega, offset, rounds = fr.omega, fr.offset, fr.num_rounds()
         layers, cur, full, local = [], slab, None, None
+        if self.one_rank_local:
+            top = self._prove_one_rank(slab, proof_stream, also_open)
+            if top is not None:
+                return top
         # fri.py:68 in every round: omega_r^(N_r) == 1 with omega_r = omega^(2^r), N_r = N / 2^r -- one condition, checked once
-        assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
+        if hasattr(fr, "_check_omega_order"):
+            fr._check_omega_order(N)                         # (once per Fri instance: a power and an inversion in Python integers)
+        else:
+            assert(omega ^ (N - 1) == omega.inverse()), "error in commit: omega does not have the right order!"
         for r in range(rounds):
             Nr = N >> r
-            if full is None and (C == 1 or Nr <= self.local_tail):
+            if full is None and (C == 1 or Nr <= self.local_tail or (self.one_rank_local and hasattr(eng, "commit_rounds"))):      # (one rank: nothing to gather, the slab IS the codeword)
                 full = self._natural(cur, C)                # one row left / a short codeword: collect it everywhere, go local
                 rest = self._commit_tail(full, Nr, offset, omega, rounds - r, proof_stream)
                 if rest is not None:                        # ... and the library ran every remaining round in one call
@@ -1207,6 +1226,39 @@ class ShardedFri:
         proof_stream.push(last_list)
 
         return self._query_all(layers, last_list, proof_stream)
+
+    def _prove_one_rank(self, slab, proof_stream, also_open):
+        """ONE rank on the HIP engine: the slab is the codeword in natural order, so Fri.prove's one-call form (sc_fri_prove_dev:
+        commit phase, index sampling and every opening -- the caller's committed layers included -- in one library call) serves
+        it as it serves a single GPU's prover; the slab's memory is handed over as it is (DeviceVector.wrap).  None when a
+        precondition of that form does not hold (the rounds then run as on any number of ranks)."""
+        eng = self.engine
+        if not isinstance(eng, HipFriEngine) or not slab.is_cuda or not slab.is_contiguous():
+            return None
+        import starkcore as sc
+        from fri import AlsoOpen
+        if _current_raw_stream(self.device) != sc.library_stream():
+            return None                                    # (the one-call form runs on the library's stream)
+        N = self.fri.domain_length
+        inner = None
+        if also_open is not None:
+            more, shift = getattr(also_open, "layers", None), getattr(also_open, "shift", None)
+            if more is None or shift is None or not all(layer["kind"] == "local" and isinstance(layer["tree"], HipFriEngine._Tree) and layer["length"] == N for layer in more):
+                return None
+            codewords = []
+            for layer in more:
+                cw = layer.get("codeword")
+                if cw is None:
+                    vec = layer["vec"]
+                    cw = layer["codeword"] = sc.DeviceCodeword(sc.DeviceVector.wrap(vec.data_ptr(), N, vec), self.fri.field)
+                    cw._tree = layer["tree"].tree
+                codewords.append(cw)
+            inner = AlsoOpen(None, codewords=codewords, shift=shift)
+        codeword = sc.DeviceCodeword(sc.DeviceVector.wrap(slab.data_ptr(), N, slab), self.fri.field)
+        top = self.fri._prove_in_library(codeword, proof_stream, inner)
+        if top is not None and also_open is not None:
+            also_open.answers = inner.answers
+        return top
 
     def _commit_tail(self, full, Nr, offset, omega, rounds_left, proof_stream):
         """the remaining rounds of the commit phase on the gathered codeword through the engine's whole-loop call, when there is

@@ -113,24 +113,22 @@ class HipReplicatedSteps:
 
     # -- between a polynomial and the torch tensor the collectives and the sharded transforms work on
     def coefficients(self, poly, length=None):
-        """coefficients as a torch tensor [length][2] (a copy: torch owns what the collectives touch)"""
+        """coefficients as a torch tensor [length][2]: a VIEW of the library's vector (CUDA array interface; the tensor keeps the
+        vector alive) -- nothing on the sharded side writes into a polynomial's coefficients (slab_of copies what it keeps)"""
         length = len(poly) if length is None else length
-        t = torch.empty((max(length, 1), 2), dtype=torch.int64, device=self.device)
-        if length:
-            self.join()
-            _sc._check(_sc.lib().sc_memcpy_dev(t.data_ptr(), poly.vec.ptr, length, None))
-            self.join()
-        return t[:length]
+        if not length:
+            return torch.empty((0, 2), dtype=torch.int64, device=self.device)
+        self.join()
+        return torch.as_tensor(poly.vec, device=self.device)[:length]
 
     def polynomial(self, tensor, length):
-        """the first `length` rows of a [..][2] tensor as a polynomial"""
-        vec = _sc.DeviceVector(max(length, 1))
-        if length:
-            tensor = tensor.contiguous()
-            self.join()
-            _sc._check(_sc.lib().sc_memcpy_dev(vec.ptr, tensor.data_ptr(), length, None))
-            self.join()                                   # `tensor` may go back to torch's allocator once this returns
-        return DevicePolynomial(vec, self.field, length)
+        """the first `length` rows of a [..][2] tensor as a polynomial: a vector handle over the tensor's own memory (sc_vec_wrap;
+        the polynomial keeps the tensor alive), no copy"""
+        if not length:
+            return DevicePolynomial(_sc.DeviceVector(1), self.field, 0)
+        tensor = tensor.contiguous()
+        self.join()
+        return DevicePolynomial(_sc.DeviceVector.wrap(tensor.data_ptr(), length, tensor), self.field, length)
 
 
 class ShardedFastStark(FastStark):
@@ -421,6 +419,7 @@ class ShardedFastStark(FastStark):
         together = None
         if hasattr(self.sfri.engine, "query_many") and type(proof_stream) is ProofStream:
             together = AlsoOpen(lambda indices: (layers, [opened_positions(indices)] * len(layers)))
+            together.layers, together.shift = list(layers), self.expansion_factor      # the same request as data (ShardedFri on one rank hands it to the library)
         indices = self.sfri.prove(slab, proof_stream, together) if together is not None else self.sfri.prove(slab, proof_stream)
         self._mark("FRI: commit + query phases (sharded), openings fetched with them")
 

@@ -38,6 +38,7 @@ SIGNATURES = {
     "sc_field_selftest": (_int, [_int, _vp, _vp, _vp, _u64]),
     "sc_vec_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
     "sc_vec_free": (_int, [_vp]),
+    "sc_vec_wrap": (_int, [_vp, _u64, ctypes.POINTER(_vp)]),
     "sc_vec_len": (_u64, [_vp]),
     "sc_vec_ptr": (_vp, [_vp]),
     "sc_vec_zero": (_int, [_vp]),
@@ -289,6 +290,23 @@ class DeviceVector:
         h = _vp()
         _check(lib().sc_vec_alloc(self.n, ctypes.byref(h)))
         self._h = h
+
+    @classmethod
+    def wrap(cls, ptr, n, keep):
+        """a vector over device memory somebody else owns (sc_vec_wrap): `keep` -- the owner, e.g. a torch tensor -- stays alive
+        as long as this object does.  No copy."""
+        v = cls.__new__(cls)
+        v.n = int(n)
+        h = _vp()
+        _check(lib().sc_vec_wrap(_vp(int(ptr)), v.n, ctypes.byref(h)))
+        v._h, v._keep = h, keep
+        return v
+
+    @property
+    def __cuda_array_interface__(self):
+        """the elements as an [n][2] array of int64 limbs for whoever speaks the CUDA array interface (torch.as_tensor(vec,
+        device=...) is a view: no copy; the consumer keeps this object alive)"""
+        return {"shape": (self.n, 2), "typestr": "<i8", "data": (int(self.ptr), False), "version": 3, "strides": None}
 
     @classmethod
     def adopt(cls, handle, n):

@@ -747,3 +747,34 @@ def test_urandom_prefetch_then_sample(sc):
         vals = sc.unpack(v.to_bytes())
         assert all(0 <= x < p for x in vals) and len(set(vals)) == count
     sc._check(lib.sc_urandom_prefetch(1000, 17))                                          # left unused: the next call (or shutdown) collects it
+
+
+def test_pool_cap_and_trim(sc):
+    """the free lists of the device-memory pool must be steerable -- a cap the caller sets, and a trim that hands the
+    idle buffers back to the device (torch's allocator in the same process, or another rank on the same GPU, may need them)."""
+    import torch
+    lib = sc.lib()
+    n = 1 << 22                                   # 64 MB vectors
+    sc.synchronize()
+    sc.set_tuning("pool_trim", 1)
+    free0 = torch.cuda.mem_get_info(0)[0]
+    vs = [sc.DeviceVector(n) for _ in range(4)]
+    for v in vs:
+        v.free() if hasattr(v, "free") else None
+    del vs
+    sc.synchronize()
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    assert held >= 3 * 16 * n, held               # the freed vectors sit in the pool
+    sc.set_tuning("pool_trim", 1)
+    assert free0 - torch.cuda.mem_get_info(0)[0] < 16 * n
+    sc.set_tuning("pool_cap_mb", 0)               # nothing is kept from now on
+    try:
+        v = sc.DeviceVector(n)
+        del v
+        sc.synchronize()
+        w = sc.DeviceVector(16)                   # (an allocation reaps what was parked behind events)
+        del w
+        sc.set_tuning("pool_trim", 1)
+        assert free0 - torch.cuda.mem_get_info(0)[0] < 16 * n
+    finally:
+        sc.set_tuning("pool_cap_mb", 72 * 1024)
