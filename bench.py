@@ -890,7 +890,7 @@ def stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend,
         rec = {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_%dgpu" % (log_fri - 4, log_fri, world), "log2n": log_fri, "world_size": world,
                "registers": 2, "colinearity_checks": s, "expansion_factor": 4, "ms_per_proof": 1e3 * elapsed / steps,
                "trace": "device-resident columns (fast_stark.DeviceTrace), generated on the host outside the timed region",
-               "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace-domain polynomials replicated",
+               "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace interpolation one register per rank (broadcast); combination replicated",
                "proof_bytes": len(proof), "proof_sha256_16": digest.hex()[:16], "same_proof_on_every_rank": same_everywhere,
                "verify_accepts": verifies, "verify_s": verify_s, "preprocess_s": preprocess_s, "runs_ms": [round(x * 1e3, 3) for x in t.tolist()]}
         if phase_ms is not None:

@@ -12,9 +12,11 @@ what is big -- everything that lives on the FRI domain (expansion_factor x the t
   * the low-degree test is `ShardedFri.prove` (slab-local folds, no element exchange), and the openings of the committed
     codewords (fast_stark.py:154-175) are answered by the owning ranks and merged with one collective per codeword.
 
-What is small stays replicated on every rank and runs exactly as in fast_stark.FastStark (same code): the trace interpolation
-over the subproduct tree, the AIR substitution in the value domain, the degree bookkeeping and the weighted sum of the
-nonlinear combination -- polynomials of the trace domain's size.  Byte parity ties the rest to the host: the os.urandom draws
+The trace interpolation (fast_stark.py:84-87) is spread by COLUMN: register s is interpolated by rank s mod G (closed forms on the
+progression {omicron^i}: csrc/geoseq.cuh) and broadcast -- the registers are independent, and the next steps need every
+polynomial's coefficients on every rank.  What is small stays replicated on every rank and runs exactly as in
+fast_stark.FastStark (same code): the degree bookkeeping and the weighted sum of the nonlinear combination -- polynomials of the
+trace domain's size.  Byte parity ties the rest to the host: the os.urandom draws
 (rank 0 draws, in the reference's order, and broadcasts the bytes), Fiat-Shamir, the proof stream.  Every rank ends with the
 same proof, byte-identical to `FastStark.prove` on one GPU with the same random bytes (tests/test_gpu_sharded.py).
 """
@@ -74,10 +76,11 @@ class HipReplicatedSteps:
         domain = DeviceDomain.geometric(self.field.one(), self.stark.omicron, count)
         return DevicePolynomial.from_codeword(fast_zerofier_device(domain))
 
-    def trace_polynomials(self, trace, rows, registers, raw):
+    def trace_polynomials(self, trace, rows, registers, raw, only=None):
         """fast_stark.py:79-87: the trace with its randomizer rows (`raw`: the os.urandom draws, in the reference's order)
         interpolated column by column through {omicron^i, i < rows} -- a geometric progression: a handful of convolutions per
-        column over tables built once (csrc/geoseq.cuh).  trace: the reference's list of rows, or a fast_stark.DeviceTrace."""
+        column over tables built once (csrc/geoseq.cuh).  trace: the reference's list of rows, or a fast_stark.DeviceTrace.
+        only: the registers THIS rank interpolates (None: all of them); the others' places hold None."""
         stark, field = self.stark, self.field
         if isinstance(trace, _fs.DeviceTrace):
             columns = stark._randomized_columns(trace, raw)
@@ -87,7 +90,7 @@ class HipReplicatedSteps:
             full = trace + [draws[r * width:(r + 1) * width] for r in range(stark.num_randomizers)]
             columns = [DeviceCodeword.from_list([row[s] for row in full], field) for s in registers]
         domain = stark._trace_domain(rows)
-        return [DevicePolynomial.from_codeword(fast_interpolate_device(domain, column)) for column in columns]
+        return [DevicePolynomial.from_codeword(fast_interpolate_device(domain, column)) if only is None or s in only else None for s, column in zip(registers, columns)]
 
     def coset_divide(self, lhs, rhs, exact):
         s = self.stark
@@ -188,6 +191,34 @@ class ShardedFastStark(FastStark):
         """column slabs [rows][cols/G] of every rank -> the whole natural-order vector [rows*cols][2], on every rank"""
         parts = self.sfri._all_gather(slab)                           # [G][rows][cols/G][2]
         return parts.permute(1, 0, 2, 3).reshape(rows * cols, 2).contiguous()
+
+    def _broadcast(self, t, src):
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":        # functional runs with several ranks on one GPU: host-staged
+            host = t.cpu()
+            dist.broadcast(host, src=src, group=self.group)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=src, group=self.group)
+        return t
+
+    def _trace_polynomials_by_column(self, trace, rows, registers, raw):
+        steps, G, g = self.steps, self.world, self.rank
+        if G == 1:
+            return steps.trace_polynomials(trace, rows, registers, raw)
+        registers = list(registers)
+        mine = [s for s in registers if s % G == g]
+        polys = steps.trace_polynomials(trace, rows, registers, raw, only=mine)
+        for k, s in enumerate(registers):
+            if s % G == g:
+                t = steps.coefficients(polys[k], rows).contiguous()
+                if t.shape[0] < rows:                      # (an interpolant whose top coefficients vanish is still `rows` long on the wire)
+                    t = torch.cat([t, torch.zeros((rows - t.shape[0], 2), dtype=t.dtype, device=t.device)])
+            else:
+                t = torch.empty((rows, 2), dtype=torch.int64, device=self.device)
+            self._broadcast(t, s % G)
+            if s % G != g:
+                polys[k] = steps.polynomial(t, rows)
+        return polys
 
     def _shared_random_bytes(self, count):
         """`count` draws of os.urandom(17) in the reference's order (fast_stark.py:80, :117), made by rank 0 and broadcast: every
@@ -359,10 +390,14 @@ class ShardedFastStark(FastStark):
 
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)
-        # replicated: the trace polynomials through {omicron^i} (fast_stark.py:84-87)
+        # the trace polynomials through {omicron^i} (fast_stark.py:84-87): the registers are independent columns --
+        # register s is interpolated by rank s mod G and broadcast; every rank needs every polynomial's coefficients next (the
+        # boundary quotients and the AIR's point cut their own slabs out of them).  [Sharding ONE column's interpolation instead --
+        # its four transforms of twice the trace length through ShardedNtt -- is four corner turns per column for half a
+        # millisecond of arithmetic: DESIGN.md section 4.]
         steps = self.steps
-        trace_polynomials = steps.trace_polynomials(trace, trace_rows, registers, raw)
-        self._mark("trace interpolation (replicated)")
+        trace_polynomials = self._trace_polynomials_by_column(trace, trace_rows, registers, raw)
+        self._mark("trace interpolation (one register per rank, broadcast)")
         # sharded: boundary quotients, their LDEs and commitments (fast_stark.py:89-105)
         zerofiers_dev = [steps.lift(z) for z in zerofiers]
         boundary_quotients = [self._coset_divide(steps.subtract(trace_polynomials[s], interpolants[s]), zerofiers_dev[s], exact=True) for s in registers]

@@ -420,14 +420,15 @@ def stark_main():
         def zerofier(self, domain, root, order):
             return poly(po.fast_zerofier([d.value for d in domain], root.value, order))
 
-        def trace_polynomials(self, trace, rows, registers, raw):
+        def trace_polynomials(self, trace, rows, registers, raw, only=None):
             s = self.stark
             width = s.num_registers
             draws = [field.sample(raw[17 * i:17 * i + 17]) for i in range(len(raw) // 17)]
             trace = trace + [draws[r * width:(r + 1) * width] for r in range(s.num_randomizers)]
             assert len(trace) == rows
             domain = [pow(s.omicron.value, i, P) for i in range(rows)]
-            return [poly(po.fast_interpolate(domain, [row[r].value for row in trace], s.omicron.value, s.omicron_domain_length)) for r in registers]
+            return [poly(po.fast_interpolate(domain, [row[r].value for row in trace], s.omicron.value, s.omicron_domain_length)) if only is None or r in only else None
+                    for r in registers]
 
         def coset_divide(self, lhs, rhs, exact):
             if exact:
