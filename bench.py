@@ -976,7 +976,7 @@ def extras(sc, lib, stream=None):
     sc.synchronize()
     fr = Fri(field.generator(), om, N, 4, 40)
     best, runs = None, []
-    for _ in range(8):                   # every run is listed: the first pays allocations and tables, an occasional one a full
+    for _ in range(16):                  # every run is listed: the first pays allocations and tables, an occasional one a full
         cw = sc.DeviceCodeword(cwv, field)   # collection of this process's heap (torch, numpy) by CPython's collector
         ps = ProofStream()
         t0 = time.perf_counter()
@@ -985,9 +985,15 @@ def extras(sc, lib, stream=None):
         runs.append(round(dt * 1e3, 3))
         best = dt if best is None or dt < best else best
     t0 = time.perf_counter()
+    serialized = ps.serialize()          # (not part of Fri.prove in the reference either: fri.py:115-130 returns the indices; ip.py:18 serializes)
+    serialize_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
     verified = fr.verify(ps, [])        # outside the timed loop: the proof that was timed is a proof the verifier accepts
-    res["fri_prove_2p22_ef4_s40"] = {"ms": best * 1e3, "rounds": fr.num_rounds(), "proof_objects": len(ps.objects), "verify_accepts": bool(verified),
-                                     "verify_s": time.perf_counter() - t0, "runs_ms": runs}
+    res["fri_prove_2p22_ef4_s40"] = {"ms": best * 1e3, "median_ms": sorted(runs)[len(runs) // 2], "rounds": fr.num_rounds(), "proof_objects": len(ps.objects),
+                                     "verify_accepts": bool(verified), "verify_s": time.perf_counter() - t0, "runs_ms": runs,
+                                     "proof_bytes": len(serialized), "serialize_ms_outside_the_timed_call": serialize_ms,
+                                     "how": "one library call (sc_fri_prove_dev): commit phase with the rounds below 2^17 in one persistent launch (fri_tail_kernel), "
+                                            "transcript challenge, index sampling, one query kernel writing the openings to pinned host memory"}
     del cw, cwv, coeffs
     # configs[4] on ONE GPU: the polynomial-core call census of FastStark.prove replayed at
     # fri_domain_length 2^24, omicron_domain_length 2^22, 2 registers: 4 LDEs to 2^24, 2 coset divisions at 2^22,
