@@ -34,6 +34,14 @@
 //                            test the paths of a, b, c -- 4 s items; an element's key is key_base | index
 //   'O' u32 k  u32 field  u64 key_base  u32 depth  | u32 idx[k] | values 16 k | paths 64 depth k
 //                            leaf, path, leaf, path, ... of one committed codeword (fast_stark.py:154-175): 2 k items
+// and the same two with their payload left WHERE THE DEVICE WROTE IT (the pinned answer buffer of sc_fri_prove_dev): the op carries
+// addresses in this process, nothing is copied into the description
+//   'Q' u32 s  u32 field  u32 k  | k x (u64 key_base, u32 depth) | u64 elems  u64 paths  u64 positions
+//                            every round of a query phase over k codewords: codeword j's openings lie in the three arrays in
+//                            the order [a (s), b (s)] if j < k - 1, then [c (s)] if j > 0 (elements 16 bytes, paths 64 depth_j,
+//                            positions u64), codeword after codeword; 4 s (k - 1) items, as k - 1 'R' ops would produce
+//   'P' u32 k  u32 field  u64 key_base  u32 depth  u64 positions  u64 values  u64 paths
+//                            as 'O', positions u64
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -206,6 +214,27 @@ struct ProofPickler {
         if (++L.batch == 1000 || L.done == L.count) { put(0x65); L.batch = 0; }         // APPENDS
     }
     void save_path(const uint8_t* raw, uint32_t depth) {
+        // fifty thousand digests per proof: when no frame can end inside this path (a save() begins a new frame only at 64 KiB) and
+        // the list is one batch, its bytes are a fixed pattern -- EMPTY_LIST MEMOIZE [MARK] (SHORT_BINBYTES 64 <digest> MEMOIZE)*
+        // APPEND|APPENDS -- written in one go instead of four checked writes per digest
+        const size_t open_len = used - frame_start - FRAME_HEADER;
+        const size_t total = 2 + (depth >= 2 ? 1 : 0) + (size_t)depth * 67 + (depth ? 1 : 0);
+        if (depth <= 1000 && !bytes_at && open_len + total < FRAME_TARGET) {
+            room(total);
+            uint8_t* o = base + used;
+            *o++ = 0x5d; *o++ = 0x94;
+            if (depth >= 2) *o++ = 0x28;
+            for (uint32_t i = 0; i < depth; ++i) {
+                *o++ = 0x43; *o++ = 64;
+                memcpy(o, raw + (size_t)i * 64, 64);
+                o += 64;
+                *o++ = 0x94;
+            }
+            if (depth) *o++ = depth == 1 ? 0x61 : 0x65;
+            used += total;
+            memo_next += depth + 1;
+            return;
+        }
         boundary(); put(0x5d); memoize();                                              // EMPTY_LIST MEMOIZE
         ListCtx L{depth, 0, 0};
         for (uint32_t i = 0; i < depth; ++i) { item_begin(L); save_bytes(raw + (size_t)i * 64, 64); item_end(L); }
@@ -218,6 +247,61 @@ struct ProofPickler {
         const uint8_t op = *p++;
         auto u32 = [&](uint32_t* v) { if (end - p < 4) return false; memcpy(v, p, 4); p += 4; return true; };
         auto u64 = [&](uint64_t* v) { if (end - p < 8) return false; memcpy(v, p, 8); p += 8; return true; };
+        if (op == 'Q' || op == 'P') {                      // several items of the enclosing list, payload by address
+            if (!L) return nullptr;
+            uint32_t k, f;
+            if (!u32(&k) || !u32(&f) || f >= nfields) return nullptr;
+            if (op == 'P') {
+                uint64_t base, p_pos, p_val, p_path; uint32_t depth;
+                if (!u64(&base) || !u32(&depth) || !u64(&p_pos) || !u64(&p_val) || !u64(&p_path)) return nullptr;
+                if (L->done + 2ull * k > L->count || (k && (!p_pos || !p_val || (depth && !p_path)))) return nullptr;
+                const uint64_t* pos = (const uint64_t*)(uintptr_t)p_pos;
+                const uint8_t *val = (const uint8_t*)(uintptr_t)p_val, *path = (const uint8_t*)(uintptr_t)p_path;
+                for (uint32_t t = 0; t < k; ++t) {
+                    item_begin(*L); save_element(f, base | (uint32_t)pos[t], val + 16ull * t); item_end(*L);
+                    item_begin(*L); save_path(path + (size_t)t * 64 * depth, depth); item_end(*L);
+                }
+                return p;
+            }
+            // 'Q': k = s here, then the number of codewords
+            const uint32_t s_ = k;
+            uint32_t nk;
+            if (!u32(&nk) || nk < 2 || nk > 64 || (size_t)(end - p) < (size_t)nk * 12 + 24) return nullptr;
+            uint64_t base[64]; uint32_t depth[64];
+            for (uint32_t j = 0; j < nk; ++j) { memcpy(&base[j], p, 8); memcpy(&depth[j], p + 8, 4); p += 12; }
+            uint64_t p_el, p_path, p_pos;
+            if (!u64(&p_el) || !u64(&p_path) || !u64(&p_pos) || !p_el || !p_path || !p_pos) return nullptr;
+            if (L->done + 4ull * s_ * (nk - 1) > L->count) return nullptr;
+            const uint8_t *el = (const uint8_t*)(uintptr_t)p_el, *paths = (const uint8_t*)(uintptr_t)p_path;
+            const uint64_t* pos = (const uint64_t*)(uintptr_t)p_pos;
+            size_t eo[65], po[65];
+            eo[0] = po[0] = 0;
+            for (uint32_t j = 0; j < nk; ++j) {
+                const size_t cnt = (j + 1 < nk ? 2ull * s_ : 0) + (j > 0 ? s_ : 0);
+                eo[j + 1] = eo[j] + cnt;
+                po[j + 1] = po[j] + cnt * 64 * depth[j];
+            }
+            for (uint32_t i = 0; i + 1 < nk; ++i) {
+                const size_t c_at = i + 2 < nk ? 2ull * s_ : 0;
+                const size_t a0 = eo[i], b0 = eo[i] + s_, c0 = eo[i + 1] + c_at;
+                for (uint32_t t = 0; t < s_; ++t) {
+                    item_begin(*L);
+                    boundary();                                // save(tuple)
+                    save_element(f, base[i] | (uint32_t)pos[a0 + t], el + 16 * (a0 + t));
+                    save_element(f, base[i] | (uint32_t)pos[b0 + t], el + 16 * (b0 + t));
+                    save_element(f, base[i + 1] | (uint32_t)pos[c0 + t], el + 16 * (c0 + t));
+                    put(0x87); memoize();                      // TUPLE3 MEMOIZE
+                    item_end(*L);
+                }
+                const size_t dc = depth[i], dn = depth[i + 1];
+                for (uint32_t t = 0; t < s_; ++t) {
+                    item_begin(*L); save_path(paths + po[i] + (size_t)t * 64 * dc, (uint32_t)dc); item_end(*L);
+                    item_begin(*L); save_path(paths + po[i] + (size_t)(s_ + t) * 64 * dc, (uint32_t)dc); item_end(*L);
+                    item_begin(*L); save_path(paths + po[i + 1] + (c_at + t) * 64 * dn, (uint32_t)dn); item_end(*L);
+                }
+            }
+            return p;
+        }
         if (op == 'R' || op == 'O') {                      // several items of the enclosing list
             if (!L) return nullptr;
             uint32_t k, f;

@@ -364,8 +364,9 @@ class FastStark:
         if lazy is not None:
             # the device's answers as they are (proof_objects.Openings): same transcript bytes, no object per digest
             answers = together.answers if together is not None and together.answers is not None else _sc.query_codewords_raw(committed, [quadrupled_indices] * len(committed))
-            for codeword, (values, paths) in zip(committed, answers):
-                lazy.add(_po.Openings(codeword, quadrupled_indices, values, paths))
+            arrays = together.position_arrays if together is not None and together.answers is answers and together.position_arrays else [None] * len(committed)
+            for codeword, (values, paths), where in zip(committed, answers, arrays):
+                lazy.add(_po.Openings(codeword, quadrupled_indices, values, paths, where))
         elif all(isinstance(codeword, DeviceCodeword) for codeword in committed):
             # every codeword's openings in ONE device round trip; pushed leaf, path, leaf, path, ... codeword by codeword
             for entries, paths in query_codewords(committed, [quadrupled_indices] * len(committed)):

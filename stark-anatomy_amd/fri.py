@@ -30,6 +30,7 @@ class AlsoOpen:
     def __init__(self, requests, codewords=None, shift=None):
         self.requests, self.answers = requests, None
         self.codewords, self.shift = codewords, shift
+        self.position_arrays = None                        # per codeword: its opened positions as a uint64 array next to the answers
 
 
 def library_transcript(proof_stream, rounds):
@@ -273,12 +274,14 @@ class Fri:
             lazy.add(_po.FriQueryPhase(holders, s, counts[:rounds], depths[:rounds], data[:16 * own], data[el_bytes:el_bytes + own_paths], positions))
         if also_open is not None:
             vo, po, fetched = own, el_bytes + own_paths, []
+            where = data[el_bytes + path_bytes:el_bytes + path_bytes + 8 * total].view(np.uint64)
             for c, d in zip(counts[rounds:], depths[rounds:]):
                 fetched.append((data[16 * vo:16 * (vo + c)], data[po:po + 64 * c * d].reshape(c, 64 * d)))
                 vo += c
                 po += 64 * c * d
             also_open.answers = fetched
             also_open.positions = list(quad)
+            also_open.position_arrays = [where[own + 4 * s * e:own + 4 * s * (e + 1)] for e in range(ne)]      # the same, as the library wrote them
         return list(top)
 
     def _query_all(self, codewords, top_level_indices, proof_stream, also_open=None):

@@ -222,8 +222,22 @@ class FriQueryPhase:
                                              paths[i][:s], paths[i][s:2 * s], paths[i + 1][c_at:c_at + s]))
         return self._rounds
 
+    payload_bytes = property(lambda self: int(self.elems.nbytes + self.paths.nbytes))
+
     def ops(self, ctx):
-        return b"".join(r.ops(ctx) for r in self.rounds())
+        """the 'Q' op of csrc/proof_pickle.h: the three arrays stay where the device wrote them, the description carries their
+        addresses (this segment keeps them alive)"""
+        k = len(self.holders)
+        if k < 2 or self.s == 0:
+            return b""
+        f = ctx.field_index(self.holders[0].field)
+        if any(ctx.field_index(h.field) != f for h in self.holders):
+            raise _Unsupported("two fields in one query phase")
+        if not (self.elems.flags["C_CONTIGUOUS"] and self.paths.flags["C_CONTIGUOUS"] and self.positions.flags["C_CONTIGUOUS"]) or self.positions.dtype != np.uint64:
+            return b"".join(r.ops(ctx) for r in self.rounds())
+        head = _struct.pack("<cIII", b"Q", self.s, f, k)
+        per = b"".join(_struct.pack("<QI", _codeword_uid(h) << 32, d) for h, d in zip(self.holders, self.depths))
+        return head + per + _struct.pack("<QQQ", self.elems.ctypes.data, self.paths.ctypes.data, self.positions.ctypes.data)
 
     def materialize(self):
         return [obj for r in self.rounds() for obj in r.materialize()]
@@ -232,16 +246,27 @@ class FriQueryPhase:
 class Openings:
     """leaf, path, leaf, path, ... of one committed codeword (fast_stark.py:154-175)"""
 
-    def __init__(self, codeword, indices, values, paths):
-        self.cw, self.indices, self.values, self.paths = entries_of(codeword), indices, values, paths
+    def __init__(self, codeword, indices, values, paths, positions=None):
+        """positions (optional): the indices once more as a contiguous uint64 array -- with values and paths as contiguous arrays
+        too (the pinned answers of sc_fri_prove_dev) the description carries addresses instead of copies"""
+        self.cw, self.indices, self.values, self.paths, self.positions = entries_of(codeword), indices, values, paths, positions
         self.count = 2 * len(indices)
 
+    @property
+    def payload_bytes(self):
+        return 16 * len(self.indices) + int(getattr(self.paths, "nbytes", 0))
+
     def ops(self, ctx):
-        """the 'O' op of csrc/proof_pickle.h"""
+        """the 'O' op of csrc/proof_pickle.h ('P' -- payload by address -- when it lies in contiguous arrays)"""
         k = len(self.indices)
         if k == 0:
             return b""
         depth = self.paths.shape[1] // 64
+        pos, val = self.positions, self.values
+        if (isinstance(pos, np.ndarray) and pos.dtype == np.uint64 and pos.flags["C_CONTIGUOUS"] and len(pos) == k and isinstance(val, np.ndarray)
+                and val.dtype == np.uint8 and val.flags["C_CONTIGUOUS"] and val.nbytes == 16 * k and self.paths.flags["C_CONTIGUOUS"]):
+            return _struct.pack("<cIIQIQQQ", b"P", k, ctx.field_index(self.cw.field), _codeword_uid(self.cw) << 32, depth,
+                                pos.ctypes.data, val.ctypes.data, self.paths.ctypes.data if depth else 0)
         head = _struct.pack("<cIIQI", b"O", k, ctx.field_index(self.cw.field), _codeword_uid(self.cw) << 32, depth)
         return b"".join((head, np.asarray(self.indices, dtype=np.uint32).tobytes(), bytes(self.values), self.paths.tobytes()))
 
@@ -317,7 +342,9 @@ class LazyProofObjects:
             moduli = b"".join(f.p.to_bytes(32, "little") for f in ctx.fields)
         except (_Unsupported, OverflowError):
             return pickle.dumps(self.materialized())
-        return _sc.pickle_proof(ops, moduli, len(ctx.fields), 32)
+        # (segments whose payload stays where the device wrote it describe it by address: the output is that much longer than the ops)
+        by_address = sum(getattr(seg, "payload_bytes", 0) for seg in self._segments)
+        return _sc.pickle_proof(ops, moduli, len(ctx.fields), 32, expect=by_address)
 
     # -- the reader's side: the reference's objects, made once
     def _segment_objects(self, k):

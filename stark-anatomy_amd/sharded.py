@@ -1258,6 +1258,7 @@ class ShardedFri:
         top = self.fri._prove_in_library(codeword, proof_stream, inner)
         if top is not None and also_open is not None:
             also_open.answers = inner.answers
+            also_open.position_arrays = inner.position_arrays
         return top
 
     def _commit_tail(self, full, Nr, offset, omega, rounds_left, proof_stream):

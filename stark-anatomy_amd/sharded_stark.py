@@ -463,8 +463,9 @@ class ShardedFastStark(FastStark):
         if lazy is not None:
             # the owners' answers as they are (proof_objects.Openings): same transcript bytes, no object per digest
             answers = together.answers if together is not None and together.answers is not None else self.sfri._open_many_arrays([(layer, quadrupled_indices) for layer in layers])
-            for layer, (values, paths) in zip(layers, answers):
-                lazy.add(_po.Openings(self.sfri._holder(layer, field), quadrupled_indices, values, paths))
+            arrays = getattr(together, "position_arrays", None) if together is not None and together.answers is answers else None
+            for layer, (values, paths), where in zip(layers, answers, arrays or [None] * len(layers)):
+                lazy.add(_po.Openings(self.sfri._holder(layer, field), quadrupled_indices, values, paths, where))
             layers = []
         for entries, paths in self.sfri._open_many([(layer, quadrupled_indices) for layer in layers]) if layers else []:
             if type(proof_stream) is ProofStream:            # push == objects.append

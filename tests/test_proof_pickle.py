@@ -254,3 +254,26 @@ def test_query_phase_segment_from_the_one_call_provers_buffer(seed):
     assert got == pickle.dumps(list(per_round.objects))
     assert pickle.dumps(list(one.objects)) == got           # materialised from detached holders: the same sharing
     assert len(one.objects) == rounds + 1 + 4 * s * (rounds - 1)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_openings_described_by_address(seed):
+    """proof_objects.Openings with its payload left in contiguous arrays (values uint8 [16 k], paths uint8 [k][64 depth], positions
+    uint64 [k] -- the pinned answer buffer of sc_fri_prove_dev): the 'P' op of csrc/proof_pickle.h must write what the copying 'O' op
+    and CPython write, repeated positions (one object, a memo hit) included."""
+    rng = random.Random(300 + seed)
+    cw = FakeCodeword(1 << 9, MAIN, rng)
+    k, depth = rng.choice([1, 7, 160]), 9
+    opened = sorted(rng.choice(range(len(cw))) for _ in range(k))
+    values = np.frombuffer(cw.raw(opened), dtype=np.uint8).copy()
+    paths = np.frombuffer(rng.randbytes(64 * depth * k), dtype=np.uint8).reshape(k, 64 * depth).copy()
+
+    def stream(by_address):
+        ps = ProofStream()
+        ps.push(b"r" * 64)
+        lazy = po_.lazy_objects(ps)
+        lazy.add(po_.Openings(cw, opened, values if by_address else values.tobytes(), paths, np.asarray(opened, dtype=np.uint64) if by_address else None))
+        return ps
+    a, b = stream(True), stream(False)
+    assert b"P" in a.objects._segments[-1].ops(po_._Context())[:1] and b"O" in b.objects._segments[-1].ops(po_._Context())[:1]
+    assert a.serialize() == b.serialize() == pickle.dumps(list(b.objects))
