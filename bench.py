@@ -489,6 +489,7 @@ def main():
                          "traffic": measured_traffic(log2n) if not sharded else None, "kernel": "ntt_pass_kernel" if not sharded else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "valu_insts_per_launch": measured_valu(log2n) if not sharded else None,
+                         "pmc_collected_with_these_kernel_sources": pmc_figures_are_current(),
                          "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 and valu_insts (SQ_INSTS_VALU, wave-level) per launch from profiles/ (PMC passes); "
                                  "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor (13 of 17.5 us at 2^20), see DESIGN.md 3.1"},
         }
@@ -1183,6 +1184,33 @@ def measured_valu(log2n):
         except Exception:
             pass
     return best
+
+
+KERNEL_SOURCES = ("ntt_tile.cuh", "ntt_plan.h", "field.cuh", "field_asm.cuh")
+
+
+def kernel_source_digest():
+    """SHA-256 over the sources that define ntt_pass_kernel: tools/gpu_record.sh stores it next to the PMC figures it collects
+    (profiles/rNN/traffic.json), and a bench line says so when the figures it quotes predate a change to those files"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(REPO, "stark-anatomy_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_figures_are_current():
+    """True / False / None (no record): were the latest committed PMC figures collected with today's kernel sources?"""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None
+    try:
+        recorded = json.load(open(files[-1])).get("kernel_source_sha256_16")
+    except Exception:
+        return None
+    return None if recorded is None else recorded == kernel_source_digest()
 
 
 def measured_traffic(log2n):

@@ -237,23 +237,23 @@ def pickle_proof(ops, moduli, nfields, modulus_bytes, expect=0):
     """pickle.dumps of the object graph described by `ops` (csrc/proof_pickle.h; host only).  expect: bytes of payload the
     description refers to by address (they appear in the output, not in `ops`)"""
     import numpy as np
-    global _pickle_scratch
     need = ctypes.c_uint64()
     size = len(ops) + int(expect)
     cap = size + size // 8 + 4096
-    # one scratch buffer per process, grown when a proof needs more: fresh megabytes from the allocator are page faults on first
-    # touch (a 3 MB proof: more time than pickling it), a zeroed ctypes buffer a memset on top.  (Serialization runs under the GIL.)
-    if _pickle_scratch is None or _pickle_scratch.size < cap:
-        _pickle_scratch = np.empty(cap + cap // 4, dtype=np.uint8)
-    out = _pickle_scratch
+    # one scratch buffer per THREAD (the library call releases the GIL), grown when a proof needs more: fresh megabytes from the
+    # allocator are page faults on first touch (a 3 MB proof: more time than pickling it), a zeroed ctypes buffer a memset on top
+    out = getattr(_pickle_scratch, "buffer", None)
+    if out is None or out.size < cap:
+        out = _pickle_scratch.buffer = np.empty(cap + cap // 4, dtype=np.uint8)
     _check(lib().sc_pickle_proof(ops, len(ops), moduli, nfields, modulus_bytes, _vp(out.ctypes.data), out.size, ctypes.byref(need)))
     if need.value > out.size:
-        out = _pickle_scratch = np.empty(need.value + need.value // 4, dtype=np.uint8)
+        out = _pickle_scratch.buffer = np.empty(need.value + need.value // 4, dtype=np.uint8)
         _check(lib().sc_pickle_proof(ops, len(ops), moduli, nfields, modulus_bytes, _vp(out.ctypes.data), out.size, ctypes.byref(need)))
     return out[:need.value].tobytes()
 
 
-_pickle_scratch = None
+import threading as _threading
+_pickle_scratch = _threading.local()
 
 
 def fe_bytes(v):

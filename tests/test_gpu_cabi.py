@@ -4,6 +4,8 @@ through size-independent properties.  Integer work => bit-exact everywhere."""
 import ctypes
 import hashlib
 
+import numpy as np
+
 import pytest
 
 from conftest import load_golden
@@ -778,3 +780,139 @@ def test_pool_cap_and_trim(sc):
         assert free0 - torch.cuda.mem_get_info(0)[0] < 16 * n
     finally:
         sc.set_tuning("pool_cap_mb", 72 * 1024)
+
+
+@pytest.mark.parametrize("logN,s,prior_count", [(6, 2, 0), (10, 8, 3), (13, 40, 1), (18, 40, 2)])
+def test_fri_prove_in_one_call_through_the_cabi(sc, logN, s, prior_count):
+    """sc_fri_prove_dev (reference code/fri.py:115-130) called as a C caller would: the commit phase's roots against the oracle's
+    Merkle trees of the oracle's folds (alphas recomputed with hashlib from pickle.dumps of the roots so far, ip.py:18-25), the
+    top-level indices against blake2b (fri.py:36-51) over SHAKE-256 of the transcript with the last codeword pickled by CPython,
+    every opened element and authentication path against the oracle's codewords and trees, the positions against fri.py:98-113 --
+    with the answers in pinned memory of sc_host_alloc (written by the kernel itself) and in plain memory (two copies), with the
+    commit phase's device state handed out (trees and vectors then serve the same openings again) and kept by the library."""
+    import hashlib
+    import pickle
+    from hashlib import blake2b, shake_256
+    from algebra import Field, FieldElement
+    lib, field = sc.lib(), Field.main()
+    N = 1 << logN
+    om, g = field.primitive_nth_root(N), field.generator()
+    coeffs = packed(9100 + logN, N // 4)
+    cw0 = C.coset_evaluate(coeffs, N // 4, po.GENERATOR, om.value, N)
+    vec = sc.DeviceVector.from_bytes(cw0)
+    rounds, length = 0, N
+    while length > 4 and length > 4 * s:
+        rounds, length = rounds + 1, length // 2
+    n_last = N >> (rounds - 1)
+    prior = [bytes([i + 1]) * 64 for i in range(prior_count)]
+    # what the reference computes, with the oracle's arithmetic
+    codewords, roots, transcript, omega, offset = [cw0], [], list(prior), om.value, g.value
+    for r in range(rounds):
+        roots.append(C.merkle_commit(codewords[-1], N >> r))
+        transcript.append(roots[-1])
+        if r + 1 < rounds:
+            alpha = field.sample(shake_256(pickle.dumps(transcript)).digest(32))
+            codewords.append(C.fold(codewords[-1], N >> r, alpha.value, offset, omega))
+            omega, offset = omega * omega % po.P, offset * offset % po.P
+    last = [FieldElement(v, field) for v in synth.unpack_ints(codewords[-1])]
+    seed = shake_256(pickle.dumps(transcript + [last])).digest(32)
+    top, residues, counter = [], set(), 0
+    while len(top) < s:
+        i = int.from_bytes(blake2b(seed + bytes(counter)).digest(), "big") % (N // 2)
+        counter += 1
+        if i % n_last not in residues:
+            residues.add(i % n_last)
+            top.append(i)
+    positions, idx, prev = [], list(top), None
+    for j in range(rounds):
+        half, here = (N >> j) // 2, []
+        if j + 1 < rounds:
+            idx = [i % half for i in idx]
+            here += idx + [i + half for i in idx]
+        if j > 0:
+            here += prev
+        prev = idx
+        positions.append(here)
+    extra_shift = 4
+    quad = sorted(top + [(i + extra_shift) % N for i in top] + [(i + N // 2) % N for i in top] + [(i + extra_shift + N // 2) % N for i in top])
+    extra_data = packed(9200 + logN, N)
+    extra_vec = sc.DeviceVector.from_bytes(extra_data)
+    extra_tree = sc.MerkleTree.from_device(extra_vec)
+    counts = [len(p) for p in positions] + [4 * s]
+    depths = [(N >> j).bit_length() - 1 for j in range(rounds)] + [logN]
+    total = sum(counts)
+    el_bytes = (16 * total + 255) & ~255
+    path_bytes = sum(64 * c * d for c, d in zip(counts, depths))
+    nbytes = el_bytes + path_bytes + 8 * total
+
+    def call(answers_ptr, keep):
+        vecs = (ctypes.c_void_p * max(1, rounds - 1))()
+        trees = (ctypes.c_void_p * rounds)()
+        roots_out = ctypes.create_string_buffer(64 * rounds)
+        alphas = (ctypes.c_uint64 * max(2, 2 * (rounds - 1)))()
+        last_raw = ctypes.create_string_buffer(16 * n_last)
+        top_out = (ctypes.c_uint64 * s)()
+        quad_out = (ctypes.c_uint64 * (4 * s))()
+        sc._check(lib.sc_fri_prove_dev(vec.ptr, N, sc.fe_bytes(g.value), sc.fe_bytes(om.value), rounds, s, b"".join(prior), (ctypes.c_uint32 * max(1, prior_count))(*map(len, prior)), prior_count,
+                                       1, (ctypes.c_void_p * 1)(extra_tree._h), (ctypes.c_void_p * 1)(extra_vec.ptr), extra_shift,
+                                       vecs if keep else None, trees if keep else None, roots_out, alphas if keep else None, last_raw, top_out, quad_out, answers_ptr, nbytes, None))
+        assert [roots_out.raw[64 * r:64 * r + 64] for r in range(rounds)] == roots
+        assert last_raw.raw == codewords[-1] and list(top_out) == top and list(quad_out) == quad
+        return vecs, trees
+
+    def check(raw):
+        vo, po_ = 0, el_bytes
+        where = np.frombuffer(raw[el_bytes + path_bytes:el_bytes + path_bytes + 8 * total], dtype=np.uint64).tolist()
+        for j, (c, d) in enumerate(zip(counts, depths)):
+            data, n, want_pos = (codewords[j], N >> j, positions[j]) if j < rounds else (extra_data, N, quad)
+            assert where[vo:vo + c] == want_pos, j
+            for t, i in enumerate(want_pos):
+                assert raw[16 * (vo + t):16 * (vo + t + 1)] == data[16 * i:16 * i + 16], (j, t)
+            for t in ([0, c // 2, c - 1] if c else []):                 # three paths per codeword against the oracle's tree
+                got = raw[po_ + 64 * d * t:po_ + 64 * d * (t + 1)]
+                assert got == b"".join(C.merkle_open(data, n, want_pos[t])), (j, t)
+            vo += c
+            po_ += 64 * c * d
+    pinned = sc.HostBuffer(nbytes)
+    call(pinned.ptr, keep=False)
+    first = pinned.array.tobytes()
+    check(first)
+    plain = ctypes.create_string_buffer(nbytes)
+    vecs, trees = call(ctypes.cast(plain, ctypes.c_void_p), keep=True)
+    assert plain.raw[:el_bytes + path_bytes] == first[:el_bytes + path_bytes]                  # the staged form: the same answers
+    # the device state that was handed out: codeword r's vector and tree
+    for r in range(rounds):
+        tree = sc.MerkleTree(ctypes.c_void_p(trees[r]), roots[r], N >> r)
+        if r > 0:
+            folded = sc.DeviceVector.adopt(vecs[r - 1], N >> r)
+            assert folded.to_bytes() == codewords[r]
+        assert tree.open_batch([0])[0] == C.merkle_open(codewords[r], N >> r, 0) if (N >> r) > 1 else True
+    # a buffer that is too small, and one more colinearity test than the last codeword has entries
+    assert lib.sc_fri_prove_dev(vec.ptr, N, sc.fe_bytes(g.value), sc.fe_bytes(om.value), rounds, s, b"", (ctypes.c_uint32 * 1)(), 0, 0, None, None, 0,
+                                None, None, ctypes.create_string_buffer(64 * rounds), None, ctypes.create_string_buffer(16 * n_last), (ctypes.c_uint64 * s)(), None,
+                                pinned.ptr, 16, None) == -6
+    assert lib.sc_host_free(ctypes.cast(plain, ctypes.c_void_p)) == -6                          # not a buffer of sc_host_alloc
+
+
+def test_vec_wrap_is_a_view_of_the_callers_memory(sc):
+    """sc_vec_wrap: a vector handle over device memory the caller owns (a torch tensor's storage) -- the library reads and writes
+    it in place, sc_vec_free leaves the memory alone; and a library vector seen by torch through the CUDA array interface."""
+    import torch
+    n = 1 << 12
+    data = packed(9300, n)
+    t = torch.from_numpy(np.frombuffer(data, dtype=np.int64).reshape(n, 2).copy()).cuda()
+    v = sc.DeviceVector.wrap(t.data_ptr(), n, t)
+    assert v.to_bytes() == data
+    root = sc.MerkleTree.from_device(v).root
+    assert root == C.merkle_commit(data, n)
+    sc._check(sc.lib().sc_vec_zero(v._h))
+    sc.synchronize()
+    assert not t.any()                                        # written through the handle
+    v.free()
+    t.fill_(7)                                                # the memory is still the tensor's
+    torch.cuda.synchronize()
+    assert int(t[5, 1]) == 7
+    w = sc.DeviceVector.from_bytes(data)
+    view = torch.as_tensor(w, device="cuda")
+    assert tuple(view.shape) == (n, 2) and view.data_ptr() == int(w.ptr)
+    assert view.cpu().numpy().tobytes() == data
