@@ -343,6 +343,9 @@ int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]);
  * (fri.py:36-51) for a power-of-two `size`: `number` indices below size, pairwise distinct modulo reduced_size, candidate k = the
  * big-endian integer of blake2b(seed + k zero bytes) mod size (SC_ERR_UNSUPPORTED where the reference's assertion fails) */
 int sc_blake2b(const void* in, uint64_t len, uint8_t out[64]);
+/* SHAKE-256(pickle.dumps(items + [root])) (ip.py:18-25) in the split form the commit loops use: every whole rate block in front of
+ * the pending 64-byte root absorbed before the root is known, the rest after (csrc/transcript.h: PendingChallenge) */
+int sc_transcript_challenge(const void* data, const uint32_t* lens, uint64_t count, const uint8_t root[64], uint8_t* out, uint64_t out_len);
 int sc_fri_sample_indices(const void* seed, uint64_t seed_len, uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t* out);
 int sc_transcript_bytes(const void* data, const uint32_t* lens, uint64_t count, void* out, uint64_t out_cap, uint64_t* out_len);
 int sc_merkle_open(const sc_merkle_t* tree, uint64_t index, uint8_t* path_out /* 64*log2 N */); /* Merkle.open, merkle.py:16-27 */

@@ -369,6 +369,23 @@ int sc_field_sample(const void* bytes, uint64_t len, uint64_t out[2]) {
     out[0] = v.lo; out[1] = v.hi;
     return SC_OK;
 }
+// SHAKE-256(pickle.dumps(items + [root])) computed the way the commit loops compute it -- everything in front of the 64-byte `root`
+// absorbed first (PendingChallenge::prepare), the root dropped in afterwards (finish): the split form pinned to hashlib by
+// tests/test_host_cpu.py for every item count and alignment of the root inside a rate block
+int sc_transcript_challenge(const void* data, const uint32_t* lens, uint64_t count, const uint8_t root[64], uint8_t* out, uint64_t out_len) {
+    if ((!data && count) || (!lens && count) || !root || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    std::vector<uint8_t> items;
+    const uint8_t* p = (const uint8_t*)data;
+    for (uint64_t i = 0; i < count; ++i) {
+        if (lens[i] > 255) return fail(SC_ERR_UNSUPPORTED, "transcript item too long for the fixed layout");
+        transcript_item(items, p, lens[i]);
+        p += lens[i];
+    }
+    PendingChallenge pending;
+    if (!pending.prepare(items, (size_t)count + 1)) return fail(SC_ERR_UNSUPPORTED, "transcript too large for the fixed layout");
+    pending.finish(root, out, (size_t)out_len);
+    return SC_OK;
+}
 int sc_blake2b(const void* in, uint64_t len, uint8_t out[64]) {
     if ((!in && len) || !out) return fail(SC_ERR_BAD_ARG, "null argument");
     blake2b_512((const uint8_t*)in, (size_t)len, out);

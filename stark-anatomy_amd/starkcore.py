@@ -105,6 +105,7 @@ SIGNATURES = {
     "sc_pickle_proof": (_int, [_vp, _u64, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _u64, ctypes.POINTER(_u64)]),
     "sc_field_sample": (_int, [_vp, _u64, _vp]),
     "sc_blake2b": (_int, [_vp, _u64, _vp]),
+    "sc_transcript_challenge": (_int, [_vp, _vp, _u64, _vp, _vp, _u64]),
     "sc_fri_sample_indices": (_int, [_vp, _u64, _u64, _u64, ctypes.c_uint32, _vp]),
     "sc_transcript_bytes": (_int, [_vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_u64)]),
     "sc_merkle_open": (_int, [_vp, _u64, _vp]),

@@ -319,3 +319,28 @@ def test_library_index_sampling_matches_hashlib_and_the_reference_loop():
     got = (ctypes.c_uint64 * 9)()
     assert lib.sc_fri_sample_indices(b"s" * 32, 32, 1 << 10, 8, 9, got) == starkcore.SC_ERR_UNSUPPORTED
     assert lib.sc_fri_sample_indices(b"s" * 32, 32, 1000, 8, 4, got) == starkcore.SC_ERR_UNSUPPORTED
+
+
+def test_library_challenge_with_the_root_dropped_in_last():
+    """The commit loops hash the transcript in two steps (csrc/transcript.h: PendingChallenge): while the device computes a root,
+    every whole SHAKE-256 rate block in front of it is absorbed; when it arrives it is dropped into the prepared bytes and the
+    last block or two follow.  Same digest as hashlib over pickle.dumps (ip.py:18-25) for every number of prior items -- the
+    root's place inside a 136-byte block moves by 67 bytes per item, so 0 ... 40 items cover every alignment, a root that straddles
+    two blocks, the one-item layout (APPEND instead of MARK ... APPENDS) -- and for items of other lengths in front."""
+    import ctypes
+    import pickle
+    import random
+    from hashlib import shake_256
+    import starkcore
+    lib = starkcore.lib()
+    rng = random.Random(13)
+    shapes = [[64] * k for k in range(0, 41)] + [[0], [1, 255], [5, 64, 64, 17], [64] * 300]
+    for lens in shapes:
+        items = [rng.randbytes(n) for n in lens]
+        root = rng.randbytes(64)
+        for outlen in (32, 200):
+            out = ctypes.create_string_buffer(outlen)
+            assert lib.sc_transcript_challenge(b"".join(items), (ctypes.c_uint32 * max(1, len(items)))(*lens), len(items), root, out, outlen) == 0
+            assert out.raw == shake_256(pickle.dumps(items + [root])).digest(outlen), lens
+    out = ctypes.create_string_buffer(32)
+    assert lib.sc_transcript_challenge(b"x" * 256, (ctypes.c_uint32 * 1)(256), 1, bytes(64), out, 32) == starkcore.SC_ERR_UNSUPPORTED
