@@ -754,21 +754,32 @@ def test_urandom_prefetch_then_sample(sc):
 def test_pool_cap_and_trim(sc):
     """the free lists of the device-memory pool must be steerable -- a cap the caller sets, and a trim that hands the
     idle buffers back to the device (torch's allocator in the same process, or another rank on the same GPU, may need them)."""
-    import torch
     lib = sc.lib()
+    # the HIP runtime this process is bound to, without torch (the ASan runs cannot initialise torch.cuda): by symbol if it was
+    # loaded globally, else by the path it is mapped from
+    hip = ctypes.CDLL(None)
+    if not hasattr(hip, "hipMemGetInfo"):
+        with open("/proc/self/maps") as maps:
+            path = next(line.split()[-1] for line in maps if "libamdhip64" in line)
+        hip = ctypes.CDLL(path)
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
     n = 1 << 22                                   # 64 MB vectors
     sc.synchronize()
     sc.set_tuning("pool_trim", 1)
-    free0 = torch.cuda.mem_get_info(0)[0]
+    free0 = free_bytes()
     vs = [sc.DeviceVector(n) for _ in range(4)]
     for v in vs:
         v.free() if hasattr(v, "free") else None
     del vs
     sc.synchronize()
-    held = free0 - torch.cuda.mem_get_info(0)[0]
+    held = free0 - free_bytes()
     assert held >= 3 * 16 * n, held               # the freed vectors sit in the pool
     sc.set_tuning("pool_trim", 1)
-    assert free0 - torch.cuda.mem_get_info(0)[0] < 16 * n
+    assert free0 - free_bytes() < 16 * n
     sc.set_tuning("pool_cap_mb", 0)               # nothing is kept from now on
     try:
         v = sc.DeviceVector(n)
@@ -777,7 +788,7 @@ def test_pool_cap_and_trim(sc):
         w = sc.DeviceVector(16)                   # (an allocation reaps what was parked behind events)
         del w
         sc.set_tuning("pool_trim", 1)
-        assert free0 - torch.cuda.mem_get_info(0)[0] < 16 * n
+        assert free0 - free_bytes() < 16 * n
     finally:
         sc.set_tuning("pool_cap_mb", 72 * 1024)
 
