@@ -26,7 +26,8 @@ import torch.distributed as dist
 import fast_stark as _fs
 from fast_stark import *                      # noqa: F401,F403  (FastStark and the reference's star-imported names)
 from ntt import DevicePolynomial, DeviceDomain, _shrink_order, coset_divide_device, fast_interpolate_device, fast_zerofier_device
-from sharded import ShardedNtt, ShardedFri, _current_raw_stream
+from sharded import ShardedNtt, _current_raw_stream
+from sharded_fri import ShardedFri
 import starkcore as _sc
 
 
