@@ -200,6 +200,7 @@ int upload(void* d, const void* h, size_t bytes, hipStream_t st);
 int download(void* h, const void* d, size_t bytes, hipStream_t st);
 int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st);
 int gather_device(const Fe* v, const uint64_t* d_idx, uint64_t k, Fe* d_out, hipStream_t st);
+int read_small_polled(const void* d_src, size_t bytes, hipStream_t st, void* host_out);
 
 // ---- merkle_fri.hip
 int merkle_climb(uint64_t* levels, uint64_t N, int lvl, hipStream_t st, volatile uint64_t* host = nullptr, uint64_t seq = 0, bool* published = nullptr);

@@ -630,10 +630,54 @@ int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStrea
     unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(pointwise_div_kernel<K>, dim3(blocks), dim3(256), 0, st, a, b, out, n, (uint32_t*)fl);
     HIPCHK(hipGetLastError());
-    uint32_t hflag = 0;
-    HIPCHK(hipMemcpyAsync(&hflag, fl, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (hflag) return fail(SC_ERR_DIV_ZERO, "divide by zero");
+    uint64_t hflag = 0;
+    SCCHK(read_small_polled(fl, 8, st, &hflag));                  // (the flag is the low 32 bits of a word of the scratch buffer)
+    if ((uint32_t)hflag) return fail(SC_ERR_DIV_ZERO, "divide by zero");
+    return SC_OK;
+}
+
+// A few words of device memory to the host WITHOUT a copy engine and without putting the thread to sleep: a one-wave kernel behind
+// whatever produced them writes them to a pinned slot, then -- ordered behind them -- a sequence number the host polls (the scheme
+// the Merkle roots travel by).  A degree, an exactness flag, a divide-by-zero flag: a proof reads two dozen of them, and a
+// pageable hipMemcpyAsync + hipStreamSynchronize is 15-25 us each where this is 2-3.  Falls back to the copy when no slot is free.
+__global__ void __launch_bounds__(64) words_publish_kernel(const uint64_t* __restrict__ src, uint32_t nwords, volatile uint64_t* host, uint64_t seq) {
+    if (threadIdx.x < nwords) host[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) host[8] = seq;
+}
+int read_small_polled(const void* d_src, size_t bytes, hipStream_t st, void* host_out) {
+    const int slot = (bytes <= 64 && ((uintptr_t)d_src & 7) == 0) ? root_slot_get() : -1;
+    if (slot < 0) {
+        HIPCHK(hipMemcpyAsync(host_out, d_src, bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return SC_OK;
+    }
+    const uint64_t seq = ++g.root_seq;
+    volatile uint64_t* host = (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * slot);
+    hipLaunchKernelGGL(words_publish_kernel, dim3(1), dim3(64), 0, st, (const uint64_t*)d_src, (uint32_t)((bytes + 7) / 8), host, seq);
+    hipError_t e = hipGetLastError();
+    bool landed = false;
+    if (e == hipSuccess) {
+        for (long spin = 0; spin < SPIN_POLLS; ++spin) {
+            if (__atomic_load_n(host + 8, __ATOMIC_ACQUIRE) == seq) { landed = true; break; }
+            if ((spin & 4095) == 4095) {
+                e = hipStreamQuery(st);
+                if (e != hipErrorNotReady) break;              // finished (the number is there now) or failed
+                (void)hipGetLastError();
+                e = hipSuccess;
+            }
+        }
+        if (!landed) {
+            (void)hipGetLastError();
+            e = hipStreamSynchronize(st);
+            landed = e == hipSuccess && __atomic_load_n(host + 8, __ATOMIC_ACQUIRE) == seq;
+            if (e == hipSuccess && !landed) e = hipErrorUnknown;
+        }
+    }
+    if (landed) memcpy(host_out, (const void*)host, bytes);
+    else (void)hipStreamSynchronize(st);                       // nothing may still write to the slot when it is reused
+    g.free_root_slots.push_back(slot);
+    if (!landed) return fail(SC_ERR_HIP, hipGetErrorString(e));
     return SC_OK;
 }
 
@@ -1201,8 +1245,7 @@ int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t 
             hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const Fe*)full + n_out, cnt, (long long*)fl);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipMemcpyAsync(&deg, fl, sizeof deg, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
         *exact = deg < 0 ? 1 : 0;
     }
     return SC_OK;
@@ -1223,14 +1266,12 @@ int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* st
         hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((top + 255) / 256)), dim3(256), 0, st, (const Fe*)d_v + (n - top), top, (long long*)fl);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(&deg, fl, sizeof deg, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
     if (deg >= 0) deg += (long long)(n - top);
     else if (n > top) {
         hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((n - top + 255) / 256)), dim3(256), 0, st, (const Fe*)d_v, n - top, (long long*)fl);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&deg, fl, sizeof deg, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
     }
     *degree_out = (int64_t)deg;
     return SC_OK;

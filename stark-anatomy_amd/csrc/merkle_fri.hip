@@ -140,9 +140,8 @@ int merkle_build_device(const Fe* d_elems, uint64_t N, uint8_t root_out[64], sc_
         *tree = t;
         return SC_OK;
     }
-    e = hipMemcpyAsync(root_out, levels + 8 * (2 * N - 2), 64, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { pool_free(levels, tree_bytes); return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    // (the root of a synchronous build travels like the others: a pinned slot the host polls, not a copy and a sleeping wait)
+    if (read_small_polled(levels + 8 * (2 * N - 2), 64, st, root_out) != SC_OK) { pool_free(levels, tree_bytes); return SC_ERR_HIP; }
     if (tree) {
         sc_merkle* t = new sc_merkle{levels, N, ilog2(N)};
         memcpy(t->root, root_out, 64);

@@ -410,8 +410,7 @@ int geodomain_detect(const Fe* d_points, uint64_t n, Fe* first, Fe* ratio, bool*
     *is_geometric = false;
     if (n < 2) return SC_OK;
     Fe head[2];
-    HIPCHK(hipMemcpyAsync(head, d_points, 2 * sizeof(Fe), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    SCCHK(read_small_polled(d_points, 2 * sizeof(Fe), st, head));
     if (fe_is_zero(head[0]) || fe_is_zero(head[1]) || fe_ge_p(head[0]) || fe_ge_p(head[1])) return SC_OK;
     const Fe r_m = mont_mul(to_mont(head[1]), mont_inv(to_mont(head[0])));
     void* fl;
@@ -419,10 +418,9 @@ int geodomain_detect(const Fe* d_points, uint64_t n, Fe* first, Fe* ratio, bool*
     HIPCHK(hipMemsetAsync(fl, 0, 4, st));
     hipLaunchKernelGGL(geo_detect_kernel, dim3(pt_blocks(n)), dim3(256), 0, st, d_points, n, r_m, (uint32_t*)fl);
     HIPCHK(hipGetLastError());
-    uint32_t bad = 1;
-    HIPCHK(hipMemcpyAsync(&bad, fl, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (bad) return SC_OK;
+    uint64_t bad = 1;
+    SCCHK(read_small_polled(fl, 8, st, &bad));
+    if ((uint32_t)bad) return SC_OK;
     *first = head[0];
     *ratio = from_mont(r_m);
     *is_geometric = true;
