@@ -840,10 +840,30 @@ int sc_vec_zero(sc_vec_t* v) {
     if (v->n) HIPCHK(hipMemsetAsync(v->d, 0, v->n * sizeof(Fe), g.stream));
     return SC_OK;
 }
+// a few hundred bytes travel as a KERNEL ARGUMENT: the launch copies them, nothing is staged, nothing is waited for -- a pageable
+// hipMemcpyAsync has to be followed by a wait for the stream (the host buffer is the caller's), and in the middle of a proof that
+// wait is for everything the GPU still has queued (boundary zerofiers of three coefficients, 160 randomizer rows: 40 us each)
+struct SmallPayload { uint64_t w[256]; };
+__global__ void __launch_bounds__(256) small_upload_kernel(uint64_t* __restrict__ dst, const SmallPayload p, uint32_t nwords) {
+    if (threadIdx.x < nwords) dst[threadIdx.x] = p.w[threadIdx.x];
+}
 int sc_vec_upload(sc_vec_t* v, uint64_t offset, const void* host, uint64_t count) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!v || offset + count > v->n) return fail(SC_ERR_BAD_ARG, "upload out of range");
+    if (count && count * sizeof(Fe) <= 4 * sizeof(SmallPayload)) {
+        const uint8_t* src = (const uint8_t*)host;
+        uint64_t* dst = (uint64_t*)(v->d + offset);
+        for (size_t left = count * sizeof(Fe); left;) {
+            const size_t take = left < sizeof(SmallPayload) ? left : sizeof(SmallPayload);
+            SmallPayload p;
+            memcpy(p.w, src, take);
+            hipLaunchKernelGGL(small_upload_kernel, dim3(1), dim3(256), 0, g.stream, dst, p, (uint32_t)(take / 8));
+            src += take; dst += take / 8; left -= take;
+        }
+        HIPCHK(hipGetLastError());
+        return SC_OK;
+    }
     SCCHK(upload(v->d + offset, host, count * sizeof(Fe), g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return SC_OK;

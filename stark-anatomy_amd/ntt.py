@@ -300,8 +300,9 @@ class DevicePolynomial:
     def coset_evaluate(self, offset, generator, order):
         """fast_coset_evaluate (code/ntt.py:132-135) -> DeviceCodeword"""
         out = DeviceVector(order)
+        # (enqueued, not waited for: whatever reads the codeword next runs on the same stream, and vectors freed meanwhile are parked
+        # behind an event -- sc_vec_free never hands memory back while a stream may still use it)
         _sc._check(_sc.lib().sc_coset_evaluate_dev(self.vec.ptr, self.n, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out.ptr, None))
-        _sc.synchronize()
         return DeviceCodeword(out, self.field)
 
 
@@ -357,8 +358,7 @@ def fast_coset_evaluate_device(polynomial, offset, generator, order):
     out = DeviceVector(order)
     src = DeviceVector.from_bytes(_pack(coeffs)) if m else DeviceVector(1)
     _sc._check(_sc.lib().sc_coset_evaluate_dev(src.ptr, m, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out.ptr, None))
-    _sc.synchronize()
-    return DeviceCodeword(out, offset.field)
+    return DeviceCodeword(out, offset.field)          # (not waited for: `src` is parked behind an event when it is freed)
 
 
 def fast_coset_evaluate(polynomial, offset, generator, order):
