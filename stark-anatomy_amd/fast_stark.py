@@ -439,6 +439,7 @@ class FastStark:
                 if degree > bound - dr:
                     continue                                             # not exact: the reference's way decides what comes out
                 out[i] = DevicePolynomial(whole, field, degree + 1) if degree >= 0 else DevicePolynomial(DeviceVector(1), field, 0)
+                out[i]._degree = degree                                  # just read: the degree check of fast_stark.py:124 need not ask the device again
         return [q if q is not None else reference_way(a) for q, a in zip(out, constraints)]
 
     def _randomized_columns(self, trace, raw):

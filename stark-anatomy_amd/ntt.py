@@ -253,7 +253,9 @@ class DevicePolynomial:
         coeffs = polynomial.coefficients
         field = field if field is not None else coeffs[0].field
         _require_main_field(field)
-        return cls(DeviceVector.from_bytes(_pack(coeffs)) if coeffs else DeviceVector(1), field, len(coeffs))
+        out = cls(DeviceVector.from_bytes(_pack(coeffs)) if coeffs else DeviceVector(1), field, len(coeffs))
+        out._degree = polynomial.degree()                  # known on the host: no round trip to the device for it later
+        return out
 
     @classmethod
     def from_codeword(cls, codeword):
@@ -295,7 +297,10 @@ class DevicePolynomial:
         out = DeviceVector(max(self.n, 1))
         if self.n:
             _sc._check(_sc.lib().sc_scale_dev(self.vec.ptr, out.ptr, self.n, _sc.fe_bytes(factor.value), None))
-        return DevicePolynomial(out, self.field, self.n)
+        scaled = DevicePolynomial(out, self.field, self.n)
+        if factor.value % self.field.p != 0:
+            scaled._degree = self._degree                  # coefficient i times factor^i: the same coefficients vanish (None stays None)
+        return scaled
 
     def coset_evaluate(self, offset, generator, order):
         """fast_coset_evaluate (code/ntt.py:132-135) -> DeviceCodeword"""
@@ -329,9 +334,11 @@ def coset_divide_device(lhs, rhs, offset, primitive_root, root_order, exact=Fals
     flag = ctypes.c_int(0)
     _sc._check(_sc.lib().sc_coset_divide_dev(lhs.vec.ptr, dl + 1, rhs.vec.ptr, dr + 1, _sc.fe_bytes(offset.value), _sc.fe_bytes(root.value), order,
                                              out.ptr, n_out, ctypes.byref(flag) if exact else None, None))
+    quotient = DevicePolynomial(out, field, n_out)
     if exact:
         assert(flag.value == 1), "cannot perform polynomial division because remainder is not zero"
-    return DevicePolynomial(out, field, n_out)
+        quotient._degree = dl - dr                         # an exact quotient's leading coefficient is lhs's over rhs's: not zero
+    return quotient
 
 
 def fast_zerofier_device(domain):
