@@ -847,23 +847,26 @@ struct SmallPayload { uint64_t w[256]; };
 __global__ void __launch_bounds__(256) small_upload_kernel(uint64_t* __restrict__ dst, const SmallPayload p, uint32_t nwords) {
     if (threadIdx.x < nwords) dst[threadIdx.x] = p.w[threadIdx.x];
 }
+// `bytes` (any number, at most 4 payloads) from host memory to 8-byte aligned device memory with room for the last word, as kernel arguments
+static bool upload_small(void* d_dst, const void* host, size_t bytes, hipStream_t st) {
+    if (bytes > 4 * sizeof(SmallPayload)) return false;
+    const uint8_t* src = (const uint8_t*)host;
+    uint64_t* dst = (uint64_t*)d_dst;
+    for (size_t left = bytes; left;) {
+        const size_t take = left < sizeof(SmallPayload) ? left : sizeof(SmallPayload);
+        SmallPayload p;
+        p.w[(take - 1) / 8] = 0;
+        memcpy(p.w, src, take);
+        hipLaunchKernelGGL(small_upload_kernel, dim3(1), dim3(256), 0, st, dst, p, (uint32_t)((take + 7) / 8));
+        src += take; dst += (take + 7) / 8; left -= take;
+    }
+    return hipGetLastError() == hipSuccess;
+}
 int sc_vec_upload(sc_vec_t* v, uint64_t offset, const void* host, uint64_t count) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     if (!v || offset + count > v->n) return fail(SC_ERR_BAD_ARG, "upload out of range");
-    if (count && count * sizeof(Fe) <= 4 * sizeof(SmallPayload)) {
-        const uint8_t* src = (const uint8_t*)host;
-        uint64_t* dst = (uint64_t*)(v->d + offset);
-        for (size_t left = count * sizeof(Fe); left;) {
-            const size_t take = left < sizeof(SmallPayload) ? left : sizeof(SmallPayload);
-            SmallPayload p;
-            memcpy(p.w, src, take);
-            hipLaunchKernelGGL(small_upload_kernel, dim3(1), dim3(256), 0, g.stream, dst, p, (uint32_t)(take / 8));
-            src += take; dst += take / 8; left -= take;
-        }
-        HIPCHK(hipGetLastError());
-        return SC_OK;
-    }
+    if (count && upload_small(v->d + offset, host, count * sizeof(Fe), g.stream)) return SC_OK;
     SCCHK(upload(v->d + offset, host, count * sizeof(Fe), g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return SC_OK;
@@ -1317,13 +1320,19 @@ int sc_mpoly_eval_ex_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t
     const size_t cbytes = (cm.size() * sizeof(Fe) + 255) & ~255ull;
     void* buf;
     SCCHK(scratch(4, cbytes + nterms * nvars + 256, &buf));
-    SCCHK(upload(buf, cm.data(), cm.size() * sizeof(Fe), st));
-    if (nterms) SCCHK(upload((char*)buf + cbytes, exps, nterms * nvars, st));
+    // (a handful of terms: coefficients and exponents go in as kernel arguments and nothing has to be waited for afterwards)
+    const bool small = upload_small(buf, cm.data(), cm.size() * sizeof(Fe), st) && (!nterms || upload_small((char*)buf + cbytes, exps, nterms * nvars, st));
+    if (!small) {
+        SCCHK(upload(buf, cm.data(), cm.size() * sizeof(Fe), st));
+        if (nterms) SCCHK(upload((char*)buf + cbytes, exps, nterms * nvars, st));
+    }
     if (!vals_converted) hipLaunchKernelGGL(to_mont_kernel, dim3((unsigned)((nvars * n + 255) / 256)), dim3(256), 0, st, (Fe*)d_vals, nvars * n);
     hipLaunchKernelGGL(mpoly_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fe*)d_vals, (uint32_t)nvars, n,
                        (const uint8_t*)((char*)buf + cbytes), (const Fe*)buf, (uint32_t)nterms, (Fe*)d_out);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));       // cm / exps are host temporaries of this call
+    // (not waited for on the library's own stream: the scratch tables' next writer is ordered behind this kernel there; a caller's
+    // stream shares the scratch buffer with other streams, so the call still ends with the kernel done)
+    if (!small || st != g.stream) HIPCHK(hipStreamSynchronize(st));       // cm / exps may be host temporaries of this call
     return SC_OK;
 }
 

@@ -890,7 +890,9 @@ def test_fri_prove_in_one_call_through_the_cabi(sc, logN, s, prior_count):
     check(first)
     plain = ctypes.create_string_buffer(nbytes)
     vecs, trees = call(ctypes.cast(plain, ctypes.c_void_p), keep=True)
-    assert plain.raw[:el_bytes + path_bytes] == first[:el_bytes + path_bytes]                  # the staged form: the same answers
+    # the staged form: the same answers (the bytes between the elements and the 256-byte boundary the paths start at are nobody's)
+    assert plain.raw[:16 * total] == first[:16 * total] and plain.raw[el_bytes:el_bytes + path_bytes] == first[el_bytes:el_bytes + path_bytes]
+    check(plain.raw)
     # the device state that was handed out: codeword r's vector and tree
     for r in range(rounds):
         tree = sc.MerkleTree(ctypes.c_void_p(trees[r]), roots[r], N >> r)
