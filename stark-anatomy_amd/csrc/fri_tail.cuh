@@ -13,8 +13,10 @@
 //                       microsecond later), then it waits for the next challenge in a pinned host word and hands it to the others.
 //
 // The Fiat-Shamir step itself -- SHAKE-256 over pickle.dumps(transcript), ip.py:18-25 -- stays with the host thread that is polling
-// the root slot anyway (csrc/transcript.h): root out and challenge back are two posted bus writes and ~3 us of hashing, less than a
-// wave of 25 lanes needs for the two Keccak permutations, and no launch separates the rounds any more.  Nothing spins for ever:
+// the root slot anyway (csrc/transcript.h): root out and challenge back cost 4.8 us per round, 0.5-0.8 us of it hashing (the blocks in
+// front of the pending root are absorbed while the device works), where ONE Keccak-f[1600] permutation takes a lone wave 7.3 us on
+// 25 lanes and 8.9 us in one lane (tools/microbench/keccak_wave.hip, profiles/r05/keccak_wave_ubench.txt) -- and no launch separates
+// the rounds any more.  Nothing spins for ever:
 // every wait gives up after TAIL_SPIN_LIMIT polls and raises the abort flag, and the host then finishes the rounds the classic way.
 #pragma once
 #include "merkle.cuh"
