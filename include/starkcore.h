@@ -60,8 +60,9 @@ int sc_stream(void** stream_out);
 int sc_stream_join(void* other_stream);
 /* tuning knobs for experiments (defaults are the measured optimum; -1 = choose by size where applicable): key in
  * {"max_tile_log","loge","max_col_log","min_tiles_log","single_pass_max_log","max_digit_log","direct_tw_max_log",
- *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune","fri_tail"}.  Plans are re-derived on the next
- * call; results never depend on the tuning.  Two keys manage the device-memory pool instead (freed vectors and trees are kept
+ *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune","fri_tail","fri_tail_stall"}.  Plans are re-derived on the next
+ * call; results never depend on the tuning ("fri_tail_stall" = k >= 0 is a test hook: the host withholds the challenge after round k of
+ * the persistent tail kernel, whose wait then gives up after 2^13 polls; -1 = off).  Two keys manage the device-memory pool instead (freed vectors and trees are kept
  * on exact-size free lists, by default up to a quarter of the device's memory divided by the processes sharing the device;
  * environment STARKCORE_POOL_CAP_MB): "pool_cap_mb" = what the lists may keep from now on, "pool_trim" = hand everything on them
  * back to the device now (a caller whose own allocator -- torch's -- ran out of memory). */
@@ -315,6 +316,9 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
                      void* answers, uint64_t answers_bytes, void* stream);
 /* pinned, device-visible host memory from a pool kept by the library (an allocation of megabytes costs hundreds of microseconds):
  * what sc_fri_prove_dev's query kernel writes a proof's openings to */
+/* diagnostics of the persistent tail kernel of the commit phase (csrc/fri_tail.cuh): out[0] = launches so far, out[1] = launches
+ * whose wait for a challenge or a peer workgroup gave up, after which the rounds were finished with the per-round launches */
+int sc_fri_tail_stats(uint64_t out[2]);
 int sc_host_alloc(uint64_t bytes, void** out);
 int sc_host_free(void* p);
 /* the host-side pieces of that step on their own (no GPU needed; tests pin them to hashlib / pickle):

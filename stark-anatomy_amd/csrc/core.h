@@ -121,6 +121,7 @@ struct Ctx {
     unsigned long long* trace = nullptr;   // diagnostics: phase stamps of the next fixed-shape pass launches (sc_debug_trace)
     int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)
     int fri_tail = -1;       // the persistent tail kernel of Fri.commit (csrc/fri_tail.cuh): -1 = environment STARKCORE_FRI_TAIL (default on), 0 / 1
+    int fri_tail_stall = -1; // tests: the host withholds the challenge of this round of the tail kernel (its wait then times out: the abort path)
     uint8_t* root_slots = nullptr;        // pinned host memory: roots of asynchronously built Merkle trees in flight
     uint64_t root_seq = 0;
     std::vector<int> free_root_slots;

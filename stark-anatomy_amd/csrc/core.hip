@@ -785,6 +785,7 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "prune") g.tuning.prune = value;
     else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "fri_tail") g.fri_tail = value ? 1 : 0;
+    else if (k == "fri_tail_stall") g.fri_tail_stall = value;                               // tests only: see core.h
     else if (k == "pool_cap_mb") g_pool_cap = (size_t)(value < 0 ? 0 : value) << 20;       // what the free lists may keep from now on
     else if (k == "pool_trim") {                                                            // give everything in the free lists back to the device now
         if (g.init) { (void)hipDeviceSynchronize(); reap_pending(true); pool_clear(); }

@@ -62,6 +62,7 @@ struct TailParams {
     TailHost* host;
     uint64_t seq;
     int trace;            // workgroup 0 stamps its phases into host->stamps
+    uint32_t spin_limit;  // polls before a wait gives up (TAIL_SPIN_LIMIT; tests shorten it)
 };
 
 #if defined(__HIPCC__)
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(256) fri_tail_kernel(const TailParams P) {
                     uint32_t spins = 0;
                     while (__hip_atomic_load(&ctl->arrive[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > TAIL_SPIN_LIMIT || __hip_atomic_load(&ctl->abort[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; break; }
+                        if (++spins > P.spin_limit || __hip_atomic_load(&ctl->abort[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; break; }
                     }
                     __hip_atomic_store(&ctl->arrive[r][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // left zero for the next call
                 }
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256) fri_tail_kernel(const TailParams P) {
                         uint32_t spins = 0;
                         while (P.host->alpha[r + 1][2] != P.seq) {
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > TAIL_SPIN_LIMIT) { s_abort = 1; break; }
+                            if (++spins > P.spin_limit) { s_abort = 1; break; }
                         }
                         if (!s_abort) {
                             const Fe a{P.host->alpha[r + 1][0], P.host->alpha[r + 1][1]};
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(256) fri_tail_kernel(const TailParams P) {
                 uint32_t spins = 0;
                 while (ld_agent(&ctl->alpha[r + 1][2]) != P.seq) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > TAIL_SPIN_LIMIT || __hip_atomic_load(&ctl->abort[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; break; }
+                    if (++spins > P.spin_limit || __hip_atomic_load(&ctl->abort[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; break; }
                 }
                 if (!s_abort) s_alpha = Fe{ld_agent(&ctl->alpha[r + 1][0]), ld_agent(&ctl->alpha[r + 1][1])};
             }

@@ -440,6 +440,7 @@ namespace {
 std::vector<TailCtl*> g_tail_ctl_free;
 std::vector<TailHost*> g_tail_host_free;
 uint64_t g_tail_seq = 0;
+uint64_t g_tail_launches = 0, g_tail_fallbacks = 0;     // sc_fri_tail_stats
 int tail_blocks_get(TailCtl** c, TailHost** h) {
     if (g_tail_ctl_free.empty()) {
         TailCtl* d = nullptr;
@@ -458,6 +459,7 @@ int tail_blocks_get(TailCtl** c, TailHost** h) {
     return SC_OK;
 }
 constexpr int TAIL_NOT_TAKEN = 1;
+constexpr int TAIL_GAVE_UP = 2;           // a launch whose wait timed out: the caller finishes this commit without trying the kernel again
 }  // namespace
 
 // Codewords `first` .. rounds - 1 of the commit phase (trees, roots, the folds between them) by fri_tail_kernel; `cur` = codeword
@@ -465,7 +467,7 @@ constexpr int TAIL_NOT_TAKEN = 1;
 // (into vecs_out[first - 1], allocated by the caller).  The host thread stays in the loop for the Fiat-Shamir step only: per round
 // it polls the root's pinned slot, hashes the transcript and writes the next challenge to the pinned word the kernel polls.
 // SC_OK: trees_out / vecs_out / roots_out / alphas_out filled to the end (and *last_there set when `last_host` got the last codeword);
-// TAIL_NOT_TAKEN: the shape is not the kernel's, or a wait inside it timed out -- nothing the caller holds has changed.
+// TAIL_NOT_TAKEN: the shape is not the kernel's; TAIL_GAVE_UP: a wait inside it timed out -- either way nothing the caller holds has changed.
 static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint64_t n, Fe alpha0, Fe off, Fe om, uint32_t first, uint32_t rounds,
                            std::vector<uint8_t>& items, uint64_t prior_count, sc_vec_t** vecs_out, sc_merkle_t** trees_out, uint8_t* roots_out,
                            uint64_t* alphas_out, hipStream_t st, Fe* last_host, bool* last_there, const std::function<void()>* on_last) {
@@ -485,6 +487,7 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
     P.ctl = ctl; P.host = host; P.seq = ++g_tail_seq;
     static const bool tracing = getenv("STARKCORE_FRI_TIMING") != nullptr;
     P.trace = tracing ? 1 : 0;
+    P.spin_limit = g.fri_tail_stall >= 0 ? (1u << 13) : TAIL_SPIN_LIMIT;
     std::vector<double> host_us;                           // tracing: when each root was seen and each challenge written (host clock)
     const auto t_launch = std::chrono::steady_clock::now();
     auto host_stamp = [&] { if (tracing) host_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count()); };
@@ -519,6 +522,7 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
     for (uint32_t k = 0; k < R; ++k) nwg = std::max(nwg, tail_workgroups(P.log_n0 - k));
     hipLaunchKernelGGL(fri_tail_kernel, dim3(nwg), dim3(256), 0, st, P);
     if (hipGetLastError() != hipSuccess) { give_back(true); return TAIL_NOT_TAKEN; }
+    ++g_tail_launches;
     bool aborted = false;
     for (uint32_t k = 0; k < R && !aborted; ++k) {
         volatile uint64_t* slot = host->root[k];
@@ -562,6 +566,7 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
         transcript_item(items, roots_out + 64 * r, 64);
         const Fe alpha = sample_field(digest, 32);
         alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
+        if (g.fri_tail_stall == (int)k) { aborted = true; break; }      // tests: the challenge never comes; the kernel's wait gives up
         host->alpha[k + 1][0] = alpha.lo;
         host->alpha[k + 1][1] = alpha.hi;
         __atomic_store_n(&host->alpha[k + 1][2], P.seq, __ATOMIC_RELEASE);
@@ -571,7 +576,8 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
         (void)hipStreamSynchronize(st);                        // (a kernel still waiting for a challenge that will not come times out)
         (void)hipGetLastError();
         give_back(false);
-        return TAIL_NOT_TAKEN;
+        ++g_tail_fallbacks;
+        return TAIL_GAVE_UP;
     }
     if (tracing) {
         // device stamps are a 100 MHz counter: 10 ns each
@@ -621,6 +627,7 @@ static int fri_commit_locked(std::unique_lock<std::mutex>& lk, const void* d_cod
     const Fe* cur = (const Fe*)d_codeword;
     uint64_t n = N;
     uint32_t made_trees = 0, made_vecs = 0;
+    bool tail_gave_up = false;
     auto undo = [&](int rc) {
         (void)hipStreamSynchronize(st);
         for (uint32_t i = 0; i < made_trees; ++i) { sc_merkle* t = trees_out[i]; if (t->slot >= 0) (void)merkle_root_wait(t, true); pool_free(t->d_levels, (2 * t->N - 1) * 64); delete t; trees_out[i] = nullptr; }
@@ -653,11 +660,12 @@ static int fri_commit_locked(std::unique_lock<std::mutex>& lk, const void* d_cod
         transcript_item(items, trees_out[r]->root, 64);
         const Fe alpha = sample_field(digest, 32);
         alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
-        if (n / 2 <= (1ull << TAIL_MAX_LOG)) {
+        if (!tail_gave_up && n / 2 <= (1ull << TAIL_MAX_LOG)) {
             // from here on every round is latency: the rest of the commit phase is one persistent launch (csrc/fri_tail.cuh)
             rc = fri_tail_rounds(lk, cur, n, alpha, off, om, r + 1, rounds, items, prior_count, vecs_out, trees_out, roots_out, alphas_out, st, last_host, last_there, on_last);
             if (rc == SC_OK) return SC_OK;
-            if (rc != TAIL_NOT_TAKEN) return undo(rc);
+            if (rc == TAIL_GAVE_UP) tail_gave_up = true;
+            else if (rc != TAIL_NOT_TAKEN) return undo(rc);
         }
         rc = fold_and_build(cur, n, alpha, off, om, nxt->d, &trees_out[r + 1], st);
         if (rc != SC_OK) return undo(rc);
@@ -686,6 +694,13 @@ uint64_t* g_query_flag = nullptr;                       // pinned word the last 
 uint64_t g_query_seq = 0;
 size_t host_pool_size(size_t bytes) { size_t b = 4096; while (b < bytes) b <<= 1; return b; }
 }  // namespace
+int sc_fri_tail_stats(uint64_t out[2]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!out) return fail(SC_ERR_BAD_ARG, "null argument");
+    out[0] = g_tail_launches;
+    out[1] = g_tail_fallbacks;
+    return SC_OK;
+}
 int sc_host_alloc(uint64_t bytes, void** out) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());

@@ -99,6 +99,7 @@ SIGNATURES = {
     "sc_fri_commit_dev": (_int, [_vp, _u64, _vp, _vp, ctypes.c_uint32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "sc_fri_prove_dev": (_int, [_vp, _u64, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _u64, _vp]),
+    "sc_fri_tail_stats": (_int, [_vp]),
     "sc_host_alloc": (_int, [_u64, _vp]),
     "sc_host_free": (_int, [_vp]),
     "sc_shake256": (_int, [_vp, _u64, _vp, _u64]),

@@ -346,6 +346,42 @@ def test_fri_commit_persistent_tail_kernel_equals_the_per_round_launches():
             assert objects[1] == po.C.merkle_commit(cw1, N // 2), logN
 
 
+def test_fri_tail_kernel_whose_challenge_never_comes_gives_up_and_the_rounds_finish_the_classic_way():
+    """Nothing in csrc/fri_tail.cuh may spin for ever: a wait that is not answered gives up, raises the abort flag, every workgroup
+    leaves, and the host finishes the commit phase with the per-round launches -- the same proof.  sc_set_tuning("fri_tail_stall", k)
+    makes the host withhold the challenge after the tail kernel's k-th root (and shortens the kernel's patience to milliseconds)."""
+    import starkcore as sc
+    rec = [r for r in load_golden("fri.json")["prove_synth"] if r["logN"] == 12][0]
+    N = 1 << rec["logN"]
+    om = field.primitive_nth_root(N)
+    poly = Polynomial([FieldElement(v, field) for v in synth.synth_ints(rec["coeff_seed"], N // 4)])
+    fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+
+    def prove():
+        ps = ProofStream()
+        top = fr.prove(fast_coset_evaluate_device(poly, field.generator(), om, N), ps)
+        return top, hashlib.sha256(ps.serialize()).hexdigest()
+    import ctypes
+
+    def stats():
+        out = (ctypes.c_uint64 * 2)()
+        sc._check(sc.lib().sc_fri_tail_stats(out))
+        return out[0], out[1]
+    want = (rec["top_level_indices"], rec["serialized_sha256"])
+    launches, fallbacks = stats()
+    assert prove() == want and stats() == (launches + 1, fallbacks)
+    try:
+        for k in (0, 2):
+            sc.set_tuning("fri_tail_stall", k)
+            before = stats()
+            assert prove() == want, k
+            assert stats() == (before[0] + 1, before[1] + 1), k     # the kernel was launched, gave up, and the classic rounds finished the proof
+    finally:
+        sc.set_tuning("fri_tail_stall", -1)
+    before = stats()
+    assert prove() == want and stats() == (before[0] + 1, before[1])   # ... and the next proof takes the persistent kernel again
+
+
 def test_fri_commit_with_a_proof_stream_subclass_and_a_long_transcript(monkeypatch):
     """(1) a ProofStream SUBCLASS that derives its challenges differently (the reference's SignatureProofStream prefixes
     the document, code/rpsss.py) must never take the library's commit loop, which hashes pickle(objects) itself -- prover and
