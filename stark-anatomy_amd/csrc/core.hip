@@ -139,11 +139,32 @@ __global__ void __launch_bounds__(256) axpy_shift_kernel(Fe* __restrict__ acc, c
 // out[0] = max index of a non-zero element, or -1 (Polynomial.degree, code/univariate.py:7-17, on a coefficient vector in HBM)
 // (one atomic per WAVE that holds a non-zero element, on the wave's highest such index: a dense vector used to issue one
 // contended atomic per element -- 129 us per call at 2^21 coefficients, 9 % of the GPU time of a 2^24 proof)
+// A grid of at most 2048 workgroups strides over the vector, four rows of 256 elements per step (every load a coalesced 16-byte-per-
+// lane stream, four in flight per thread): the scan of the 12.6 M coefficients that must vanish after an exact division on a 2^24
+// domain ran at 1.06 TB/s with one element per thread and one workgroup per 256 elements.
+constexpr int DEGREE_PER_THREAD = 4;
+constexpr unsigned DEGREE_MAX_BLOCKS = 2048;
 __global__ void __launch_bounds__(256) vec_degree_kernel(const Fe* __restrict__ v, uint64_t n, long long* out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool nz = i < n && !fe_is_zero(v[i]);
-    const unsigned long long lanes = __ballot(nz);
-    if (lanes && (threadIdx.x & 63u) == 0) atomicMax(out, (long long)(i + (63 - __clzll((long long)lanes))));
+    const uint64_t step = (uint64_t)gridDim.x * (256 * DEGREE_PER_THREAD);
+    long long best = -1;                               // (wave-uniform) the highest non-zero index this wave has seen
+    for (uint64_t base = (uint64_t)blockIdx.x * (256 * DEGREE_PER_THREAD) + threadIdx.x; base - threadIdx.x < n; base += step) {
+        Fe x[DEGREE_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < DEGREE_PER_THREAD; ++k) {
+            const uint64_t i = base + 256u * k;
+            x[k] = i < n ? v[i] : Fe{0, 0};
+        }
+#pragma unroll
+        for (int k = 0; k < DEGREE_PER_THREAD; ++k) {
+            const unsigned long long lanes = __ballot(!fe_is_zero(x[k]));
+            if (lanes) best = (long long)(base - (threadIdx.x & 63u) + 256u * k + (63 - __clzll((long long)lanes)));      // (later rows and steps are higher)
+        }
+    }
+    if (best >= 0 && (threadIdx.x & 63u) == 0) atomicMax(out, best);
+}
+static inline unsigned degree_blocks(uint64_t n) {
+    const uint64_t b = (n + 256 * DEGREE_PER_THREAD - 1) / (256 * DEGREE_PER_THREAD);
+    return (unsigned)(b < DEGREE_MAX_BLOCKS ? (b ? b : 1) : DEGREE_MAX_BLOCKS);
 }
 
 // MPolynomial.evaluate_symbolic (code/multivariate.py:83-90) in the VALUE domain: the AIR polynomial evaluated pointwise on
@@ -332,7 +353,13 @@ int fail(int code, const std::string& msg) {
 }
 
 int ensure_init() {
-    if (g.init) return SC_OK;
+    if (g.init) {
+        // HIP's current device is per host thread and starts at 0: a thread other than the one that initialised the library (a
+        // prover thread of a rank that owns device k != 0) is bound to the library's device on its first call
+        static thread_local bool bound = false;
+        if (!bound) { HIPCHK(hipSetDevice(g.device)); bound = true; }
+        return SC_OK;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(SC_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
@@ -625,10 +652,11 @@ int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStrea
     void* fl;
     SCCHK(scratch(4, 256, &fl));
     HIPCHK(hipMemsetAsync(fl, 0, 4, st));
-    constexpr int K = 8;
-    uint64_t threads = (n + K - 1) / K;
-    unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL(pointwise_div_kernel<K>, dim3(blocks), dim3(256), 0, st, a, b, out, n, (uint32_t*)fl);
+    static const int K = [] { const char* e = getenv("STARKCORE_DIV_K"); return e && atoi(e) == 8 ? 8 : 16; }();      // (A/B knob)
+    const uint64_t threads = (n + K - 1) / K;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (K == 8) hipLaunchKernelGGL(pointwise_div_kernel<8>, dim3(blocks), dim3(256), 0, st, a, b, out, n, (uint32_t*)fl);
+    else hipLaunchKernelGGL(pointwise_div_kernel<16>, dim3(blocks), dim3(256), 0, st, a, b, out, n, (uint32_t*)fl);
     HIPCHK(hipGetLastError());
     uint64_t hflag = 0;
     SCCHK(read_small_polled(fl, 8, st, &hflag));                  // (the flag is the low 32 bits of a word of the scratch buffer)
@@ -1266,7 +1294,7 @@ int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t 
         HIPCHK(hipMemsetAsync(fl, 0xFF, sizeof deg, st));          // -1, without a pageable host-to-device copy in front of the kernel
         if (order > n_out) {
             const uint64_t cnt = order - n_out;
-            hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const Fe*)full + n_out, cnt, (long long*)fl);
+            hipLaunchKernelGGL(vec_degree_kernel, dim3(degree_blocks(cnt)), dim3(256), 0, st, (const Fe*)full + n_out, cnt, (long long*)fl);
             HIPCHK(hipGetLastError());
         }
         SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
@@ -1287,13 +1315,13 @@ int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* st
     // the rest only when those are all zero
     const uint64_t top = n < (1ull << 16) ? n : (1ull << 16);
     if (top) {
-        hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((top + 255) / 256)), dim3(256), 0, st, (const Fe*)d_v + (n - top), top, (long long*)fl);
+        hipLaunchKernelGGL(vec_degree_kernel, dim3(degree_blocks(top)), dim3(256), 0, st, (const Fe*)d_v + (n - top), top, (long long*)fl);
         HIPCHK(hipGetLastError());
     }
     SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
     if (deg >= 0) deg += (long long)(n - top);
     else if (n > top) {
-        hipLaunchKernelGGL(vec_degree_kernel, dim3((unsigned)((n - top + 255) / 256)), dim3(256), 0, st, (const Fe*)d_v, n - top, (long long*)fl);
+        hipLaunchKernelGGL(vec_degree_kernel, dim3(degree_blocks(n - top)), dim3(256), 0, st, (const Fe*)d_v, n - top, (long long*)fl);
         HIPCHK(hipGetLastError());
         SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
     }

@@ -154,7 +154,38 @@ SC_HD Fe mont_pow128(Fe base_m, uint64_t e_lo, uint64_t e_hi) {
 
 // inverse of a Montgomery-form value, result in Montgomery form; inverse(0) = 0 like the reference's
 // xgcd-based Field.inverse (code/algebra.py:87-89).
-SC_HD Fe mont_inv(Fe a_m) { return mont_pow128(a_m, 0xFFFFFFFFFFFFFFFFull, P_HI - 1); }   // p - 2
+// x^(p - 2) by an addition chain on the shape of p - 2 = 406 * 2^119 + (2^119 - 1): y = x^(2^119 - 1) (118 squarings, 11 products:
+// exponents 2^k - 1 for k = 1, 2, 3, 6, 7, 14, 28, 29, 58, 59, 118, 119), z = y x = x^(2^119), result = z^406 y (406 = 110010110b:
+// 8 squarings, 4 products) -- 143 modular products where square-and-multiply over the 128 bits takes 252.
+SC_HD Fe mont_sqr_n(Fe v, int n) {
+    for (int i = 0; i < n; ++i) v = mont_mul(v, v);
+    return v;
+}
+SC_HD Fe mont_inv(Fe x) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // (the host inverts a handful of constants per call; its optimiser takes minutes over the chain below with mont_mul_c inlined)
+    return mont_pow128(x, 0xFFFFFFFFFFFFFFFFull, P_HI - 1);
+#else
+    const Fe x2 = mont_mul(mont_sqr_n(x, 1), x);
+    const Fe x3 = mont_mul(mont_sqr_n(x2, 1), x);
+    const Fe x6 = mont_mul(mont_sqr_n(x3, 3), x3);
+    const Fe x7 = mont_mul(mont_sqr_n(x6, 1), x);
+    const Fe x14 = mont_mul(mont_sqr_n(x7, 7), x7);
+    const Fe x28 = mont_mul(mont_sqr_n(x14, 14), x14);
+    const Fe x29 = mont_mul(mont_sqr_n(x28, 1), x);
+    const Fe x58 = mont_mul(mont_sqr_n(x29, 29), x29);
+    const Fe x59 = mont_mul(mont_sqr_n(x58, 1), x);
+    const Fe x118 = mont_mul(mont_sqr_n(x59, 59), x59);
+    const Fe y = mont_mul(mont_sqr_n(x118, 1), x);           // x^(2^119 - 1)
+    const Fe z = mont_mul(y, x);                              // x^(2^119)
+    Fe w = mont_mul(mont_sqr_n(z, 1), z);                     // 11b
+    w = mont_mul(mont_sqr_n(w, 3), z);                        // 11001b
+    w = mont_mul(mont_sqr_n(w, 2), z);                        // 1100101b
+    w = mont_mul(mont_sqr_n(w, 1), z);                        // 11001011b
+    w = mont_sqr_n(w, 1);                                     // 110010110b = 406
+    return mont_mul(w, y);
+#endif
+}
 
 }  // namespace sc
 

@@ -321,6 +321,7 @@ int sc_merkle_build_noroot_dev(const void* d_elems, uint64_t N, sc_merkle_t** tr
 int sc_merkle_root(sc_merkle_t* tree, uint8_t root_out[64]) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tree || !root_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    SCCHK(ensure_init());
     SCCHK(merkle_root_wait(tree));
     memcpy(root_out, tree->root, 64);
     return SC_OK;
@@ -742,6 +743,7 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     std::unique_lock<std::mutex> lk(g_mu);
     if (!last_codeword_out || !top_indices_out || !answers || (extra_count && (!extra_trees || !extra_vecs || !extra_indices_out)) || !num_tests)
         return fail(SC_ERR_BAD_ARG, "null argument");
+    if (rounds < 1 || rounds > 60 || N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
     // vecs_out == trees_out == NULL: nobody wants the folded codewords and their trees once the openings are on the host -- the
     // library keeps them to itself and hands the memory back before it returns (no handle crosses the boundary)
     std::vector<sc_vec_t*> own_vecs;
@@ -755,7 +757,6 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
         trees_out = own_trees.data();
     }
     if (!alphas_out) { own_alphas.assign(2 * (rounds > 1 ? rounds - 1 : 1), 0); alphas_out = own_alphas.data(); }
-    if (rounds < 1 || rounds > 60 || N < 2 || !is_pow2(N)) return fail(SC_ERR_NOT_POW2, "codeword length must be a power of two >= 2 that survives the folds");
     const uint64_t n_last = N >> (rounds - 1);
     const uint32_t s = num_tests;
     if (n_last < 1 || s > n_last || rounds + extra_count > QUERY_MAX_TREES) return fail(SC_ERR_UNSUPPORTED, "shape not served by the one-call prover");
@@ -773,6 +774,10 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     path_bytes += extra_count * 4ull * s * 64 * (size_t)ilog2(N);
     const size_t el_bytes = (total * sizeof(Fe) + 255) & ~(size_t)255;
     if (answers_bytes < el_bytes + path_bytes + total * 8) return fail(SC_ERR_BAD_ARG, "answer buffer too small");
+    {
+        const auto live = g_host_live.find(answers);           // a buffer of sc_host_alloc is written by the kernel: its real size counts, not the caller's word
+        if (live != g_host_live.end() && live->second < el_bytes + path_bytes + total * 8) return fail(SC_ERR_BAD_ARG, "answer buffer too small");
+    }
     // STARKCORE_FRI_TIMING=1: the call's phases on stderr (host clock, microseconds) -- tools/fri_prove_timing.py
     static const bool timing = getenv("STARKCORE_FRI_TIMING") != nullptr;
     std::chrono::steady_clock::time_point tp[8];

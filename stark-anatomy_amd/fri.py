@@ -223,6 +223,8 @@ class Fri:
         N = self.domain_length
         if not (isinstance(codeword, DeviceCodeword) and _po.eligible(codeword) and codeword._tree is None and N >= 2 and N & (N - 1) == 0):
             return None
+        if rounds < 2:                  # (fri.py:122 reads codewords[1]: the reference itself has no proof with fewer than two codewords)
+            return None
         if self.field.p != Field.P_MAIN or s > (N >> (rounds - 1)) or s < 1 or library_transcript(proof_stream, rounds) is None:
             return None
         extra = []
