@@ -938,6 +938,8 @@ void rand_fill(size_t bytes) {
     size_t nthreads = bytes / (256u << 10);
     if (nthreads > 32) nthreads = 32;
     if (hw && nthreads > hw) nthreads = hw;
+    static const long cap = [] { const char* e = getenv("STARKCORE_RAND_THREADS"); return e ? atol(e) : 0L; }();      // (hosts that give the process few cores)
+    if (cap > 0 && nthreads > (size_t)cap) nthreads = (size_t)cap;
     if (nthreads < 1) nthreads = 1;
     auto fill = [](size_t a, size_t b) {
         while (a < b) {
