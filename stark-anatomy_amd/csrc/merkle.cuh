@@ -222,6 +222,100 @@ __device__ __forceinline__ uint32_t leaf_message(Fe x, uint64_t m[16]) {
     return nd;
 }
 
+// The same message with two of the conversion's three parts done differently (the throughput-bound tree kernels; ~35 % fewer
+// instructions than leaf_message, whose 45-character buffer is shifted by a chain of 120 selects):
+//   digits   a group y < 10^9 becomes the 32.32 fixed-point number (y * ceil(2^57 / 10^8) + 2^25) >> 25 = y / 10^8 rounded up in its
+//            last place: the integer part is the first digit, and every further digit is the integer part of fraction * 10 -- ONE
+//            v_mad_u64_u32 per digit, whose 64-bit addend carries the characters collected so far, shifted by a byte, into the high
+//            word next to the new digit (checked against all 10^9 values of y on the host: tools/hostcheck/leaf_digits_check.c);
+//   shift    the 39 characters (most significant first) go to this thread's 80 bytes of LDS followed by zeros, and the message is
+//            read back from byte offset z = the number of leading '0' characters -- unaligned ds_read_b64, no select, no funnel.
+// `slot`: 80 bytes of LDS owned by this thread, 16-byte aligned.
+// One step of the long division by 10^9: (rem * 2^32 + d) / 10^9 -> quotient (< 2^32), rem <- remainder; rem < 10^9 in and out.
+// q' = floor(cur * R / 2^64) with R = ceil(2^64 / 10^9) = 4 * 2^32 + 1266874890 is the quotient or one more (R's excess adds less
+// than 0.068 to cur / 10^9 for cur < 10^9 * 2^32), so the remainder's low word, read as signed, says which: ten instructions
+// where the compiler's 64-bit division by a constant takes fifteen (tools/hostcheck/leaf_div1e9_check.c: 3 * 10^8 cases and the boundaries).
+__device__ __forceinline__ uint32_t div1e9_step(uint32_t& rem, uint32_t d) {
+    constexpr uint32_t R0 = 1266874890u;
+    uint64_t s = (uint64_t)rem * R0 + __umulhi(d, R0);
+    s += (uint64_t)d << 2;
+    uint32_t q = (rem << 2) + (uint32_t)(s >> 32);
+    int32_t r = (int32_t)(d - q * 1000000000u);
+    const int32_t over = r >> 31;                      // all ones when q is one too many
+    q += (uint32_t)over;
+    r += over & 1000000000;
+    rem = (uint32_t)r;
+    return q;
+}
+
+#ifndef SC_LEAF_LDS
+#define SC_LEAF_LDS 1            // 0: the tree kernels convert their leaves with leaf_message (A/B builds)
+#endif
+constexpr uint32_t LEAF_SLOT_BYTES = 80;
+__device__ __forceinline__ uint32_t leaf_message_lds(Fe x, uint64_t m[16], uint8_t* slot) {
+    uint32_t d[4] = {(uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.hi, (uint32_t)(x.hi >> 32)};
+    uint32_t grp[5];   // base-10^9 digits, least significant first (the long division of leaf_message: 13 steps)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int top = (g <= 1) ? 3 : (g == 2 ? 2 : 1);
+        uint32_t rem = 0;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            if (i > top) continue;
+            d[i] = div1e9_step(rem, d[i]);
+        }
+        grp[g] = rem;
+    }
+    grp[4] = d[0];                                     // < 341: three digits
+    // 39 characters, most significant first; acc collects them big-endian, a dword is complete every fourth
+    uint32_t dw[10];
+    uint32_t acc = 0, f;
+    int pos = 0;
+#define LEAF_FIRST(digit) do { acc = (acc << 8) | (digit); if ((pos & 3) == 3) dw[pos >> 2] = acc; ++pos; } while (0)
+#define LEAF_NEXT() do { const uint64_t u_ = (uint64_t)f * 10u + ((uint64_t)(acc << 8) << 32); f = (uint32_t)u_; acc = (uint32_t)(u_ >> 32); \
+                         if ((pos & 3) == 3) dw[pos >> 2] = acc; ++pos; } while (0)
+    {
+        const uint64_t t = (uint64_t)grp[4] * 42949673u;          // ceil(2^32 / 100): integer part = the hundreds
+        f = (uint32_t)t;
+        LEAF_FIRST((uint32_t)(t >> 32));
+        LEAF_NEXT(); LEAF_NEXT();
+    }
+#pragma unroll
+    for (int g = 3; g >= 0; --g) {
+        const uint64_t t = ((uint64_t)grp[g] * 1441151881u + (1u << 25)) >> 25;
+        f = (uint32_t)t;
+        LEAF_FIRST((uint32_t)(t >> 32));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) LEAF_NEXT();
+    }
+    dw[9] = acc << 8;                                   // characters 36..38 and the byte behind the string
+#undef LEAF_FIRST
+#undef LEAF_NEXT
+    // the length: the digits of the most significant non-zero group (counted once) on top of the groups below it
+    uint32_t lead = grp[0], below = 0;
+    if (grp[1]) { lead = grp[1]; below = 9; }
+    if (grp[2]) { lead = grp[2]; below = 18; }
+    if (grp[3]) { lead = grp[3]; below = 27; }
+    if (grp[4]) { lead = grp[4]; below = 36; }
+    const uint32_t nd = lead ? below + ndigits9(lead) : 1u;
+    // to string order (first character in the lowest byte), '0' added to every character; then through LDS, shifted by z bytes
+    uint64_t* w = reinterpret_cast<uint64_t*>(slot);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t lo = __builtin_amdgcn_perm(0u, dw[2 * i] + 0x30303030u, 0x00010203u);
+        const uint32_t hi = __builtin_amdgcn_perm(0u, dw[2 * i + 1] + (i == 4 ? 0x30303000u : 0x30303030u), 0x00010203u);
+        w[i] = ((uint64_t)hi << 32) | lo;
+    }
+#pragma unroll
+    for (int i = 5; i < 10; ++i) w[i] = 0;
+    const uint8_t* from = slot + (39u - nd);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) __builtin_memcpy(&m[i], from + 8 * i, 8);
+#pragma unroll
+    for (int i = 5; i < 16; ++i) m[i] = 0;
+    return nd;
+}
+
 // LDS staging so that every global access of the tree kernels is a fully coalesced 16-byte-per-lane stream:
 // a thread's 128-byte message / 64-byte digest is strided across lanes in memory (8 resp. 4 separate partial-line
 // accesses per lane otherwise).  Slots are rotated by the owning thread id to keep the per-thread LDS accesses
@@ -334,7 +428,7 @@ __device__ __forceinline__ Fe fold_element(const FoldIn& f, uint64_t i, uint64_t
 
 template <bool LEAVES, bool FOUR_LANE, bool FOLD = false>
 __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev, const FoldIn fold = FoldIn()) {
-    __shared__ uint4 cur[256 * 4];                    // this level's digests of the subtree (16 KiB)
+    __shared__ uint4 cur[LEAVES ? 256 * 5 : 256 * 4];  // this level's digests of the subtree (16 KiB); before that, the leaf stage's 80 bytes per thread
     constexpr bool four_lane = FOUR_LANE && (SC_MERKLE_4LANE != 0);
     __shared__ uint64_t linA[four_lane ? 64 * 17 : 1], linB[four_lane ? 32 * 17 : 1];   // 4-lane path: 128 resp. 64 digests in the lin layout
     const uint32_t t = threadIdx.x;
@@ -350,8 +444,14 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         } else {
             e = elems[wg * 256u + t];
         }
+#if SC_LEAF_LDS
+        uint32_t len = leaf_message_lds(e, m, reinterpret_cast<uint8_t*>(cur) + LEAF_SLOT_BYTES * t);
+        blake2b_single_block(m, len, h);
+        __syncthreads();                               // every thread is done with its slot of `cur` before digests are published there
+#else
         uint32_t len = leaf_message(e, m);
         blake2b_single_block(m, len, h);
+#endif
     } else {
         const ulonglong2* s = reinterpret_cast<const ulonglong2*>(levels + 8 * (level_off(lvl0) + wg * 256u + t));
 #pragma unroll
