@@ -257,6 +257,14 @@ int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* e
 /* the same for several constraints over ONE set of point values: vals_converted != 0 says d_vals has been through an earlier call.
  * n may be any count (a rank's slab of a sharded value domain: the evaluation is pointwise). */
 int sc_mpoly_eval_ex_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, int vals_converted, void* stream);
+/* the same with variables that are TURNED copies of others (fast_stark.py:105-106: the point holds trace(X) and trace(omicron X); on
+ * the coset g <omicron> the second one's codeword is the first one's, one place on): variable j is read as
+ * d_vals[var_src[j]][(i + var_rot[j]) mod n] (n a power of two); var_src[j] == j with var_rot[j] == 0 for a variable stored in its
+ * own place, var_src[j] == SC_MPOLY_ABSENT for one that no term uses (its place may hold anything and is not touched; a term that
+ * does use it is an error).  A turned variable must point at a stored one.  var_src == var_rot == NULL: sc_mpoly_eval_ex_dev. */
+#define SC_MPOLY_ABSENT 0xFFFFFFFFu
+int sc_mpoly_eval_rot_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, int vals_converted,
+                          const uint32_t* var_src, const uint64_t* var_rot, void* stream);
 
 /* ---- FRI split-and-fold : code/fri.py:85 ---------------------------------------------------- */
 /* out[i] = 2^-1 * ((1 + alpha/(offset*omega^i)) * in[i] + (1 - alpha/(offset*omega^i)) * in[N/2+i]), i < N/2 */

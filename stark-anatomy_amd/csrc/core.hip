@@ -171,8 +171,10 @@ static inline unsigned degree_blocks(uint64_t n) {
 // the values of the point polynomials; vals_m: [nvars][n] in Montgomery form, coef_m: [nterms] in Montgomery form,
 // exps: [nterms][nvars].  out[i] = sum_t coef[t] * prod_j vals[j][i]^exps[t][j]  (canonical).  The term loop is uniform
 // across the wave (scalar control flow); the value loads are coalesced and stay in L1 across the terms.
+// where != nullptr: variable j is not stored but read off another one -- its value at point i is the value of variable where[2j]
+// at point (i + where[2j+1]) mod n (n a power of two): q(w X) on the coset g <w> is q's own codeword turned by one place.
 __global__ void __launch_bounds__(256) mpoly_eval_kernel(const Fe* __restrict__ vals_m, uint32_t nvars, uint64_t n, const uint8_t* __restrict__ exps,
-                                                        const Fe* __restrict__ coef_m, uint32_t nterms, Fe* __restrict__ out) {
+                                                        const Fe* __restrict__ coef_m, uint32_t nterms, Fe* __restrict__ out, const uint64_t* __restrict__ where) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe acc{0, 0};
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(256) mpoly_eval_kernel(const Fe* __restrict__ 
         for (uint32_t j = 0; j < nvars; ++j) {
             const uint32_t ej = e[j];
             if (ej == 0) continue;
-            const Fe v = vals_m[(uint64_t)j * n + i];
+            const Fe v = where ? vals_m[where[2 * j] * n + ((i + where[2 * j + 1]) & (n - 1))] : vals_m[(uint64_t)j * n + i];
             for (uint32_t k = 0; k < ej; ++k) p = mont_mul(p, v);
         }
         acc = fe_add(acc, p);
@@ -1338,10 +1340,33 @@ int sc_mpoly_eval_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* e
 // vals_converted != 0: d_vals has been through an earlier call already (several constraints over the same point values: the
 // conversion to the library's internal form happens once)
 int sc_mpoly_eval_ex_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, int vals_converted, void* stream) {
+    return sc_mpoly_eval_rot_dev(d_vals, nvars, n, exps, coefs, nterms, d_out, vals_converted, nullptr, nullptr, stream);
+}
+// var_src / var_rot (both or neither): variable j's values are not in d_vals[j] but are those of variable var_src[j] turned by
+// var_rot[j] places -- value at point i = d_vals[var_src[j]][(i + var_rot[j]) mod n], n a power of two; var_src[j] == j, var_rot[j] == 0
+// for a variable stored in its own place, var_src[j] == SC_MPOLY_ABSENT for one no term uses (its place is not touched).
+int sc_mpoly_eval_rot_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t* exps, const void* coefs, uint64_t nterms, void* d_out, int vals_converted,
+                          const uint32_t* var_src, const uint64_t* var_rot, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     hipStream_t st = pick_stream(stream);
     if (!d_vals || !d_out || nvars == 0 || nvars > 255 || n == 0) return fail(SC_ERR_BAD_ARG, "bad argument");
+    if ((var_src == nullptr) != (var_rot == nullptr)) return fail(SC_ERR_BAD_ARG, "var_src and var_rot come together");
+    std::vector<uint64_t> where;
+    if (var_src) {
+        if (!is_pow2(n)) return fail(SC_ERR_NOT_POW2, "turned variables need a power-of-two domain");
+        const uint8_t* e = exps;
+        for (uint64_t j = 0; j < nvars; ++j) {
+            const uint32_t s = var_src[j];
+            if (s == SC_MPOLY_ABSENT) {
+                for (uint64_t t = 0; t < nterms; ++t) if (e[t * nvars + j]) return fail(SC_ERR_BAD_ARG, "a term uses a variable that is marked absent");
+                where.push_back(j); where.push_back(0);
+                continue;
+            }
+            if (s >= nvars || var_src[s] != s || var_rot[s] != 0 || (s == j && var_rot[j] != 0)) return fail(SC_ERR_BAD_ARG, "a turned variable must point at one stored in its own place");
+            where.push_back(s); where.push_back(var_rot[j] & (n - 1));
+        }
+    }
     const Fe* c = (const Fe*)coefs;
     std::vector<Fe> cm(nterms ? nterms : 1);
     for (uint64_t t = 0; t < nterms; ++t) {
@@ -1349,17 +1374,26 @@ int sc_mpoly_eval_ex_dev(void* d_vals, uint64_t nvars, uint64_t n, const uint8_t
         cm[t] = to_mont(c[t]);
     }
     const size_t cbytes = (cm.size() * sizeof(Fe) + 255) & ~255ull;
+    const size_t ebytes = (nterms * nvars + 255) & ~255ull;
     void* buf;
-    SCCHK(scratch(4, cbytes + nterms * nvars + 256, &buf));
+    SCCHK(scratch(4, cbytes + ebytes + 16 * nvars + 256, &buf));
+    uint64_t* d_where = where.empty() ? nullptr : (uint64_t*)((char*)buf + cbytes + ebytes);
     // (a handful of terms: coefficients and exponents go in as kernel arguments and nothing has to be waited for afterwards)
-    const bool small = upload_small(buf, cm.data(), cm.size() * sizeof(Fe), st) && (!nterms || upload_small((char*)buf + cbytes, exps, nterms * nvars, st));
+    const bool small = upload_small(buf, cm.data(), cm.size() * sizeof(Fe), st) && (!nterms || upload_small((char*)buf + cbytes, exps, nterms * nvars, st)) &&
+                       (!d_where || upload_small(d_where, where.data(), where.size() * 8, st));
     if (!small) {
         SCCHK(upload(buf, cm.data(), cm.size() * sizeof(Fe), st));
         if (nterms) SCCHK(upload((char*)buf + cbytes, exps, nterms * nvars, st));
+        if (d_where) SCCHK(upload(d_where, where.data(), where.size() * 8, st));
     }
-    if (!vals_converted) hipLaunchKernelGGL(to_mont_kernel, dim3((unsigned)((nvars * n + 255) / 256)), dim3(256), 0, st, (Fe*)d_vals, nvars * n);
+    if (!vals_converted) {
+        if (!var_src) hipLaunchKernelGGL(to_mont_kernel, dim3((unsigned)((nvars * n + 255) / 256)), dim3(256), 0, st, (Fe*)d_vals, nvars * n);
+        else
+            for (uint64_t j = 0; j < nvars; ++j)       // only what is stored: the places of turned and of absent variables hold nothing
+                if (var_src[j] == j) hipLaunchKernelGGL(to_mont_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Fe*)d_vals + j * n, n);
+    }
     hipLaunchKernelGGL(mpoly_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fe*)d_vals, (uint32_t)nvars, n,
-                       (const uint8_t*)((char*)buf + cbytes), (const Fe*)buf, (uint32_t)nterms, (Fe*)d_out);
+                       (const uint8_t*)((char*)buf + cbytes), (const Fe*)buf, (uint32_t)nterms, (Fe*)d_out, (const uint64_t*)d_where);
     HIPCHK(hipGetLastError());
     // (not waited for on the library's own stream: the scratch tables' next writer is ordered behind this kernel there; a caller's
     // stream shares the scratch buffer with other streams, so the call still ends with the kernel done)

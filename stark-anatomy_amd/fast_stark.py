@@ -8,6 +8,7 @@ transition_constraints_degree=2)` with `preprocess / prove / verify` and the deg
 `proof_stream.push` calls is the reference's, so with a patched `fast_stark.os.urandom` the proof bytes are identical.
 """
 from functools import reduce
+import ctypes
 import os
 
 from fri import *
@@ -300,7 +301,8 @@ class FastStark:
 
         # transition polynomials: AIR evaluated symbolically in (X, trace(X), trace(omicron X)), then quotients
         x = Polynomial([field.zero(), field.one()])
-        point = [DevicePolynomial.from_polynomial(x, field) if on_device else x] + trace_polynomials + [tp.scale(self.omicron) for tp in trace_polynomials]
+        point = [DevicePolynomial.from_polynomial(x, field) if on_device else x] + trace_polynomials + \
+                [tp.scaled_later(self.omicron) if on_device else tp.scale(self.omicron) for tp in trace_polynomials]
         if on_device:
             transition_quotients = self._transition_quotients_on_device(transition_constraints, point, self._lift(transition_zerofier))
         else:
@@ -411,10 +413,23 @@ class FastStark:
         for order, (root, members) in groups.items():
             nvars, rt = len(point), _sc.fe_bytes(root.value)
             used = [any(k[j] for _, _, terms in members for k, _ in terms) for j in range(nvars)]
+            # q(root X) on the coset g <root> is q's codeword there, one place on: such a variable (the trace polynomials at
+            # omicron X, fast_stark.py:105-106, whenever the coset's root is omicron itself) is read off its source's values
+            # instead of being scaled and transformed
+            turned = {}
+            for j, q in enumerate(point):
+                source = getattr(q, "scaled_from", None)
+                if used[j] and source is not None and source[1].value == root.value:
+                    k = next((k for k, other in enumerate(point) if other is source[0]), None)
+                    if k is not None and getattr(point[k], "scaled_from", None) is None:
+                        turned[j] = k
+            stored = [(used[j] and j not in turned) or j in turned.values() for j in range(nvars)]
             vals = DeviceVector(nvars * order)
             for j, q in enumerate(point):
-                if used[j]:
+                if stored[j]:
                     _sc._check(lib.sc_coset_evaluate_dev(q.vec.ptr, degrees[j] + 1, gen, rt, order, vals.ptr + 16 * j * order, None))
+            var_src = (ctypes.c_uint32 * nvars)(*[turned.get(j, j if stored[j] else 0xFFFFFFFF) for j in range(nvars)])
+            var_rot = (ctypes.c_uint64 * nvars)(*[1 if j in turned else 0 for j in range(nvars)])
             kept = self._zerofier_values.get(order)
             if kept is not None and kept[0] is tz_dev:
                 zvals = kept[1]
@@ -429,7 +444,7 @@ class FastStark:
                 exps = bytes(e for k, _ in terms for e in k)
                 coefs = b"".join(v.to_bytes(16, "little") for _, v in terms)
                 tvals, whole = DeviceVector(order), DeviceVector(order)
-                _sc._check(lib.sc_mpoly_eval_ex_dev(vals.ptr, nvars, order, exps, coefs, len(terms), tvals.ptr, converted, None))
+                _sc._check(lib.sc_mpoly_eval_rot_dev(vals.ptr, nvars, order, exps, coefs, len(terms), tvals.ptr, converted, var_src, var_rot, None))
                 converted = 1
                 _sc._check(lib.sc_pointwise_div_dev(tvals.ptr, zvals.ptr, tvals.ptr, order, None))      # "divide by zero" like algebra.py:92
                 _sc._check(lib.sc_ntt_dev(tvals.ptr, whole.ptr, order, rt, 1, None))

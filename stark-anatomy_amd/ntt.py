@@ -302,6 +302,11 @@ class DevicePolynomial:
             scaled._degree = self._degree                  # coefficient i times factor^i: the same coefficients vanish (None stays None)
         return scaled
 
+    def scaled_later(self, factor):
+        """`scale(factor)` whose coefficients are only computed if somebody asks for them: a caller that evaluates the result on the
+        coset g <factor> never does -- q(factor X) there is q's own codeword, one place on (fast_stark.py:105-113)"""
+        return ScaledLater(self, factor)
+
     def coset_evaluate(self, offset, generator, order):
         """fast_coset_evaluate (code/ntt.py:132-135) -> DeviceCodeword"""
         out = DeviceVector(order)
@@ -309,6 +314,30 @@ class DevicePolynomial:
         # behind an event -- sc_vec_free never hands memory back while a stream may still use it)
         _sc._check(_sc.lib().sc_coset_evaluate_dev(self.vec.ptr, self.n, _sc.fe_bytes(offset.value), _sc.fe_bytes(generator.value), order, out.ptr, None))
         return DeviceCodeword(out, self.field)
+
+
+class ScaledLater(DevicePolynomial):
+    """source.scale(factor), made when `vec` is first read; `scaled_from` = (source, factor) for whoever can do without"""
+
+    def __init__(self, source, factor):
+        self.field, self.n = source.field, source.n
+        self.scaled_from = (source, factor)
+        self._made = None
+        self._degree = source._degree if factor.value % source.field.p != 0 else None
+
+    @property
+    def vec(self):
+        if self._made is None:
+            source, factor = self.scaled_from
+            self._made = DevicePolynomial.scale(source, factor)
+            if self._degree is None:
+                self._degree = self._made._degree
+        return self._made.vec
+
+    def degree(self):
+        if self._degree is None and self.scaled_from[1].value % self.field.p != 0:
+            self._degree = self.scaled_from[0].degree()      # the same coefficients vanish
+        return DevicePolynomial.degree(self)
 
 
 class _View:

@@ -121,6 +121,7 @@ SIGNATURES = {
     "sc_merkle_free": (_int, [_vp]),
     "sc_mpoly_eval_dev": (_int, [_vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
     "sc_mpoly_eval_ex_dev": (_int, [_vp, _u64, _u64, _vp, _vp, _u64, _vp, _int, _vp]),
+    "sc_mpoly_eval_rot_dev": (_int, [_vp, _u64, _u64, _vp, _vp, _u64, _vp, _int, _vp, _vp, _vp]),
     "sc_zerofier": (_int, [_vp, _u64, _vp]),
     "sc_evaluate": (_int, [_vp, _u64, _vp, _u64, _vp]),
     "sc_interpolate": (_int, [_vp, _vp, _u64, _vp]),

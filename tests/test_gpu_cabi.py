@@ -533,6 +533,37 @@ def test_query_multi_and_mpoly_eval(sc):
             acc = (acc + t) % P
         want.append(acc)
     assert synth.unpack_ints(out.to_bytes()) == want
+    # the same with turned variables (sc_mpoly_eval_rot_dev): variable 2 = variable 0 three places on, variable 3 = variable 1 one
+    # place on (mod n), variable 4 in no term and marked absent -- its place is never written and never read
+    n2, nv2 = 256, 5
+    stored = [synth.synth_ints(1500 + j, n2) for j in range(2)]
+    terms2 = [((1, 0, 2, 0, 0), 7), ((0, 3, 0, 1, 0), P - 2), ((2, 1, 1, 1, 0), rng.randrange(P)), ((0, 0, 0, 0, 0), 11)]
+    dv2 = sc.DeviceVector(nv2 * n2)
+    sc._check(lib.sc_vec_upload(dv2._h, 0, b"".join(synth.pack_ints(v) for v in stored), 2 * n2))
+    out2 = sc.DeviceVector(n2)
+    exps2 = bytes(e for k, _ in terms2 for e in k)
+    src = (ctypes.c_uint32 * nv2)(0, 1, 0, 1, 0xFFFFFFFF)
+    rot = (ctypes.c_uint64 * nv2)(0, 0, 3, 1, 0)
+    for converted in (0, 1):                       # (the second call finds the stored variables converted already)
+        sc._check(lib.sc_mpoly_eval_rot_dev(dv2.ptr, nv2, n2, exps2, synth.pack_ints([c for _, c in terms2]), len(terms2), out2.ptr, converted, src, rot, None))
+        value = lambda j, i: stored[0][(i + 3) % n2] if j == 2 else stored[1][(i + 1) % n2] if j == 3 else stored[j][i]
+        want2 = []
+        for i in range(n2):
+            acc = 0
+            for k, c in terms2:
+                t = c
+                for j, e in enumerate(k):
+                    if e:
+                        t = t * pow(value(j, i), e, P) % P
+                acc = (acc + t) % P
+            want2.append(acc)
+        assert synth.unpack_ints(out2.to_bytes()) == want2, converted
+    bad_terms = bytes([0, 0, 0, 0, 1])             # a term that uses the absent variable; a turned variable pointing at a turned one
+    with pytest.raises(sc.StarkCoreError):
+        sc._check(lib.sc_mpoly_eval_rot_dev(dv2.ptr, nv2, n2, bad_terms, synth.pack_ints([1]), 1, out2.ptr, 1, src, rot, None))
+    with pytest.raises(sc.StarkCoreError):
+        sc._check(lib.sc_mpoly_eval_rot_dev(dv2.ptr, nv2, n2, exps2, synth.pack_ints([c for _, c in terms2]), len(terms2), out2.ptr, 1,
+                                            (ctypes.c_uint32 * nv2)(0, 1, 3, 1, 0xFFFFFFFF), rot, None))
 
 
 def test_round2_device_entry_points(sc):

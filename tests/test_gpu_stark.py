@@ -103,6 +103,62 @@ def test_synthetic_air_reference_golden_proofs(device_min, monkeypatch):
         fast_stark.os.urandom = genuine
 
 
+def test_trace_at_omicron_x_is_read_off_the_trace_codeword_not_scaled_and_transformed(monkeypatch):
+    """fast_stark.py:105-106 puts trace(omicron X) in the point.  On the coset g <omicron> -- the one the value-domain transition
+    quotients use unless the degree bound lets it shrink -- that polynomial's codeword is trace(X)'s, one place on: the prover
+    neither scales the coefficients nor transforms them (sc_mpoly_eval_rot_dev reads the variable off its source), and the proof
+    is, byte for byte, the one the scale-and-transform way gives.  (A randomized trace of 296 rows: 2 * 295 > 512, so the coset
+    keeps the omicron domain's 1024 points; bench.py's sizes, whose randomized trace is a power of two, halve it -- there the
+    odd points of the omicron coset are needed, and the variable is transformed as before.)"""
+    import synth
+    import ntt as ntt_mod
+    import starkcore as sc
+    from multivariate import MPolynomial
+    field, s, T = Field.main(), 40, 136
+    col_a, col_b = synth.synthetic_air_columns(T)
+    v = MPolynomial.variables(5, field)
+    air = [v[3] - v[2], v[4] - v[1] * v[1] - v[2]]
+    boundary = [(0, 0, FieldElement(col_a[0], field)), (0, 1, FieldElement(col_b[0], field)), (T - 1, 1, FieldElement(col_b[T - 1], field))]
+    packed = [synth.pack_ints(col_a), synth.pack_ints(col_b)]
+    stark = FastStark(field, 4, s, 2 * s, 2, T)
+    assert stark.omicron_domain_length == 1024
+    lib = sc.lib()
+    real_scale, real_eval = ntt_mod.DevicePolynomial.scale, lib.sc_coset_evaluate_dev
+    scaled, evaluated, counts = [], [], []
+
+    class Spy:                                                                # notes the order of every coset transform
+        def __getattr__(self, name):
+            fn = getattr(lib, name)
+            if name != "sc_coset_evaluate_dev":
+                return fn
+            return lambda *a: (evaluated.append(int(a[4])), real_eval(*a))[1]
+    monkeypatch.setattr(ntt_mod.DevicePolynomial, "scale", lambda self, factor: (scaled.append(factor.value), real_scale(self, factor))[1])
+    genuine = fast_stark.os.urandom
+    proofs = []
+    try:
+        tz, tz_codeword, tz_root = stark.preprocess(device_resident=True)
+        for turned in (True, False):
+            if not turned:
+                monkeypatch.setattr(ntt_mod.DevicePolynomial, "scaled_later", lambda self, factor: ntt_mod.DevicePolynomial.scale(self, factor))
+            _seed_urandom(4242)
+            del scaled[:], evaluated[:]
+            stark._zerofier_values.clear()                                    # (kept between proofs: both runs evaluate them once)
+            monkeypatch.setattr(sc, "_lib", Spy())
+            try:
+                proofs.append(stark.prove(fast_stark.DeviceTrace.from_packed(packed, field), air, boundary, tz, tz_codeword))
+            finally:
+                monkeypatch.setattr(sc, "_lib", lib)
+            counts.append((scaled.count(stark.omicron.value), evaluated.count(stark.omicron_domain_length)))
+    finally:
+        fast_stark.os.urandom = genuine
+    assert proofs[0] == proofs[1]
+    assert stark.verify(proofs[0], air, boundary, tz_root) is True
+    # b' = b(omicron X) belongs to the quadratic constraint, whose coset is the whole omicron domain: read off b's codeword -- one
+    # scaling and one transform of that order fewer.  a' belongs to the linear constraint, whose coset is half as large: the odd
+    # points of the omicron coset, scaled and transformed as before.
+    assert counts[1] == (2, counts[0][1] + 1) and counts[0][0] == 1, counts
+
+
 @pytest.mark.parametrize("device_min", [32, 10 ** 9])
 def test_fast_stark(device_min, monkeypatch):      # code/test_fast_stark.py:9-65, 3 trials, seeded
     monkeypatch.setattr(FastStark, "DEVICE_MIN", device_min)
