@@ -427,7 +427,14 @@ class FastStark:
             vals = DeviceVector(nvars * order)
             for j, q in enumerate(point):
                 if stored[j]:
-                    _sc._check(lib.sc_coset_evaluate_dev(q.vec.ptr, degrees[j] + 1, gen, rt, order, vals.ptr + 16 * j * order, None))
+                    source = getattr(q, "scaled_from", None)
+                    if source is not None:
+                        # q(f X) on g <root> is q on (g f) <root>: the transform's own offset does the scaling, the scaled
+                        # coefficient vector is never made
+                        shifted = _sc.fe_bytes((self.generator * source[1]).value)
+                        _sc._check(lib.sc_coset_evaluate_dev(source[0].vec.ptr, degrees[j] + 1, shifted, rt, order, vals.ptr + 16 * j * order, None))
+                    else:
+                        _sc._check(lib.sc_coset_evaluate_dev(q.vec.ptr, degrees[j] + 1, gen, rt, order, vals.ptr + 16 * j * order, None))
             var_src = (ctypes.c_uint32 * nvars)(*[turned.get(j, j if stored[j] else 0xFFFFFFFF) for j in range(nvars)])
             var_rot = (ctypes.c_uint64 * nvars)(*[1 if j in turned else 0 for j in range(nvars)])
             kept = self._zerofier_values.get(order)

@@ -155,8 +155,8 @@ def test_trace_at_omicron_x_is_read_off_the_trace_codeword_not_scaled_and_transf
     assert stark.verify(proofs[0], air, boundary, tz_root) is True
     # b' = b(omicron X) belongs to the quadratic constraint, whose coset is the whole omicron domain: read off b's codeword -- one
     # scaling and one transform of that order fewer.  a' belongs to the linear constraint, whose coset is half as large: the odd
-    # points of the omicron coset, scaled and transformed as before.
-    assert counts[1] == (2, counts[0][1] + 1) and counts[0][0] == 1, counts
+    # points of the omicron coset -- a itself, transformed with the offset g * omicron (no scaled coefficient vector either).
+    assert counts[1] == (2, counts[0][1] + 1) and counts[0][0] == 0, counts
 
 
 @pytest.mark.parametrize("device_min", [32, 10 ** 9])
