@@ -14,17 +14,25 @@ set -u
 set -o pipefail
 REPO=$(cd "$(dirname "$0")/.." && pwd); cd $REPO
 MODE=${1:-cpu}; OUT=${2:-/tmp/sanitize}; mkdir -p $OUT
-LIBS=/tmp/sanitize_libs; mkdir -p $LIBS          # the instrumented libraries (tens of MB) stay out of $OUT, which holds the logs
+LIBS=${SAN_LIBS:-/tmp/sanitize_libs}; mkdir -p $LIBS   # the instrumented libraries (tens of MB) stay out of $OUT, which holds the logs
+# `bash tools/sanitize.sh build` with SAN_LIBS=stark-anatomy_amd/.san builds the two instrumented libraries WITHOUT a GPU (hipcc cross-
+# compiles); a later `gpu` run with the same SAN_LIBS finds them (newer than every source) and spends its GPU time on the tests only
 CSRC=stark-anatomy_amd/csrc
 CLANG_RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 CLANG_TSAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so 2>/dev/null | head -1)
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 build_lib() {   # $1 = sanitizer list, $2 = output
+  if [ -f $2 ] && [ -z "$(find $CSRC include -newer $2 -type f | head -1)" ]; then echo "(using $2, built ahead of time)"; return 0; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=$1 -fno-omit-frame-pointer -shared-libsan \
       -Wno-unused-value -Wno-unused-result -Wno-option-ignored -shared -o $2 $CSRC/core.hip $CSRC/merkle_fri.hip $CSRC/polytree_geo.hip $CSRC/fourstep.hip 2>&1 | grep -E "error" ; test -f $2
 }
 status=0
+if [ "$MODE" = build ]; then
+  build_lib address,undefined $LIBS/libstarkcore_san.so || status=1
+  if [ -n "$CLANG_TSAN" ]; then build_lib thread $LIBS/libstarkcore_tsan.so || status=1; fi
+  ls -la $LIBS; echo "sanitize.sh build: status $status"; exit $status
+fi
 if [ "$MODE" = cpu ]; then
   gcc -O1 -g -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared -o $LIBS/libstark_oracle_san.so oracle/stark_oracle.c || status=1
   g++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared -o $LIBS/libntt_emu_san.so tests/emu/ntt_emu.cpp || status=1
