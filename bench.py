@@ -563,6 +563,48 @@ def strong_record(log2n, world, seconds_per_pair, roundtrip_ok, corner_turn, byt
     return rec
 
 
+_DIRECT_PREFLIGHT = None          # the job's one pre-flight of the direct-store corner turn: {"passed": bool, ...}
+
+
+def direct_store_preflight(rank, world, dev, dist, backend):
+    """The ingredients of the direct-store corner turn -- a HIP IPC region of one process opened in another, kernels of one GPU storing
+    into another's memory -- tried by a CHILD of every rank first (stark-anatomy_amd/direct_preflight.py): between two physical GPUs they have
+    never run, and what goes wrong there may be a GPU memory fault that ends the process instead of an error the library could
+    return.  The ranks use the direct-store forms only if every child came back with status 0.  Once per job."""
+    global _DIRECT_PREFLIGHT
+    if _DIRECT_PREFLIGHT is not None:
+        return _DIRECT_PREFLIGHT
+    import shutil
+    import subprocess
+    import tempfile
+    import torch
+    on_dev = backend == "nccl"
+    box = [tempfile.mkdtemp(prefix="starkcore_preflight_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    where = box[0]
+    local = dev.index if on_dev and dev.index is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    if not on_dev:
+        local = local % max(1, torch.cuda.device_count())
+    t0 = time.perf_counter()
+    try:
+        child = subprocess.run([sys.executable, os.path.join(REPO, "stark-anatomy_amd", "direct_preflight.py"), str(rank), str(world), str(local), where],
+                               capture_output=True, text=True, timeout=120, env=dict(os.environ, STARKCORE_NO_TORCH="1"))
+        status, said = child.returncode, child.stderr.strip().splitlines()[-1:] if child.stderr.strip() else []
+    except subprocess.TimeoutExpired:
+        status, said = -1, ["no answer within 120 s"]
+    t = torch.tensor([status == 0], dtype=torch.int32, device=dev if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    passed = int(t.item()) == 1
+    if status != 0:
+        sys.stderr.write("bench.py: direct-store pre-flight, rank %d: status %d %s\n" % (rank, status, " ".join(said)))
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(where, ignore_errors=True)
+    _DIRECT_PREFLIGHT = {"form": "direct-store pre-flight (a child of every rank exports, maps and stores across processes)", "passed": passed,
+                         "this_rank_status": status, "seconds": round(time.perf_counter() - t0, 2)}
+    return _DIRECT_PREFLIGHT
+
+
 def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4, only=None):
     """The sharded transform of length 2^log2n ready to be timed: every form of the corner turn this job can run is built, its
     forward transform compared with the first form's element for element, its round trip checked, and timed for a few steps;
@@ -606,7 +648,10 @@ def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4, o
             forms.append(("library RCCL communicator, one exchange on the compute stream", dict(own, native_exchange=True)))
             forms.append(("library RCCL communicator, 2 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=2)))
             forms.append(("library RCCL communicator, 4 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=4)))
-        if not args.no_direct_store:
+        preflight = None
+        if not args.no_direct_store and world > 1:
+            preflight = direct_store_preflight(rank, world, dev, dist, backend)
+        if not args.no_direct_store and (preflight is None or preflight["passed"]):
             # no collective at all: the column stage stores block h straight into rank h's receive buffer (HIP IPC over xGMI),
             # a flag barrier, the row stage -- with the default split and, above 2^16, with the square one (fewer, longer rows)
             forms.append(("direct store: column stage writes into the peers' receive buffers (HIP IPC), flag barrier, no collective", dict(direct_store=True)))
@@ -615,6 +660,8 @@ def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4, o
         if log2n >= 20 and native:
             forms.append(("library RCCL communicator, one exchange, square split n1 = 2^%d" % (log2n // 2), dict(own, native_exchange=True, log_n1=log2n // 2)))
     candidates, y_ref, probes = [], None, []
+    if only is None and world > 1 and _DIRECT_PREFLIGHT is not None:
+        probes.append(dict(_DIRECT_PREFLIGHT))
     for label, kw in forms:
         eng = x = y = z = None
         built = True

@@ -436,6 +436,9 @@ def test_bench_two_ranks_print_the_north_star_record(sc):
     direct = [p for p in probes["probes"] if p["form"].startswith("direct store: ")][0]
     assert direct["available"] is True and direct["correct"] is True and direct["ms_per_pair"] > 0
     assert direct["receive_region_memory"] == "fine-grained"      # peers store into it while this GPU's kernels poll and read it
+    # ... and only after a child of every rank had exported, mapped and stored across processes without taking its process down
+    pre = [p for p in probes["probes"] if p["form"].startswith("direct-store pre-flight")][0]
+    assert pre["passed"] is True and pre["this_rank_status"] == 0
     node = out["config"]["node"]
     assert "rccl_version" in node and node["visible_gpus"] >= 1 and len(node["can_access_peer"]) == node["visible_gpus"]
     assert "n1 = 2^" in out["config"]["split"]
@@ -476,6 +479,20 @@ def test_bench_bare_launch_two_ranks_and_census_parity(sc):
     coeffs = synth.synth_packed(60, No // 2).tobytes()
     lde = po.C.coset_evaluate(coeffs, No // 2, po.GENERATOR, po.primitive_nth_root(Nf), Nf)
     assert po.C.merkle_commit(lde, Nf).hex()[:16] == s1["roots"][0]
+
+
+def test_bench_keeps_to_the_collectives_when_a_pre_flight_child_dies(sc):
+    """What may go wrong with the direct-store corner turn between two physical GPUs is not only an error code: a store into memory
+    the runtime mapped badly is a GPU memory fault, and that ends the process.  bench.py lets a child of every rank try the
+    ingredients first (stark-anatomy_amd/direct_preflight.py); here rank 1's child dies by SIGABRT, as a fault would end it --
+    every rank leaves the direct-store forms alone and the job still prints its line, measured through the collectives."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--scaling", "weak"],
+                     env_extra={"STARKCORE_TEST_PREFLIGHT_DIES": "1", "STARKCORE_PREFLIGHT_WAIT_S": "6"})
+    probes = out["config"]["corner_turn_probes"]
+    pre = [p for p in probes["probes"] if p["form"].startswith("direct-store pre-flight")][0]
+    assert pre["passed"] is False
+    assert not any(p["form"].startswith("direct store") for p in probes["probes"]) and "direct store" not in probes["chosen"]
+    assert out["config"]["roundtrip_bit_exact"] is True and out["value"] > 0
 
 
 def test_bench_measures_again_when_the_direct_store_fails_in_the_timed_run(sc):
