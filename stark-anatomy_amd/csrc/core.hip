@@ -358,8 +358,8 @@ int ensure_init() {
     if (g.init) {
         // HIP's current device is per host thread and starts at 0: a thread other than the one that initialised the library (a
         // prover thread of a rank that owns device k != 0) is bound to the library's device on its first call
-        static thread_local bool bound = false;
-        if (!bound) { HIPCHK(hipSetDevice(g.device)); bound = true; }
+        static thread_local int bound = -1;            // (the device, not a flag: sc_shutdown + sc_init may move the library)
+        if (bound != g.device) { HIPCHK(hipSetDevice(g.device)); bound = g.device; }
         return SC_OK;
     }
     int n = 0;
