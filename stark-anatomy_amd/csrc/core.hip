@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256) axpy_shift_kernel(Fe* __restrict__ acc, c
 // domain ran at 1.06 TB/s with one element per thread and one workgroup per 256 elements.
 constexpr int DEGREE_PER_THREAD = 4;
 constexpr unsigned DEGREE_MAX_BLOCKS = 2048;
+constexpr int DEGREE_SLOTS = 8;                        // 64 bytes: what read_small_polled carries in one transfer
 __global__ void __launch_bounds__(256) vec_degree_kernel(const Fe* __restrict__ v, uint64_t n, long long* out) {
     const uint64_t step = (uint64_t)gridDim.x * (256 * DEGREE_PER_THREAD);
     long long best = -1;                               // (wave-uniform) the highest non-zero index this wave has seen
@@ -160,7 +161,26 @@ __global__ void __launch_bounds__(256) vec_degree_kernel(const Fe* __restrict__ 
             if (lanes) best = (long long)(base - (threadIdx.x & 63u) + 256u * k + (63 - __clzll((long long)lanes)));      // (later rows and steps are higher)
         }
     }
-    if (best >= 0 && (threadIdx.x & 63u) == 0) atomicMax(out, best);
+    // One atomic per WORKGROUP that saw a non-zero element, spread over DEGREE_SLOTS words (the host takes their maximum): every
+    // wave of a strided grid finishes at the same moment, and 8192 atomics on one word cost twice the scan of a dense 2^24 vector.
+    __shared__ long long wave_best[4];
+    if ((threadIdx.x & 63u) == 0) wave_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long m = wave_best[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = wave_best[w] > m ? wave_best[w] : m;
+        if (m >= 0) atomicMax(out + (blockIdx.x & (DEGREE_SLOTS - 1)), m);
+    }
+}
+// the maximum of the kernel's DEGREE_SLOTS words (each -1 or an index), read in one polled transfer
+static int degree_read(void* fl, hipStream_t st, long long* deg) {
+    long long slots[DEGREE_SLOTS];
+    SCCHK(read_small_polled(fl, sizeof slots, st, slots));
+    long long m = -1;
+    for (int i = 0; i < DEGREE_SLOTS; ++i) m = slots[i] > m ? slots[i] : m;
+    *deg = m;
+    return SC_OK;
 }
 static inline unsigned degree_blocks(uint64_t n) {
     const uint64_t b = (n + 256 * DEGREE_PER_THREAD - 1) / (256 * DEGREE_PER_THREAD);
@@ -1295,13 +1315,13 @@ int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t 
         void* fl;
         SCCHK(scratch(7, 256, &fl));
         long long deg = -1;
-        HIPCHK(hipMemsetAsync(fl, 0xFF, sizeof deg, st));          // -1, without a pageable host-to-device copy in front of the kernel
+        HIPCHK(hipMemsetAsync(fl, 0xFF, DEGREE_SLOTS * sizeof deg, st));      // -1 in every slot, without a pageable host-to-device copy in front of the kernel
         if (order > n_out) {
             const uint64_t cnt = order - n_out;
             hipLaunchKernelGGL(vec_degree_kernel, dim3(degree_blocks(cnt)), dim3(256), 0, st, (const Fe*)full + n_out, cnt, (long long*)fl);
             HIPCHK(hipGetLastError());
         }
-        SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
+        SCCHK(degree_read(fl, st, &deg));
         *exact = deg < 0 ? 1 : 0;
     }
     return SC_OK;
@@ -1314,7 +1334,7 @@ int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* st
     void* fl;
     SCCHK(scratch(7, 256, &fl));
     long long deg = -1;
-    HIPCHK(hipMemsetAsync(fl, 0xFF, sizeof deg, st));              // -1, without a pageable host-to-device copy in front of the kernel
+    HIPCHK(hipMemsetAsync(fl, 0xFF, DEGREE_SLOTS * sizeof deg, st));  // -1 in every slot, without a pageable host-to-device copy in front of the kernel
     // the leading coefficient of a polynomial is almost always in its last few entries: look at the top 2^16 first, and at
     // the rest only when those are all zero
     const uint64_t top = n < (1ull << 16) ? n : (1ull << 16);
@@ -1322,12 +1342,12 @@ int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* st
         hipLaunchKernelGGL(vec_degree_kernel, dim3(degree_blocks(top)), dim3(256), 0, st, (const Fe*)d_v + (n - top), top, (long long*)fl);
         HIPCHK(hipGetLastError());
     }
-    SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
+    SCCHK(degree_read(fl, st, &deg));
     if (deg >= 0) deg += (long long)(n - top);
     else if (n > top) {
         hipLaunchKernelGGL(vec_degree_kernel, dim3(degree_blocks(n - top)), dim3(256), 0, st, (const Fe*)d_v, n - top, (long long*)fl);
         HIPCHK(hipGetLastError());
-        SCCHK(read_small_polled(fl, sizeof deg, st, &deg));
+        SCCHK(degree_read(fl, st, &deg));
     }
     *degree_out = (int64_t)deg;
     return SC_OK;
