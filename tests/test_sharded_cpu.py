@@ -52,3 +52,23 @@ def test_sharded_stark_prover_gloo_matches_reference_proofs(world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == world
+
+
+@pytest.mark.parametrize("case", ["no_gpu", "all_children_pass", "one_child_dies"])
+def test_direct_store_preflight_agreement_gloo(case, tmp_path):
+    """bench.direct_store_preflight (the children that try the direct-store corner turn's ingredients before any rank does): the
+    ranks must end with ONE answer -- here, without a GPU, 'no' because no child can initialise the library; with a stand-in child
+    that only walks through the file rendezvous, 'yes' when every child returns 0 and 'no' when one of them dies by SIGABRT."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1", STARKCORE_PREFLIGHT_WAIT_S="5",
+               PREFLIGHT_TMP=str(tmp_path))
+    if case != "no_gpu":
+        env["PREFLIGHT_FAKE"] = "1"
+    if case == "all_children_pass":
+        env["PREFLIGHT_EXPECT"] = "pass"
+    if case == "one_child_dies":
+        env["PREFLIGHT_FAKE_FAILS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(REPO, "tests", "preflight_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok rank") == 2
