@@ -579,9 +579,18 @@ def direct_store_preflight(rank, world, dev, dist, backend):
     import tempfile
     import torch
     on_dev = backend == "nccl"
-    box = [tempfile.mkdtemp(prefix="starkcore_preflight_") if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    where = box[0]
+    # the rendezvous directory: rank 0 makes it, its name travels as numbers (a plain tensor broadcast, like every other exchange here)
+    made = tempfile.mkdtemp(prefix="starkcore_preflight_") if rank == 0 else ""
+    name = torch.zeros(256, dtype=torch.int32)
+    if rank == 0:
+        raw = made.encode()
+        assert len(raw) < 255, made
+        name[0] = len(raw)
+        name[1:1 + len(raw)] = torch.tensor(list(raw), dtype=torch.int32)
+    name = name.to(dev) if on_dev else name
+    dist.broadcast(name, 0)
+    name = name.cpu().tolist()
+    where = bytes(name[1:1 + name[0]]).decode()
     local = dev.index if on_dev and dev.index is not None else int(os.environ.get("LOCAL_RANK", "0"))
     if not on_dev:
         local = local % max(1, torch.cuda.device_count())
