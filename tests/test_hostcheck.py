@@ -25,7 +25,7 @@ def test_leaf_message_model_against_python_str(tmp_path):
     """tools/hostcheck/leaf_message_model.c walks through leaf_message_lds's steps on the host (the divisions, the fixed-point digits,
     the big-endian collection, the byte swap, the shift by the leading zeros): 0, every power of ten and its neighbours, p - 1,
     2^128 - 1 and 200 000 random values of every length must come out as Python's str() writes them (merkle.py:13-14 hashes
-    `bytes(da)`, and FieldElement.__bytes__, algebra.py:67-68, is the decimal string of the value)."""
+    `bytes(da)`, and FieldElement.__bytes__, algebra.py:56-57, is the decimal string of the value)."""
     exe = str(tmp_path / "leaf_message_model")
     subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(SRC, "leaf_message_model.c")])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
