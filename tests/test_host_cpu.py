@@ -344,3 +344,42 @@ def test_library_challenge_with_the_root_dropped_in_last():
             assert out.raw == shake_256(pickle.dumps(items + [root])).digest(outlen), lens
     out = ctypes.create_string_buffer(32)
     assert lib.sc_transcript_challenge(b"x" * 256, (ctypes.c_uint32 * 1)(256), 1, bytes(64), out, 32) == starkcore.SC_ERR_UNSUPPORTED
+
+
+def test_inversion_chain_of_the_division_kernel_spends_143_products_on_p_minus_2():
+    """csrc/field.cuh: mont_inv on the device follows an addition chain instead of square-and-multiply over the 128 exponent bits.
+    The chain, restated on EXPONENTS (a squaring doubles, a product adds), must end at p - 2, with 126 squarings and 17 products."""
+    p = 1 + 407 * (1 << 119)
+    count = {"sq": 0, "mul": 0}
+
+    def sqn(e, n):
+        count["sq"] += n
+        return e << n
+
+    def mul(a, b):
+        count["mul"] += 1
+        return a + b
+    x = 1
+    x2 = mul(sqn(x, 1), x)
+    x3 = mul(sqn(x2, 1), x)
+    x6 = mul(sqn(x3, 3), x3)
+    x7 = mul(sqn(x6, 1), x)
+    x14 = mul(sqn(x7, 7), x7)
+    x28 = mul(sqn(x14, 14), x14)
+    x29 = mul(sqn(x28, 1), x)
+    x58 = mul(sqn(x29, 29), x29)
+    x59 = mul(sqn(x58, 1), x)
+    x118 = mul(sqn(x59, 59), x59)
+    y = mul(sqn(x118, 1), x)
+    assert y == (1 << 119) - 1
+    z = mul(y, x)
+    w = mul(sqn(z, 1), z)
+    w = mul(sqn(w, 3), z)
+    w = mul(sqn(w, 2), z)
+    w = mul(sqn(w, 1), z)
+    w = sqn(w, 1)
+    assert w == 406 * (1 << 119)
+    assert mul(w, y) == p - 2
+    assert (count["sq"], count["mul"]) == (126, 17)
+    # ... and square-and-multiply, least significant bit first as mont_pow128 does it: one squaring per bit position, one product per set bit
+    assert (p - 2).bit_length() + bin(p - 2).count("1") == 252
