@@ -824,6 +824,32 @@ def test_pool_cap_and_trim(sc):
         sc.set_tuning("pool_cap_mb", 72 * 1024)
 
 
+def test_fri_prove_in_one_call_refuses_what_it_cannot_answer(sc):
+    """sc_fri_prove_dev checks its arguments before anything is enqueued: no rounds, a length that is not a power of two, more
+    colinearity tests than the last codeword has points (fri.py:36-51 could never sample them), an answer buffer that is too small
+    -- and a PINNED answer buffer that is smaller than the caller says, which the query kernel would write past."""
+    lib = sc.lib()
+    N, rounds, s = 1 << 8, 3, 4
+    g, om = po.GENERATOR, po.primitive_nth_root(N)
+    vec = sc.DeviceVector.from_bytes(packed(9300, N))
+    need = 1 << 20
+
+    def rc(n=N, r=rounds, tests=s, answers=None, nbytes=need):
+        answers = answers if answers is not None else ctypes.create_string_buffer(need)
+        roots_out, last_raw = ctypes.create_string_buffer(64 * max(r, 1)), ctypes.create_string_buffer(16 * N)
+        top_out = (ctypes.c_uint64 * max(tests, 1))()
+        return lib.sc_fri_prove_dev(vec.ptr, n, sc.fe_bytes(g), sc.fe_bytes(om), r, tests, b"", (ctypes.c_uint32 * 1)(), 0, 0, None, None, 0,
+                                    None, None, roots_out, None, last_raw, top_out, None, answers, nbytes, None)
+    assert rc() == 0                                             # the shape itself is fine ...
+    assert rc(r=0) < 0 and rc(n=N - 1) < 0                       # ... these are not
+    assert rc(tests=(N >> (rounds - 1)) + 1) == sc.SC_ERR_UNSUPPORTED
+    assert rc(nbytes=64) < 0
+    small = sc.HostBuffer(4096)                                  # pinned, 4 KiB: the openings of this proof need more
+    assert rc(answers=ctypes.c_void_p(small.ptr.value), nbytes=need) < 0
+    assert b"too small" in lib.sc_last_error()
+    assert rc() == 0                                             # and the library is none the worse for it
+
+
 @pytest.mark.parametrize("logN,s,prior_count", [(6, 2, 0), (10, 8, 3), (13, 40, 1), (18, 40, 2)])
 def test_fri_prove_in_one_call_through_the_cabi(sc, logN, s, prior_count):
     """sc_fri_prove_dev (reference code/fri.py:115-130) called as a C caller would: the commit phase's roots against the oracle's
