@@ -57,3 +57,20 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".cuh", ".h")):
                 txt = open(os.path.join(root, fn), errors="replace").read()
                 assert "py_oracle" not in txt and "stark_oracle" not in txt and "libstark_oracle" not in txt, fn
+
+
+def test_header_names_every_tuning_key_the_library_takes():
+    """sc_set_tuning's keys live in a chain of string comparisons (csrc/core.hip) and in a comment of include/starkcore.h: the
+    comment must name every key the code takes (a knob nobody can find is a knob nobody uses -- or resets)"""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    src = open(os.path.join(root, "stark-anatomy_amd", "csrc", "core.hip")).read()
+    body = src[src.index("int sc_set_tuning("):]
+    body = body[:body.index("\nint ", 10)]
+    keys = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body)) or set(re.findall(r'"([a-z_0-9]+)"', body))
+    assert len(keys) >= 15, keys
+    header = open(os.path.join(root, "include", "starkcore.h")).read()
+    comment = header[:header.index("int sc_set_tuning(")]
+    comment = comment[comment.rindex("/*"):]
+    missing = sorted(k for k in keys if '"%s"' % k not in comment)
+    assert not missing, missing
