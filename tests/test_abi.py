@@ -74,3 +74,17 @@ def test_header_names_every_tuning_key_the_library_takes():
     comment = comment[comment.rindex("/*"):]
     missing = sorted(k for k in keys if '"%s"' % k not in comment)
     assert not missing, missing
+
+
+def test_integration_notes_list_every_environment_variable():
+    """every STARKCORE_* variable the sources read is in INTEGRATION.md's table"""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    found = set()
+    for path in glob.glob(os.path.join(root, "stark-anatomy_amd", "csrc", "*.*")) + glob.glob(os.path.join(root, "stark-anatomy_amd", "*.py")) + [os.path.join(root, "bench.py")]:
+        if path.endswith((".hip", ".h", ".cuh", ".py")):
+            found |= set(re.findall(r"STARKCORE_[A-Z_0-9]+", open(path).read()))
+    notes = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(v for v in found if v not in notes)
+    assert found and not missing, missing
