@@ -13,97 +13,108 @@ def _wrap(ints, field):
     return [FieldElement(v, field) for v in ints]
 
 
+def _last_nonzero(ints):
+    k = len(ints) - 1
+    while k >= 0 and ints[k] == 0:
+        k -= 1
+    return k
+
+
 class Polynomial:
     def __init__(self, coefficients):
-        self.coefficients = [c for c in coefficients]
+        self.coefficients = list(coefficients)
+
+    def _values(self):
+        return [c.value for c in self.coefficients]
 
     # -- structure ---------------------------------------------------------------------------
     def degree(self):
         """Index of the last non-zero coefficient; -1 for the zero polynomial (univariate.py:7-17)."""
-        for i in range(len(self.coefficients) - 1, -1, -1):
-            if self.coefficients[i].value != 0:
-                return i
-        return -1
+        return _last_nonzero(self._values())
 
     def is_zero(self):
-        return all(c.value == 0 for c in self.coefficients)
+        return _last_nonzero(self._values()) < 0
 
     def leading_coefficient(self):
+        # (the zero polynomial indexes with -1 like the reference: last list entry, IndexError on an empty list)
         return self.coefficients[self.degree()]
 
-    def __eq__(self, other):
-        d = self.degree()
-        if d != other.degree():
+    def __eq__(self, rhs):
+        """univariate.py:66-71: equal degrees, then the reference walks the WHOLE of the left list against the right one, so a
+        left operand with more trailing zeros than the right list is long raises IndexError once the real coefficients agree."""
+        mine, theirs = self._values(), rhs._values()
+        top = _last_nonzero(mine)
+        if top != _last_nonzero(theirs):
             return False
-        if d == -1:
-            return True
-        return all(self.coefficients[i] == other.coefficients[i] for i in range(len(self.coefficients)))
+        if mine[:top + 1] != theirs[:top + 1]:
+            return False
+        if top >= 0 and len(mine) > len(theirs):
+            raise IndexError("list index out of range")
+        return True
 
-    def __neq__(self, other):
-        return not self.__eq__(other)
+    def __neq__(self, rhs):
+        return not self == rhs
 
     __hash__ = None
 
     def __str__(self):
-        return "[" + ",".join(str(c) for c in self.coefficients) + "]"
+        return "[%s]" % ",".join(str(c) for c in self.coefficients)
 
     # -- ring operations ---------------------------------------------------------------------
     def __neg__(self):
-        return Polynomial([-c for c in self.coefficients])
+        if not self.coefficients:
+            return Polynomial([])
+        field = self.coefficients[0].field
+        return Polynomial(_wrap([(field.p - v) % field.p for v in self._values()], field))
 
-    def __add__(self, other):
+    def __add__(self, rhs):
         # a zero operand hands back the other operand itself (univariate.py:22-26)
-        if self.degree() == -1:
-            return other
-        if other.degree() == -1:
+        if self.is_zero():
+            return rhs
+        if rhs.is_zero():
             return self
         field = self.coefficients[0].field
         p = field.p
-        a, b = self.coefficients, other.coefficients
-        out = [0] * max(len(a), len(b))
-        for i, c in enumerate(a):
-            out[i] = c.value
-        for i, c in enumerate(b):
-            out[i] = (out[i] + c.value) % p
-        return Polynomial(_wrap(out, field))
+        a, b = self._values(), rhs._values()
+        if len(a) < len(b):
+            a, b = b, a
+        return Polynomial(_wrap([(v + b[i]) % p if i < len(b) else v for i, v in enumerate(a)], field))
 
-    def __sub__(self, other):
-        return self.__add__(-other)
+    def __sub__(self, rhs):
+        return self + (-rhs)
 
     # operands at least this long go through the GPU transform instead of the schoolbook loop (same coefficients,
     # same list length; the threshold stays above fast_multiply's own "degree < 8 -> lhs * rhs" fallback)
     FAST_MUL_MIN_LEN = 32
 
-    def __mul__(self, other):
-        if self.coefficients == [] or other.coefficients == []:
+    def __mul__(self, rhs):
+        if not self.coefficients or not rhs.coefficients:
             return Polynomial([])
         field = self.coefficients[0].field
-        if min(len(self.coefficients), len(other.coefficients)) >= Polynomial.FAST_MUL_MIN_LEN and field.p == Field.P_MAIN:
+        if min(len(self.coefficients), len(rhs.coefficients)) >= Polynomial.FAST_MUL_MIN_LEN and field.p == Field.P_MAIN:
             # Decide on DEGREES, not list lengths: lists may carry trailing zeros, and fast_multiply hands products of
             # degree < 8 straight back to `lhs * rhs` (ntt.py:44-45) -- taking the fast path for those would recurse forever.
-            dl, dr = self.degree(), other.degree()
+            dl, dr = self.degree(), rhs.degree()
             if dl + dr >= 8:
                 # Polynomial.__mul__ dominates MPolynomial.evaluate_symbolic (fast_stark.py:109-110) at scale; the product is
                 # the same polynomial, so only the time changes
                 from ntt import fast_multiply
-                full_len = len(self.coefficients) + len(other.coefficients) - 1
+                full_len = len(self.coefficients) + len(rhs.coefficients) - 1
                 order = 1 << max(1, (dl + dr).bit_length())
-                product = fast_multiply(self, other, field.primitive_nth_root(order), order).coefficients
+                product = fast_multiply(self, rhs, field.primitive_nth_root(order), order).coefficients
                 return Polynomial(product + [field.zero()] * (full_len - len(product)))
-        return self._schoolbook_mul(other)
+        return self._schoolbook_mul(rhs)
 
-    def _schoolbook_mul(self, other):
+    def _schoolbook_mul(self, rhs):
         """univariate.py:48-57: len(a) + len(b) - 1 coefficients, trailing zeros included"""
         field = self.coefficients[0].field
         p = field.p
-        b = [c.value for c in other.coefficients]
+        b = rhs._values()
         out = [0] * (len(self.coefficients) + len(b) - 1)
-        for i, c in enumerate(self.coefficients):
-            x = c.value
-            if x == 0:
-                continue
-            for j, y in enumerate(b):
-                out[i + j] = (out[i + j] + x * y) % p
+        for i, x in enumerate(self._values()):
+            if x:
+                for j, y in enumerate(b):
+                    out[i + j] = (out[i + j] + x * y) % p
         return Polynomial(_wrap(out, field))
 
     def divide(numerator, denominator):
@@ -116,10 +127,10 @@ class Polynomial:
             return (Polynomial([]), numerator)
         field = denominator.coefficients[0].field
         p = field.p
-        den = [c.value for c in denominator.coefficients]
+        den = denominator._values()
         # the reference's running remainder grows to the subtractee's length when the denominator list
         # carries trailing zeros; keep the same list length
-        rem = [c.value for c in numerator.coefficients]
+        rem = numerator._values()
         rem += [0] * max(0, (dn - dd) + len(den) - len(rem))
         quo = [0] * (dn - dd + 1)
         lead_inv = pow(den[dd], -1, p)
@@ -135,65 +146,82 @@ class Polynomial:
                 top -= 1
         return Polynomial(_wrap(quo, field)), Polynomial(_wrap(rem, field))
 
-    def __truediv__(self, other):
-        quo, rem = Polynomial.divide(self, other)
-        assert(rem.is_zero()), "cannot perform polynomial division because remainder is not zero"
-        return quo
+    def __truediv__(self, rhs):
+        quotient, remainder = self.divide(rhs)            # (a zero divisor: divide gives None and the unpacking raises TypeError)
+        assert remainder.is_zero(), "cannot perform polynomial division because remainder is not zero"
+        return quotient
 
-    def __mod__(self, other):
-        quo, rem = Polynomial.divide(self, other)
-        return rem
+    def __mod__(self, rhs):
+        _, remainder = self.divide(rhs)
+        return remainder
 
     def __xor__(self, exponent):
+        """self^exponent; the list is exponent * (len - 1) + 1 long whatever the order of the products, so the binary method
+        runs from the low bit here (univariate.py:140-150 runs from the high bit)."""
         if self.is_zero():
             return Polynomial([])
-        one = Polynomial([self.coefficients[0].field.one()])
-        if exponent == 0:
-            return one
-        acc = one
-        for i in reversed(range(exponent.bit_length())):
-            acc = acc * acc
-            if (exponent >> i) & 1:
-                acc = acc * self
-        return acc
+        power = Polynomial([self.coefficients[0].field.one()])
+        square, e = self, exponent
+        while e > 0:
+            if e & 1:
+                power = power * square
+            e >>= 1
+            if e:
+                square = square * square
+        return power
 
     # -- evaluation / interpolation ----------------------------------------------------------
     def evaluate(self, point):
         field = point.field
         p = field.p
         x = point.value
-        acc, xi = 0, 1
-        for c in self.coefficients:
-            acc = (acc + c.value * xi) % p
-            xi = xi * x % p
+        acc = 0
+        for v in reversed(self._values()):                # Horner
+            acc = (acc * x + v) % p
         return FieldElement(acc, field)
 
     def evaluate_domain(self, domain):
         return [self.evaluate(d) for d in domain]
 
+    @staticmethod
+    def _zerofier_ints(xs, p):
+        """coefficients of prod (X - x) over xs, low order first"""
+        out = [1]
+        for x in xs:
+            out = [((out[k - 1] if k else 0) - (x * out[k] if k < len(out) else 0)) % p for k in range(len(out) + 1)]
+        return out
+
     def interpolate_domain(domain, values):
-        """Lagrange interpolation (univariate.py:107-121)."""
-        assert(len(domain) == len(values)), "number of elements in domain does not match number of values -- cannot interpolate"
-        assert(len(domain) > 0), "cannot interpolate between zero points"
+        """Lagrange interpolation with the results (values AND list length len(domain)) of univariate.py:107-121, in
+        O(n^2) instead of its O(n^3): the master polynomial Z = prod (X - x_j) once, then for every point the synthetic
+        division Z / (X - x_i) weighted by y_i / prod_{j != i} (x_i - x_j).  The reference inverts each difference through
+        Field.inverse, which maps 0 to 0 (algebra.py:87-89): a repeated abscissa silently drops its terms, and so it does here."""
+        n = len(domain)
+        assert n == len(values), "number of elements in domain does not match number of values -- cannot interpolate"
+        assert n > 0, "cannot interpolate between zero points"
         field = domain[0].field
-        x = Polynomial([field.zero(), field.one()])
-        acc = Polynomial([])
-        for i in range(len(domain)):
-            prod = Polynomial([values[i]])
-            for j in range(len(domain)):
-                if j == i:
-                    continue
-                prod = prod * (x - Polynomial([domain[j]])) * Polynomial([(domain[i] - domain[j]).inverse()])
-            acc = acc + prod
-        return acc
+        p = field.p
+        xs = [d.value for d in domain]
+        master = Polynomial._zerofier_ints(xs, p)
+        out = [0] * n
+        for i, xi in enumerate(xs):
+            denom = 1
+            for j, xj in enumerate(xs):
+                if j != i:
+                    denom = denom * (xi - xj) % p
+            weight = values[i].value * pow(denom, -1, p) % p if denom else 0
+            if weight == 0:
+                continue
+            carry = 0
+            for k in range(n, 0, -1):                      # quotient of master by (X - xi), high order first
+                carry = (master[k] + xi * carry) % p
+                out[k - 1] = (out[k - 1] + weight * carry) % p
+        return Polynomial(_wrap(out, field))
 
     def zerofier_domain(domain):
+        """prod (X - d) over the domain, len(domain) + 1 coefficients (univariate.py:123-128)"""
         field = domain[0].field
-        x = Polynomial([field.zero(), field.one()])
-        acc = Polynomial([field.one()])
-        for d in domain:
-            acc = acc * (x - Polynomial([d]))
-        return acc
+        return Polynomial(_wrap(Polynomial._zerofier_ints([d.value for d in domain], field.p), field))
 
     def scale(self, factor):
         """coefficient i times factor^i (univariate.py:153-154)."""
@@ -216,9 +244,7 @@ def test_colinearity(points):
             # of non-zero slope (a constant interpolant has degree 0, a parabola 2).  The verifier runs this 3 s (rounds - 1)
             # times (fri.py:207); the cross product is ~40x cheaper than the Lagrange interpolation.
             return (y1 - y0) * (x2 - x0) == (y2 - y0) * (x1 - x0) and y1 != y0
-    domain = [p[0] for p in points]
-    values = [p[1] for p in points]
-    polynomial = Polynomial.interpolate_domain(domain, values)
+    polynomial = Polynomial.interpolate_domain([x for x, _ in points], [y for _, y in points])
     return polynomial.degree() == 1
 
 

@@ -160,14 +160,14 @@ def test_trace_at_omicron_x_is_read_off_the_trace_codeword_not_scaled_and_transf
 
 
 @pytest.mark.parametrize("device_min", [32, 10 ** 9])
-def test_fast_stark(device_min, monkeypatch):      # code/test_fast_stark.py:9-65, 3 trials, seeded
+def test_fast_stark(device_min, monkeypatch):      # code/test_fast_stark.py:9-65 with its 20 chained trials (:18), seeded
     monkeypatch.setattr(FastStark, "DEVICE_MIN", device_min)
     field = Field.main()
     rng = _seed_urandom(2024)
     expansion_factor, num_colinearity_checks, security_level = 4, 2, 2
     rp = RescuePrime()
     output_element = field.sample(bytes(b'0xdeadbeef'))
-    for trial in range(3):
+    for trial in range(20):
         input_element = output_element
         output_element = rp.hash(input_element)
         num_cycles, state_width = rp.N + 1, rp.m
