@@ -36,8 +36,12 @@ for p in (PKG, REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_ELEMENT_PER_TRANSFORM = 32   # read once + write once, 16-byte elements
+# the workloads (what a step IS) and the set-up of the sharded transform live in the package; this script times them
+from workloads import (nth_root, sharded_census, stark_census, census_record, stark_prove_measure,          # noqa: E402
+                       plain_stark_prove_measure)
+from sharded_setup import (HBM_PEAK_GBS, BYTES_PER_ELEMENT_PER_TRANSFORM, strong_record, sharded_setup,    # noqa: E402
+                           stage_breakdown, node_facts, collective_label)
+
 CLOCK_RAMP_MS = 150.0      # untimed load between the contract's window (`value`) and its repetition (`clock_ramp.steady_state`)
 
 
@@ -56,7 +60,10 @@ def cpu_baseline(sample_log2n):
     dt = time.perf_counter() - t0
     assert zs == xs
     out = {"value": 2 * n / dt, "unit": "field-elements/s", "cores": 1, "kind": "port",
-           "sample": "pure-Python port of code/ntt.py ntt+intt at n=2^%d, %.1f s, host has %d cores" % (sample_log2n, dt, os.cpu_count())}
+           "sample": "pure-Python port of code/ntt.py ntt+intt at n=2^%d, %.1f s, host has %d cores; the port works on ints with the built-in "
+                     "pow(root, i, p) where code/ntt.py runs FieldElement.__xor__ on objects (algebra.py:38-45), so it is about 6x FASTER "
+                     "than the reference itself (5.5-8.7 k elements/s, SURVEY.md App. C): every GPU/CPU ratio quoted from it is conservative"
+                     % (sample_log2n, dt, os.cpu_count())}
     try:
         m = 1 << 18
         data = synth.synth_packed(1, m).tobytes()
@@ -112,85 +119,6 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
-
-
-def nth_root(n):
-    import synth
-    r, order = GEN, 1 << 119
-    while order != n:
-        r, order = r * r % synth.P, order >> 1
-    return r
-
-
-GEN = 85408008396924667383611388730472331217
-
-
-def sharded_census(log_fri, rank, world, dev, stream, group=None, checks=40):
-    """BASELINE configs[4]: the polynomial-core call census of FastStark.prove (reference code/fast_stark.py:101-151; SURVEY.md
-    8(d)) replayed on the SHARDED layout at fri_domain_length 2^log_fri, omicron_domain_length 2^(log_fri-2), 2 registers:
-    4 LDEs to 2^log_fri (ShardedNtt.coset_evaluate: one all-to-all each) + 3 sharded Merkle commits, 2 sharded coset divisions
-    at 2^(log_fri-2) (3 all-to-alls each), ShardedFri.prove on the last codeword (no element exchange), 4 * checks openings on
-    each of the three committed codewords.  Returns per-stage seconds of this rank and the bytes it sent."""
-    import numpy as np
-    import torch
-    import synth
-    from algebra import Field
-    from fri import Fri
-    from ip import ProofStream
-    from sharded import ShardedNtt, ShardedFri
-    field = Field.main()
-    Nf, No = 1 << log_fri, 1 << (log_fri - 2)
-    omega, omicron = field.primitive_nth_root(Nf), field.primitive_nth_root(No)
-    ntt_f = ShardedNtt(log_fri, omega.value, rank, world, dev, group=group)
-    ntt_o = ShardedNtt(log_fri - 2, omicron.value, rank, world, dev, group=group)
-    polys = [torch.from_numpy(synth.synth_packed(60 + i, No // 2).view(np.int64)).to(dev) for i in range(4)]
-    fr = Fri(field.generator(), omega, Nf, 4, checks)
-    sfri = ShardedFri(fr, ntt_f.n1, rank, world, dev, group=group)
-    C = ntt_f.n2
-
-    def sync():
-        torch.cuda.synchronize()
-
-    sync()
-    times = {}
-    t0 = time.perf_counter()
-    ps = ProofStream()
-    slabs, layers = [], []
-    for i, pv in enumerate(polys):                       # 2 boundary quotients, randomizer, combination
-        slab = torch.empty(ntt_f.local_shape(False), dtype=torch.int64, device=dev)
-        ntt_f.coset_evaluate(pv, GEN, slab)
-        slabs.append(slab)
-        if i < 3:
-            sync()
-            layers.append(sfri.commit(slab, C))
-            ps.push(layers[-1]["root"])
-    sync()
-    times["lde_and_commit"] = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    den = ntt_o.slab_of(polys[3][:No // 4], "census_den").clone()
-    q = torch.empty(ntt_o.local_shape(True), dtype=torch.int64, device=dev)
-    for i in range(2):                                   # 2 transition quotients (fast_stark.py:113)
-        num = ntt_o.slab_of(polys[i], "census_num")
-        ntt_o.coset_divide(num, den, GEN, q)
-    sync()
-    times["coset_divide"] = time.perf_counter() - t1
-    t2 = time.perf_counter()
-    indices = sfri.prove(slabs[3], ps)
-    sync()
-    times["fri_prove"] = time.perf_counter() - t2
-    t3 = time.perf_counter()
-    dup = [i for i in indices] + [(i + 4) % Nf for i in indices]
-    quad = sorted(dup + [(i + Nf // 2) % Nf for i in dup])
-    for layer in layers:
-        entries, paths = sfri._open(layer, quad)
-        for e, pth in zip(entries, paths):
-            ps.push(e)
-            ps.push(pth)
-    times["openings"] = time.perf_counter() - t3
-    times["total"] = time.perf_counter() - t0
-    info = {"fri_rounds": fr.num_rounds(), "proof_objects": len(ps.objects), "proof_sha256_16": __import__("hashlib").sha256(ps.serialize()).hexdigest()[:16],
-            "all_to_all_bytes_sent_per_rank": ntt_f.bytes_exchanged + ntt_o.bytes_exchanged, "roots": [l["root"].hex()[:16] for l in layers]}
-    return times, info
 
 
 def main():
@@ -549,297 +477,6 @@ def main():
         sys.exit("round trip mismatch")
 
 
-def strong_record(log2n, world, seconds_per_pair, roundtrip_ok, corner_turn, bytes_sent_per_rank_per_pair, extra=None):
-    """one member of the north_star series: forward + inverse 2^log2n at `world` GPUs, absolute and as a fraction of the HBM
-    roofline (32 B per element per transform, over the N x 8 TB/s of the GPUs taking part)"""
-    n = 1 << log2n
-    rec = {"log2n": log2n, "n_gpus": world, "ms_per_pair": seconds_per_pair * 1e3, "elements_per_s": 2 * n / seconds_per_pair,
-           "alg_GBps": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * n / seconds_per_pair / 1e9,
-           "frac": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * n / seconds_per_pair / 1e9 / (HBM_PEAK_GBS * world),
-           "roundtrip_bit_exact": bool(roundtrip_ok), "roundtrip_check": "all 2^%d elements" % log2n,
-           "corner_turn": corner_turn, "bytes_sent_per_rank_per_pair": bytes_sent_per_rank_per_pair}
-    if extra:
-        rec.update(extra)
-    return rec
-
-
-_DIRECT_PREFLIGHT = None          # the job's one pre-flight of the direct-store corner turn: {"passed": bool, ...}
-
-
-def direct_store_preflight(rank, world, dev, dist, backend):
-    """The ingredients of the direct-store corner turn -- a HIP IPC region of one process opened in another, kernels of one GPU storing
-    into another's memory -- tried by a CHILD of every rank first (stark-anatomy_amd/direct_preflight.py): between two physical GPUs they have
-    never run, and what goes wrong there may be a GPU memory fault that ends the process instead of an error the library could
-    return.  The ranks use the direct-store forms only if every child came back with status 0.  Once per job."""
-    global _DIRECT_PREFLIGHT
-    if _DIRECT_PREFLIGHT is not None:
-        return _DIRECT_PREFLIGHT
-    import shutil
-    import subprocess
-    import tempfile
-    import torch
-    on_dev = backend == "nccl"
-    # the rendezvous directory: rank 0 makes it, its name travels as numbers (a plain tensor broadcast, like every other exchange here)
-    made = tempfile.mkdtemp(prefix="starkcore_preflight_") if rank == 0 else ""
-    name = torch.zeros(256, dtype=torch.int32)
-    if rank == 0:
-        raw = made.encode()
-        assert len(raw) < 255, made
-        name[0] = len(raw)
-        name[1:1 + len(raw)] = torch.tensor(list(raw), dtype=torch.int32)
-    name = name.to(dev) if on_dev else name
-    dist.broadcast(name, 0)
-    name = name.cpu().tolist()
-    where = bytes(name[1:1 + name[0]]).decode()
-    local = dev.index if on_dev and dev.index is not None else int(os.environ.get("LOCAL_RANK", "0"))
-    if not on_dev:
-        local = local % max(1, torch.cuda.device_count())
-    t0 = time.perf_counter()
-    try:
-        child = subprocess.run([sys.executable, os.path.join(REPO, "stark-anatomy_amd", "direct_preflight.py"), str(rank), str(world), str(local), where],
-                               capture_output=True, text=True, timeout=120, env=dict(os.environ, STARKCORE_NO_TORCH="1"))
-        status, said = child.returncode, child.stderr.strip().splitlines()[-1:] if child.stderr.strip() else []
-    except subprocess.TimeoutExpired:
-        status, said = -1, ["no answer within 120 s"]
-    t = torch.tensor([status == 0], dtype=torch.int32, device=dev if on_dev else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    passed = int(t.item()) == 1
-    if status != 0:
-        sys.stderr.write("bench.py: direct-store pre-flight, rank %d: status %d %s\n" % (rank, status, " ".join(said)))
-    dist.barrier()
-    if rank == 0:
-        shutil.rmtree(where, ignore_errors=True)
-    _DIRECT_PREFLIGHT = {"form": "direct-store pre-flight (a child of every rank exports, maps and stores across processes)", "passed": passed,
-                         "this_rank_status": status, "seconds": round(time.perf_counter() - t0, 2)}
-    return _DIRECT_PREFLIGHT
-
-
-def sharded_setup(args, log2n, rank, world, dev, dist, backend, probe_steps=4, only=None):
-    """The sharded transform of length 2^log2n ready to be timed: every form of the corner turn this job can run is built, its
-    forward transform compared with the first form's element for element, its round trip checked, and timed for a few steps;
-    the fastest correct one is returned as (step, engine, (x, y, z), description, probes).  The choice is the same on every
-    rank: a form is dropped on ALL ranks as soon as any rank fails to build it or gets a wrong result (the ranks agree on a flag
-    before the next collective), and the probe times are all-reduced.  only: a (label, kwargs) pair to build without probing."""
-    import torch
-    from sharded import ShardedNtt, init_native_comm
-    n = 1 << log2n
-    root = nth_root(n)
-    on_dev = backend == "nccl"
-
-    def agreed(flag):
-        """True iff `flag` is true on every rank"""
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return int(t.item()) == 1
-
-    forms = []                                    # (label, ShardedNtt kwargs)
-    own = dict(always_exchange=True) if args.force_diag_exchange else {}
-    if only is not None:
-        forms = [only]
-    elif world == 1 and not args.force_diag_exchange:
-        forms.append(("one rank: nothing to exchange, the column stage writes the rank's own block in place", {}))
-    else:
-        if world > 1 and not args.force_diag_exchange:
-            # the most conservative form first (it is the reference the others are compared with): one plain all_to_all_single
-            # that carries the rank's own block as well
-            forms.append(("torch.distributed all_to_all_single, own block included", dict(always_exchange=True)))
-        forms.append(("torch.distributed, one blocking exchange", dict(own)))
-        forms.append(("torch.distributed, 4 asynchronous row blocks overlapped with the row stage", dict(own, overlap_chunks=4)))
-        native = False
-        if on_dev and not args.no_native_exchange:
-            try:
-                native = init_native_comm(rank, world, dev)
-            except Exception as e1:       # noqa: BLE001
-                sys.stderr.write("bench.py: the library's RCCL communicator is unavailable (%r)\n" % (e1,))
-            native = agreed(native)
-        if native:
-            forms.append(("library RCCL communicator, one exchange on the compute stream", dict(own, native_exchange=True)))
-            forms.append(("library RCCL communicator, 2 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=2)))
-            forms.append(("library RCCL communicator, 4 row blocks on the communication stream overlapped with the row stage", dict(own, native_exchange=True, overlap_chunks=4)))
-        preflight = None
-        if not args.no_direct_store and world > 1:
-            preflight = direct_store_preflight(rank, world, dev, dist, backend)
-        if not args.no_direct_store and (preflight is None or preflight["passed"]):
-            # no collective at all: the column stage stores block h straight into rank h's receive buffer (HIP IPC over xGMI),
-            # a flag barrier, the row stage -- with the default split and, above 2^16, with the square one (fewer, longer rows)
-            forms.append(("direct store: column stage writes into the peers' receive buffers (HIP IPC), flag barrier, no collective", dict(direct_store=True)))
-            if log2n >= 20:
-                forms.append(("direct store, square split n1 = 2^%d" % (log2n // 2), dict(direct_store=True, log_n1=log2n // 2)))
-        if log2n >= 20 and native:
-            forms.append(("library RCCL communicator, one exchange, square split n1 = 2^%d" % (log2n // 2), dict(own, native_exchange=True, log_n1=log2n // 2)))
-    candidates, y_ref, probes = [], None, []
-    if only is None and world > 1 and _DIRECT_PREFLIGHT is not None:
-        probes.append(dict(_DIRECT_PREFLIGHT))
-    for label, kw in forms:
-        eng = x = y = z = None
-        built = True
-        try:
-            eng = ShardedNtt(log2n, root, rank, world, dev, **kw)
-            if kw.get("native_exchange"):
-                eng.stages.native = True
-            if kw.get("direct_store") and not eng.direct_store:
-                raise RuntimeError("the peers' regions could not be mapped (%s)" % "; ".join(eng.corner_turn_setup))
-            x = eng.synthetic_input(seed=1)
-            y = torch.empty(eng.local_shape(False), dtype=torch.int64, device=dev)
-            z = torch.empty_like(x)
-        except Exception as e1:       # noqa: BLE001
-            built = False
-            sys.stderr.write("bench.py: corner turn form '%s' unavailable on rank %d (%r)\n" % (label, rank, e1))
-        if not agreed(built):                      # nobody enters this form's collectives unless everybody can
-            probes.append({"form": label, "available": False})
-            continue
-
-        def step(eng=eng, x=x, y=y, z=z):
-            eng.forward(x, y)
-            eng.inverse(y, z)
-
-        step()
-        dist.barrier()
-        torch.cuda.synchronize()
-        same = torch.equal(z, x)
-        if kw.get("log_n1") and y_ref is not None:
-            pass                                   # another split leaves another slab layout: the round trip is its check
-        elif y_ref is None and not kw.get("log_n1"):
-            y_ref = y.clone()
-        elif y_ref is not None:
-            same = same and torch.equal(y_ref, y)
-        if kw.get("direct_store"):
-            same = same and eng.stages.direct_timed_out() == 0
-        if not agreed(same):
-            sys.stderr.write("bench.py: corner turn form '%s' gave a WRONG result (rank %d: %s)\n" % (label, rank, "ok here" if same else "mismatch"))
-            probes.append({"form": label, "available": True, "correct": False})
-            if kw.get("direct_store"):
-                eng.stages.release_direct()
-            continue
-        for _ in range(2):
-            step()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(probe_steps):
-            step()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if on_dev else "cpu")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        sec = float(t.item()) / probe_steps
-        # once more after the timed steps: a form whose hand-over only fails now and then must not be chosen either
-        same = torch.equal(z, x) and (not kw.get("direct_store") or eng.stages.direct_timed_out() == 0)
-        if not agreed(same):
-            sys.stderr.write("bench.py: corner turn form '%s' gave a WRONG result after %d steps (rank %d: %s)\n" % (label, probe_steps + 3, rank, "ok here" if same else "mismatch"))
-            probes.append({"form": label, "available": True, "correct": False, "failed_after_steps": probe_steps + 3})
-            if kw.get("direct_store"):
-                eng.stages.release_direct()
-            continue
-        candidates.append((sec, label, step, eng, (x, y, z), kw))
-        probes.append({"form": label, "available": True, "correct": True, "ms_per_pair": sec * 1e3})
-        if kw.get("direct_store"):
-            probes[-1]["setup"] = list(eng.corner_turn_setup)       # which kind of region came up (fine-grained first, then coarse-grained)
-        if kw.get("direct_store"):
-            probes[-1]["receive_region_memory"] = eng.stages.region_kind()
-    if not candidates:
-        raise RuntimeError("no working corner turn")
-    best = min(candidates, key=lambda c: c[0])         # the same choice on every rank (times are all-reduced)
-    desc = best[1] + "; probe ms/step: " + ", ".join("[%s] %.3f" % (c[1], c[0] * 1e3) for c in candidates)
-    for c in candidates:                               # the losers give their buffers (and mapped regions) back
-        if c is not best and getattr(c[3].stages, "direct", False):
-            dist.barrier()
-            c[3].stages.release_direct()
-    return best[2], best[3], best[4], desc, {"chosen": best[1], "chosen_kwargs": {k: v for k, v in best[5].items()}, "probes": probes}
-
-
-def stage_breakdown(eng, xyz, rank, world, dev, dist, backend, reps=10):
-    """Where a sharded transform's time goes, per direction: the column stage and the row stage of this rank timed ALONE with HIP
-    events (local kernels, no exchange: the stage object's cols / rows on scratch buffers), the whole transform the same way,
-    `exchange_and_waiting_us` = whole - cols - rows (the corner turn plus whatever the stages wait for: a derived figure -- in
-    the direct-store form the column stage's own stores ARE the exchange, so it also holds the slower remote stores).  Max over
-    ranks.  Bytes: what one rank sends to ONE peer per transform."""
-    import torch
-    x, y, z = xyz
-    st = eng.stages
-    G = world
-    on_dev = backend == "nccl"
-    stream = torch.cuda.current_stream(dev)
-    out = {}
-    if st is None:
-        return out
-    scratch_send = torch.empty((eng.n // G, 2), dtype=torch.int64, device=dev)
-    scratch_recv = torch.empty((eng.n // G, 2), dtype=torch.int64, device=dev)
-
-    def timed(fn):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if world > 1:
-            dist.barrier()
-        e0.record(stream)
-        for _ in range(reps):
-            fn()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], dtype=torch.float64, device=dev if on_dev else "cpu")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    for name, inv, src, dst in (("forward", 0, x, y), ("inverse", 1, y, z)):
-        cols = timed(lambda: eng._run(lambda: st.cols(inv, src, scratch_send, scratch_recv)))
-        rows = timed(lambda: eng._run(lambda: st.rows(inv, scratch_recv, dst, 0, 1, False)))
-        whole = timed((lambda: eng.forward(x, y)) if inv == 0 else (lambda: eng.inverse(y, z)))
-        out[name] = {"cols_us": cols, "rows_us": rows, "whole_us": whole, "exchange_and_waiting_us": whole - cols - rows}
-    # the timed stages have overwritten y / z with transforms of scratch data: restore the pair the caller checks
-    eng.forward(x, y)
-    eng.inverse(y, z)
-    torch.cuda.synchronize()
-    out["bytes_to_each_peer_per_transform"] = (eng.n // G // G) * 16 if G > 1 else 0
-    out["messages_per_rank_per_transform"] = G - 1
-    return out
-
-
-def node_facts(dev):
-    """what the first multi-GPU run should say about the node without a second run: RCCL / HIP versions, the peer-access matrix"""
-    import torch
-    facts = {}
-    try:
-        facts["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
-    except Exception as e:       # noqa: BLE001
-        facts["rccl_version"] = repr(e)[:80]
-    facts["hip_version"] = getattr(torch.version, "hip", None)
-    n = torch.cuda.device_count()
-    facts["visible_gpus"] = n
-    try:
-        facts["can_access_peer"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]
-    except Exception as e:       # noqa: BLE001
-        facts["can_access_peer"] = repr(e)[:80]
-    try:
-        facts["device_name"] = torch.cuda.get_device_name(dev)
-    except Exception:            # noqa: BLE001
-        pass
-    return facts
-
-
-def collective_label(backend, world, ngpu, shared_gpus):
-    if backend == "nccl":
-        return "nccl (RCCL), %d ranks on %d GPUs" % (world, ngpu)
-    return "gloo, host-staged: %d ranks sharing %d GPU(s) -- functional run, NOT a scaling measurement" % (world, ngpu)
-
-
-def census_record(times, info, log_fri, world, dist, backend, dev):
-    """max over ranks of every stage time (ms) + what rank 0 saw"""
-    import torch
-    keys = sorted(times)
-    t = torch.tensor([times[k] for k in keys], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    rec = {"log2_fri_domain": log_fri, "world_size": world}
-    for k, v in zip(keys, t.tolist()):
-        rec[k + "_ms"] = v * 1e3
-    rec.update(info)
-    return rec
-
-
 def run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gpus):
     """--workload stark_census: one step = the whole sharded census; value = ms per census (max over ranks)."""
     import torch
@@ -873,86 +510,6 @@ def run_census_workload(args, rank, world, dev, stream, dist, backend, shared_gp
                "stages_best_run": rec}
         emit(out)
     dist.destroy_process_group()
-
-
-def synthetic_stark_instance(log_fri, s=40):
-    """The synthetic configs[4] workload: the 2-register AIR (a, b) -> (b, a*a + b) over a trace of T = 2^(log_fri - 4) - 4 s rows,
-    so that the randomized trace has 2^(log_fri - 4) rows and the FRI domain 2^log_fri points (expansion factor 4).  Returns
-    (field, T, packed columns (bytes per register), air, boundary): the columns are handed to the prover as a device-resident
-    fast_stark.DeviceTrace -- a trace of 2^20 rows as the reference's list of lists is two million Python objects."""
-    from algebra import Field, FieldElement
-    from multivariate import MPolynomial
-    k = log_fri - 4
-    field = Field.main()
-    p = field.p
-    T = (1 << k) - 4 * s
-    from synth import synthetic_air_columns
-    col_a, col_b = synthetic_air_columns(T)
-    pack = lambda col: b"".join(map(int.to_bytes, col, itertools.repeat(16), itertools.repeat("little")))
-    v = MPolynomial.variables(5, field)                  # X, a, b, a', b'
-    air = [v[3] - v[2], v[4] - v[1] * v[1] - v[2]]
-    boundary = [(0, 0, FieldElement(col_a[0], field)), (0, 1, FieldElement(col_b[0], field)), (T - 1, 1, FieldElement(col_b[T - 1], field))]
-    return field, T, [pack(col_a), pack(col_b)], air, boundary
-
-
-def stark_prove_measure(log_fri, steps, warmup, rank, world, dev, dist, backend, phases=False):
-    """sharded_stark.ShardedFastStark.prove (reference code/fast_stark.py:76-178) on the synthetic 2-register AIR (a, b) -> (b, a*a + b)
-    with a 2^(log_fri - 4)-row randomized trace that is RESIDENT IN HBM as columns when the timed region starts: (seconds summed
-    over `steps` proofs, max over ranks per proof; record for rank 0).  Every rank must end with the same proof; rank 0 verifies
-    it with FastStark.verify outside the timed region.  phases: one more (untimed) proof with the per-phase breakdown."""
-    import hashlib
-    import torch
-    from fast_stark import DeviceTrace
-    from sharded_stark import ShardedFastStark
-    s = 40
-    field, T, packed, air, boundary = synthetic_stark_instance(log_fri, s)
-    stark = ShardedFastStark(field, 4, s, 2 * s, 2, T, rank, world, dev)
-    assert stark.fri_domain_length == 1 << log_fri
-    trace = DeviceTrace.from_packed(packed, field)
-    t0 = time.perf_counter()
-    tz, layer, root = stark.preprocess(device_resident=True)
-    torch.cuda.synchronize()
-    preprocess_s = time.perf_counter() - t0
-    for _ in range(warmup):
-        stark.prove(trace, air, boundary, tz, layer)
-    dist.barrier()
-    torch.cuda.synchronize()
-    totals, proof = [], None
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        proof = stark.prove(trace, air, boundary, tz, layer)
-        torch.cuda.synchronize()
-        totals.append(time.perf_counter() - t0)
-    dist.barrier()
-    t = torch.tensor(totals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)              # per step: the slowest rank
-    elapsed = float(t.sum().item())
-    digest = hashlib.sha256(proof).digest()
-    mine = torch.tensor(list(digest[:8]), dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-    lo, hi = mine.clone(), mine.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    same_everywhere = bool(torch.equal(lo, hi))
-    phase_ms = None
-    if phases:
-        stark.phase_log = []
-        stark.prove(trace, air, boundary, tz, layer)
-        phase_ms = [[name, round(1e3 * sec, 3)] for name, sec in stark.phase_log]
-        stark.phase_log = None
-    rec = None
-    if rank == 0:
-        t0 = time.perf_counter()
-        verifies = bool(stark.verify(proof, air, boundary, root))
-        verify_s = time.perf_counter() - t0
-        rec = {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_%dgpu" % (log_fri - 4, log_fri, world), "log2n": log_fri, "world_size": world,
-               "registers": 2, "colinearity_checks": s, "expansion_factor": 4, "ms_per_proof": 1e3 * elapsed / steps,
-               "trace": "device-resident columns (fast_stark.DeviceTrace), generated on the host outside the timed region",
-               "parallelism": "sharded LDEs (1 corner turn each), commitments, quotients, FRI and openings; trace interpolation one register per rank (broadcast); combination replicated",
-               "proof_bytes": len(proof), "proof_sha256_16": digest.hex()[:16], "same_proof_on_every_rank": same_everywhere,
-               "verify_accepts": verifies, "verify_s": verify_s, "preprocess_s": preprocess_s, "runs_ms": [round(x * 1e3, 3) for x in t.tolist()]}
-        if phase_ms is not None:
-            rec["phases_ms_synchronised_after_each"] = phase_ms
-    return elapsed, same_everywhere, rec
 
 
 def run_stark_prove_workload(args, rank, world, dev, stream, dist, backend, shared_gpus):
@@ -1044,14 +601,24 @@ def extras(sc, lib, stream=None):
     t0 = time.perf_counter()
     serialized = ps.serialize()          # (not part of Fri.prove in the reference either: fri.py:115-130 returns the indices; ip.py:18 serializes)
     serialize_ms = (time.perf_counter() - t0) * 1e3
+    # like for like with the reference's Fri.prove, which builds every tuple and path INSIDE the call (fri.py:98-113): here the call
+    # describes the proof objects and serialize() materialises them, so prove + serialize is the figure that covers the same work
+    both = []
+    for _ in range(5):
+        cw2, ps2 = sc.DeviceCodeword(cwv, field), ProofStream()
+        t0 = time.perf_counter()
+        fr.prove(cw2, ps2)
+        ps2.serialize()
+        both.append(round((time.perf_counter() - t0) * 1e3, 3))
     t0 = time.perf_counter()
     verified = fr.verify(ps, [])        # outside the timed loop: the proof that was timed is a proof the verifier accepts
     res["fri_prove_2p22_ef4_s40"] = {"ms": best * 1e3, "median_ms": sorted(runs)[len(runs) // 2], "rounds": fr.num_rounds(), "proof_objects": len(ps.objects),
                                      "verify_accepts": bool(verified), "verify_s": time.perf_counter() - t0, "runs_ms": runs,
                                      "proof_bytes": len(serialized), "serialize_ms_outside_the_timed_call": serialize_ms,
+                                     "prove_plus_serialize_ms": {"best": min(both), "median": sorted(both)[len(both) // 2], "runs": both},
                                      "how": "one library call (sc_fri_prove_dev): commit phase with the rounds below 2^17 in one persistent launch (fri_tail_kernel), "
                                             "transcript challenge, index sampling, one query kernel writing the openings to pinned host memory"}
-    del cw, cwv, coeffs
+    del cw, cw2, cwv, coeffs
     # configs[4] on ONE GPU: the polynomial-core call census of FastStark.prove replayed at
     # fri_domain_length 2^24, omicron_domain_length 2^22, 2 registers: 4 LDEs to 2^24, 2 coset divisions at 2^22,
     # 3 Merkle commits of 2^24 leaves, Fri.prove on the combined codeword (17 rounds), 4 x 160 openings.
@@ -1143,85 +710,6 @@ def extras(sc, lib, stream=None):
     except Exception as e:
         res["stark_prove_2p24_1gpu"] = {"error": repr(e)}
     return res
-
-
-def plain_stark_prove_measure(log_fri, steps):
-    """fast_stark.FastStark.prove on one GPU (no process group): ms per proof from a device-resident trace to the serialized proof"""
-    from fast_stark import DeviceTrace, FastStark
-    s = 40
-    field, T, packed, air, boundary = synthetic_stark_instance(log_fri, s)
-    stark = FastStark(field, 4, s, 2 * s, 2, T)
-    trace = DeviceTrace.from_packed(packed, field)
-    sc = sys.modules["starkcore"]
-    t0 = time.perf_counter()
-    tz, tz_codeword, root = stark.preprocess(device_resident=True)
-    sc.synchronize()
-    preprocess_s = time.perf_counter() - t0
-    stark.prove(trace, air, boundary, tz, tz_codeword)
-    runs, proof = [], None
-    for _ in range(steps):
-        sc.synchronize()
-        t0 = time.perf_counter()
-        proof = stark.prove(trace, air, boundary, tz, tz_codeword)
-        sc.synchronize()
-        runs.append(time.perf_counter() - t0)
-    t0 = time.perf_counter()
-    verifies = bool(stark.verify(proof, air, boundary, root))
-    return {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_1gpu" % (log_fri - 4, log_fri), "ms_per_proof": 1e3 * min(runs),
-            "runs_ms": [round(1e3 * r, 3) for r in runs], "registers": 2, "colinearity_checks": s, "expansion_factor": 4,
-            "trace": "device-resident columns (fast_stark.DeviceTrace)", "proof_bytes": len(proof), "verify_accepts": verifies,
-            "verify_s": time.perf_counter() - t0, "preprocess_s": preprocess_s,
-            "randomness": "the operating system's (getrandom, drawn by the library)" if sys.modules["fast_stark"].os_urandom_is_genuine() else "patched os.urandom"}
-
-
-def stark_census(sc, lib, field, log_fri):
-    import ctypes
-    import synth
-    from fri import Fri
-    from ip import ProofStream
-    GEN = 85408008396924667383611388730472331217
-    Nf, No = 1 << log_fri, 1 << (log_fri - 2)
-    omega, omicron = field.primitive_nth_root(Nf), field.primitive_nth_root(No)
-    polys = [sc.DeviceVector.from_bytes(synth.synth_packed(60 + i, No // 2).tobytes()) for i in range(4)]
-    sc.synchronize()
-    t0 = time.perf_counter()
-    ps = ProofStream()
-    codewords = []
-    for i, pv in enumerate(polys):                       # 2 boundary quotients, randomizer, combination
-        cw = sc.DeviceVector(Nf)
-        sc._check(lib.sc_coset_evaluate_dev(pv.ptr, No // 2, sc.fe_bytes(GEN), sc.fe_bytes(omega.value), Nf, cw.ptr, None))
-        codewords.append(sc.DeviceCodeword(cw, field))
-        if i < 3:
-            ps.push(codewords[i].tree().root)
-    t_lde_commit = time.perf_counter() - t0
-    # 2 transition quotients: coset NTTs of numerator and zerofier, pointwise division, inverse NTT (device-resident core)
-    t1 = time.perf_counter()
-    a, b, q = sc.DeviceVector(No), sc.DeviceVector(No), sc.DeviceVector(No)
-    for i in range(2):
-        sc._check(lib.sc_coset_evaluate_dev(polys[i].ptr, No // 2, sc.fe_bytes(GEN), sc.fe_bytes(omicron.value), No, a.ptr, None))
-        sc._check(lib.sc_coset_evaluate_dev(polys[3].ptr, No // 4, sc.fe_bytes(GEN), sc.fe_bytes(omicron.value), No, b.ptr, None))
-        sc._check(lib.sc_pointwise_div_dev(a.ptr, b.ptr, q.ptr, No, None))
-        sc._check(lib.sc_ntt_dev(q.ptr, a.ptr, No, sc.fe_bytes(omicron.value), 1, None))
-    sc.synchronize()
-    t_div = time.perf_counter() - t1
-    t2 = time.perf_counter()
-    fr = Fri(field.generator(), omega, Nf, 4, 40)
-    indices = fr.prove(codewords[3], ps)
-    t_fri = time.perf_counter() - t2
-    t3 = time.perf_counter()
-    dup = [i for i in indices] + [(i + 4) % Nf for i in indices]
-    quad = sorted(dup + [(i + Nf // 2) % Nf for i in dup])
-    for cw in codewords[:3]:
-        entries, paths = cw.query(quad)
-        for e, pth in zip(entries, paths):
-            ps.push(e)
-            ps.push(pth)
-    t_open = time.perf_counter() - t3
-    total = time.perf_counter() - t0
-    import hashlib
-    return {"ms": total * 1e3, "lde_and_commit_ms": t_lde_commit * 1e3, "coset_divide_ms": t_div * 1e3, "fri_prove_ms": t_fri * 1e3,
-            "openings_ms": t_open * 1e3, "fri_rounds": fr.num_rounds(), "proof_objects": len(ps.objects),
-            "proof_sha256_16": hashlib.sha256(ps.serialize()).hexdigest()[:16], "roots": [o.hex()[:16] for o in ps.objects[:3]]}
 
 
 def measured_valu(log2n):

@@ -248,6 +248,10 @@ class Fri:
         total = sum(counts)
         el_bytes = (16 * total + 255) & ~255
         path_bytes = sum(64 * c * d for c, d in zip(counts, depths))
+        # Lifetime: `answers` is pinned host memory from the library's pool; the segments added to the stream below (and
+        # also_open.answers) are VIEWS of it, so it stays page-locked for as long as the stream's described objects live and goes
+        # back to the pool when the stream is dropped after serialize().  A caller that keeps streams calls
+        # proof_stream.objects.detach() (proof_objects.LazyProofObjects.detach) to hold plain objects instead.
         answers = _sc.HostBuffer(el_bytes + path_bytes + 8 * total)
         extra_trees = [cw.tree() for cw in extra]
         # no handle of the commit phase comes back (vecs_out = trees_out = NULL): nothing reads the folded codewords or their trees
@@ -282,7 +286,6 @@ class Fri:
                 vo += c
                 po += 64 * c * d
             also_open.answers = fetched
-            also_open.positions = list(quad)
             also_open.position_arrays = [where[own + 4 * s * e:own + 4 * s * (e + 1)] for e in range(ne)]      # the same, as the library wrote them
         return list(top)
 

@@ -334,6 +334,11 @@ class ScaledLater(DevicePolynomial):
                 self._degree = self._made._degree
         return self._made.vec
 
+    @vec.setter
+    def vec(self, value):
+        # (DevicePolynomial.__init__ is deliberately not run: there is no vector until somebody reads it)
+        raise AttributeError("ScaledLater.vec is derived from scaled_from; wrap a new vector in a DevicePolynomial instead")
+
     def degree(self):
         if self._degree is None and self.scaled_from[1].value % self.field.p != 0:
             self._degree = self.scaled_from[0].degree()      # the same coefficients vanish

@@ -40,6 +40,16 @@ class _Context:
     def __init__(self):
         self.fields = []
         self.seen = set()                                  # ids of the real objects described so far
+        self.uids = {}                                     # process-wide codeword id -> small id of this serialization
+
+    def uid(self, holder):
+        """The codeword's id inside THIS serialization (1, 2, ...).  The pickler's memo key of an element is
+        (field << 56) ^ (id << 32 | index): 24 bits for the id.  The process-wide counter behind `_codeword_uid` grows by one per
+        codeword and round of every proof a long-lived prover makes and would spill into the field bits after 2^24 of them;
+        a proof describes a few dozen codewords."""
+        local = self.uids.setdefault(_codeword_uid(holder), len(self.uids) + 1)
+        assert local < (1 << 24)
+        return local
 
     def field_index(self, field):
         for i, f in enumerate(self.fields):
@@ -121,7 +131,7 @@ def _element_ops(ctx, cw, indices, values):
     rec = np.empty(k, dtype=_E)
     rec["op"] = ord("E")
     rec["f"] = ctx.field_index(cw.field)
-    rec["key"] = (np.uint64(_codeword_uid(cw)) << np.uint64(32)) | np.asarray(indices, dtype=np.uint64)
+    rec["key"] = (np.uint64(ctx.uid(cw)) << np.uint64(32)) | np.asarray(indices, dtype=np.uint64)
     rec["v"] = np.frombuffer(values, dtype=np.uint8).reshape(k, 16)
     return rec
 
@@ -178,7 +188,7 @@ class FriRound:
         f = ctx.field_index(self.cur.field)
         if ctx.field_index(self.nxt.field) != f:
             raise _Unsupported("two fields in one round")
-        head = _struct.pack("<cIIQQII", b"R", s, f, _codeword_uid(self.cur) << 32, _codeword_uid(self.nxt) << 32, d_cur, d_nxt)
+        head = _struct.pack("<cIIQQII", b"R", s, f, ctx.uid(self.cur) << 32, ctx.uid(self.nxt) << 32, d_cur, d_nxt)
         idx = np.asarray(self.idx, dtype=np.uint32).tobytes()
         return b"".join((head, idx, bytes(self.val[0]), bytes(self.val[1]), bytes(self.val[2]),
                          self.paths[0].tobytes(), self.paths[1].tobytes(), self.paths[2].tobytes()))
@@ -236,7 +246,7 @@ class FriQueryPhase:
         if not (self.elems.flags["C_CONTIGUOUS"] and self.paths.flags["C_CONTIGUOUS"] and self.positions.flags["C_CONTIGUOUS"]) or self.positions.dtype != np.uint64:
             return b"".join(r.ops(ctx) for r in self.rounds())
         head = _struct.pack("<cIII", b"Q", self.s, f, k)
-        per = b"".join(_struct.pack("<QI", _codeword_uid(h) << 32, d) for h, d in zip(self.holders, self.depths))
+        per = b"".join(_struct.pack("<QI", ctx.uid(h) << 32, d) for h, d in zip(self.holders, self.depths))
         return head + per + _struct.pack("<QQQ", self.elems.ctypes.data, self.paths.ctypes.data, self.positions.ctypes.data)
 
     def materialize(self):
@@ -265,9 +275,9 @@ class Openings:
         pos, val = self.positions, self.values
         if (isinstance(pos, np.ndarray) and pos.dtype == np.uint64 and pos.flags["C_CONTIGUOUS"] and len(pos) == k and isinstance(val, np.ndarray)
                 and val.dtype == np.uint8 and val.flags["C_CONTIGUOUS"] and val.nbytes == 16 * k and self.paths.flags["C_CONTIGUOUS"]):
-            return _struct.pack("<cIIQIQQQ", b"P", k, ctx.field_index(self.cw.field), _codeword_uid(self.cw) << 32, depth,
+            return _struct.pack("<cIIQIQQQ", b"P", k, ctx.field_index(self.cw.field), ctx.uid(self.cw) << 32, depth,
                                 pos.ctypes.data, val.ctypes.data, self.paths.ctypes.data if depth else 0)
-        head = _struct.pack("<cIIQI", b"O", k, ctx.field_index(self.cw.field), _codeword_uid(self.cw) << 32, depth)
+        head = _struct.pack("<cIIQI", b"O", k, ctx.field_index(self.cw.field), ctx.uid(self.cw) << 32, depth)
         return b"".join((head, np.asarray(self.indices, dtype=np.uint32).tobytes(), bytes(self.values), self.paths.tobytes()))
 
     def materialize(self):
@@ -360,6 +370,16 @@ class LazyProofObjects:
                 out.extend(seg.objects if isinstance(seg, _Real) else self._segment_objects(k))
             self._all = out
         return self._all
+
+    def detach(self):
+        """Make the reference's objects once and keep ONLY them.  The described segments are views into the pinned host buffer the
+        query kernel wrote (starkcore.HostBuffer: megabytes per proof, page-locked, back in the library's pool when the last view
+        dies); serializing and dropping the stream -- what a prover does -- releases it by itself.  A process that RETAINS proof
+        streams calls this (or reads the objects and drops the stream) so that it holds ordinary Python objects, as the
+        reference's streams do, instead of page-locked memory."""
+        objects = list(self.materialized())
+        self._segments, self._cache, self._all = [_Real(objects)], {}, None
+        return self
 
     def __len__(self):
         return sum(seg.count for seg in self._segments)

@@ -73,7 +73,7 @@ def unpack_ints(buf):
 
 def synthetic_air_columns(T, a=3, b=5):
     """The two registers of the synthetic configs[4] workload as Python ints: T rows of (a, b) -> (b, a*a + b) mod p from (3, 5).
-    bench.synthetic_stark_instance, the golden generator (tests/golden/make_golden.py --stark-synth, which hands the same rows to the
+    workloads.synthetic_stark_instance, the golden generator (tests/golden/make_golden.py --stark-synth, which hands the same rows to the
     reference's FastStark) and the tests all take their trace from here."""
     col_a, col_b = [], []
     for _ in range(T):

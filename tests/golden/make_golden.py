@@ -384,7 +384,7 @@ def gen_stark():
 
 
 def gen_stark_synth(cases):
-    """The workload bench.py times for BASELINE configs[4] -- bench.synthetic_stark_instance: the 2-register AIR (a, b) -> (b, a*a + b),
+    """The workload bench.py times for BASELINE configs[4] -- workloads.synthetic_stark_instance: the 2-register AIR (a, b) -> (b, a*a + b),
     T = 2^(log_fri - 4) - 4 s rows, expansion factor 4, s colinearity checks, security level 2 s -- proven by the REFERENCE's
     FastStark (fast_stark.py:76-178) with a seeded os.urandom.  cases: [(log_fri, s, seed)].  Records are merged into
     fast_stark_synth.json by (log_fri, s, seed), so the long sizes can be added one at a time (2^14: minutes; 2^16: about an hour)."""

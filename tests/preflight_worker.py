@@ -1,4 +1,4 @@
-"""bench.direct_store_preflight under gloo on a machine WITHOUT a GPU (tests/test_sharded_cpu.py): every rank's child
+"""sharded_setup.direct_store_preflight under gloo on a machine WITHOUT a GPU (tests/test_sharded_cpu.py): every rank's child
 (stark-anatomy_amd/direct_preflight.py) fails to initialise the library, says so with its exit status, and the ranks agree -- through the
 file rendezvous directory rank 0 made and the all-reduce behind it -- that the direct-store forms are not to be tried.  With
 PREFLIGHT_FAKE=1 the child is replaced by a stand-in that only walks through the rendezvous (handle / stored / checked files), so that
@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd"))
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import bench
+    import sharded_setup
     if os.environ.get("PREFLIGHT_FAKE") == "1":
         # the stand-in child: the same files in the same order, no library
         import direct_preflight as real
@@ -32,8 +32,8 @@ def main():
                     "sys.exit(0)\n" % os.path.dirname(real.__file__))
         real_join = os.path.join
         os.path.join = lambda *a: stand_in if a[-1] == "direct_preflight.py" else real_join(*a)      # bench.py builds the child's path with it
-    out = bench.direct_store_preflight(rank, world, torch.device("cpu"), dist, "gloo")
-    again = bench.direct_store_preflight(rank, world, torch.device("cpu"), dist, "gloo")
+    out = sharded_setup.direct_store_preflight(rank, world, torch.device("cpu"), dist, "gloo")
+    again = sharded_setup.direct_store_preflight(rank, world, torch.device("cpu"), dist, "gloo")
     assert again is out                                                                    # once per job
     want = os.environ.get("PREFLIGHT_EXPECT", "fail")
     assert out["passed"] is (want == "pass"), out

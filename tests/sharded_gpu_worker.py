@@ -183,13 +183,13 @@ def stark_check(rank, world, dev):
 
 
 def stark_reference_goldens(rank, world, dev, max_log_fri=14):
-    """The workload bench.py times for BASELINE configs[4] (bench.synthetic_stark_instance), as the REFERENCE's FastStark proved it
+    """The workload bench.py times for BASELINE configs[4] (workloads.synthetic_stark_instance), as the REFERENCE's FastStark proved it
     (tests/golden/fast_stark_synth.json, written by make_golden.py --stark-synth with the same seeded os.urandom): every rank must
     end with those bytes, from the host-list trace and from device-resident columns."""
     import hashlib
     import json
     import random
-    import bench
+    import workloads
     import fast_stark
     from algebra import FieldElement
     from ip import ProofStream
@@ -201,7 +201,7 @@ def stark_reference_goldens(rank, world, dev, max_log_fri=14):
             log_fri, s = rec["log_fri"], rec["num_colinearity_checks"]
             if log_fri > max_log_fri:
                 continue
-            field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+            field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
             stark = ShardedFastStark(field, 4, s, rec["security_level"], 2, T, rank, world, dev)
             for resident in (False, True):
                 rng = random.Random(rec["urandom_seed"])

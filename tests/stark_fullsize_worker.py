@@ -25,13 +25,13 @@ def main():
     dev = torch.device("cuda", 0)
     import starkcore as sc
     sc.init(0)
-    import bench
+    import workloads
     import fast_stark
     from fast_stark import DeviceTrace
     from sharded_stark import ShardedFastStark
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s = 40
-    field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+    field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
     trace = DeviceTrace.from_packed(packed, field)
     fast_stark.os.urandom = random.Random(seed).randbytes        # (rank 0's draws are the ones every rank uses: broadcast)
     stark = ShardedFastStark(field, 4, s, 2 * s, 2, T, rank, world, dev)

@@ -73,14 +73,14 @@ def test_fri_prove_2p22_against_oracle(sc):
 def test_stark_census_2p24_two_paths_and_oracle(sc):
     import torch
     sys.path.insert(0, REPO)
-    import bench
+    import workloads
     from algebra import Field
     field = Field.main()
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        times, info = bench.sharded_census(24, 0, 1, dev, stream)
-    plain = bench.stark_census(sc, sc.lib(), field, 24)
+        times, info = workloads.sharded_census(24, 0, 1, dev, stream)
+    plain = workloads.stark_census(sc, sc.lib(), field, 24)
     assert info["fri_rounds"] == plain["fri_rounds"] == 17
     assert info["roots"] == plain["roots"]
     assert info["proof_objects"] == plain["proof_objects"] == 3 + 17 + 1 + 16 * 40 * 4 + 3 * 160 * 2
@@ -101,13 +101,13 @@ def test_stark_prover_full_size_two_provers_one_proof(sc, log_fri):
     arithmetic only: hashlib, Python ints -- accepts it and rejects it for a false boundary claim."""
     import random
     import torch
-    import bench
+    import workloads
     import fast_stark
     from algebra import FieldElement
     from fast_stark import DeviceTrace, FastStark
     from sharded_stark import ShardedFastStark
     s = 40
-    field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+    field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
     trace = DeviceTrace.from_packed(packed, field)
     genuine = fast_stark.os.urandom
 
@@ -145,12 +145,12 @@ def test_stark_prover_full_size_two_ranks(sc, world):
     import socket
     import subprocess
     import sys
-    import bench
+    import workloads
     import fast_stark
     from conftest import REPO
     from fast_stark import DeviceTrace, FastStark
     log_fri, s, seed = 24, 40, 5151
-    field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+    field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
     genuine = fast_stark.os.urandom
     try:
         fast_stark.os.urandom = random.Random(seed).randbytes

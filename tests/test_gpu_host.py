@@ -472,6 +472,33 @@ def test_a_kept_proof_stream_does_not_keep_the_codewords(monkeypatch):
     assert pickle.dumps(list(ps.objects)) == before
 
 
+def test_a_detached_proof_stream_holds_plain_objects_and_no_pinned_memory():
+    """The described segments of a one-call Fri.prove are views of pinned host memory (starkcore.HostBuffer).  objects.detach()
+    swaps them for the reference's objects: the buffer's memory goes back to the pool (seen through the weak reference numpy's base
+    object allows), and the stream serializes to the same bytes and verifies."""
+    import gc
+    import weakref
+    import numpy as np
+    import proof_objects
+    rec = [r for r in load_golden("fri.json")["prove_synth"] if r["logN"] == 12][0]
+    N = 1 << rec["logN"]
+    om = field.primitive_nth_root(N)
+    poly = Polynomial([FieldElement(v, field) for v in synth.synth_ints(rec["coeff_seed"], N // 4)])
+    fr = Fri(field.generator(), om, N, rec["expansion_factor"], rec["num_colinearity_tests"])
+    ps = ProofStream()
+    fr.prove(fast_coset_evaluate_device(poly, field.generator(), om, N), ps)
+    before = ps.serialize()
+    assert hashlib.sha256(before).hexdigest() == rec["serialized_sha256"]
+    lazy = ps.objects
+    assert isinstance(lazy, proof_objects.LazyProofObjects)
+    pinned = [weakref.ref(seg.elems.base) for seg in lazy._segments if isinstance(getattr(seg, "elems", None), np.ndarray) and seg.elems.base is not None]
+    assert lazy.detach() is lazy
+    assert all(isinstance(seg, proof_objects._Real) for seg in lazy._segments)
+    gc.collect()
+    assert all(ref() is None for ref in pinned), "a detached stream still refers to the pinned answers"
+    assert ps.serialize() == before and fr.verify(ps, []) is True
+
+
 def test_merkle_through_host_api():
     g = load_golden("merkle.json")
     for rec in g["commit"]:

@@ -275,11 +275,11 @@ def test_a_proof_leaves_no_device_memory_to_the_cycle_collector(sc):
     objects die -- by reference counting, not whenever the cycle collector gets round to it: a tree that waits in a cycle makes the
     next proof miss the pool, and a 2 GB hipMalloc costs 60 ms (seen as 300-800 ms outliers, profiles/r04)."""
     import gc
-    import bench
+    import workloads
     import starkcore
     from fast_stark import DeviceTrace, FastStark
     from sharded_stark import ShardedFastStark
-    field, T, packed, air, boundary = bench.synthetic_stark_instance(14, 40)
+    field, T, packed, air, boundary = workloads.synthetic_stark_instance(14, 40)
     trace = DeviceTrace.from_packed(packed, field)
     dev = torch.device("cuda", 0)
     provers = [ShardedFastStark(field, 4, 40, 80, 2, T, 0, 1, dev), FastStark(field, 4, 40, 80, 2, T)]

@@ -64,12 +64,12 @@ def test_fast_stark_seeded_golden_proofs(device_min, monkeypatch):
 
 @pytest.mark.parametrize("device_min", [32, 10 ** 9])
 def test_synthetic_air_reference_golden_proofs(device_min, monkeypatch):
-    """The workload bench.py TIMES for BASELINE configs[4] (bench.synthetic_stark_instance: 2-register AIR (a, b) -> (b, a*a + b),
+    """The workload bench.py TIMES for BASELINE configs[4] (workloads.synthetic_stark_instance: 2-register AIR (a, b) -> (b, a*a + b),
     T = 2^(log_fri - 4) - 4 s rows, expansion factor 4, s colinearity checks) as the REFERENCE's FastStark.prove proved it with the
     same seeded os.urandom (tests/golden/fast_stark_synth.json, make_golden.py --stark-synth; code/fast_stark.py:76-178): FRI domains
     2^10 ... 2^16, i.e. the multi-pass LDE plans, the progression interpolation, the value-domain transition quotients and the
     library commit loop at sizes where they are the code that runs -- byte for byte, from host rows and from device-resident columns."""
-    import bench
+    import workloads
     import synth
     monkeypatch.setattr(FastStark, "DEVICE_MIN", device_min)
     genuine = fast_stark.os.urandom
@@ -78,7 +78,7 @@ def test_synthetic_air_reference_golden_proofs(device_min, monkeypatch):
             log_fri, s = rec["log_fri"], rec["num_colinearity_checks"]
             if device_min > 32 and log_fri > 14:
                 continue                                   # (the host-list data flow at 2^16: minutes of Python lists, nothing new)
-            field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+            field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
             assert T == rec["original_trace_length"]
             stark = FastStark(field, rec["expansion_factor"], s, rec["security_level"], 2, T)
             assert (stark.omicron_domain_length, stark.fri_domain_length) == (rec["omicron_domain_length"], rec["fri_domain_length"])

@@ -56,7 +56,7 @@ def test_sharded_stark_prover_gloo_matches_reference_proofs(world):
 
 @pytest.mark.parametrize("case", ["no_gpu", "all_children_pass", "one_child_dies"])
 def test_direct_store_preflight_agreement_gloo(case, tmp_path):
-    """bench.direct_store_preflight (the children that try the direct-store corner turn's ingredients before any rank does): the
+    """sharded_setup.direct_store_preflight (the children that try the direct-store corner turn's ingredients before any rank does): the
     ranks must end with ONE answer -- here, without a GPU, 'no' because no child can initialise the library; with a stand-in child
     that only walks through the file rendezvous, 'yes' when every child returns 0 and 'no' when one of them dies by SIGABRT."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1", STARKCORE_PREFLIGHT_WAIT_S="5",

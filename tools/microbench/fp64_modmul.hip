@@ -19,6 +19,7 @@
 #include <cstring>
 #include <cfenv>
 #include <vector>
+#include <type_traits>
 #include "field.cuh"
 #include "fp64_modmul.h"
 
@@ -77,15 +78,19 @@ __global__ void __launch_bounds__(256) fp_kernel(const Fe* __restrict__ in, cons
         x[r] = fq::from_u128<0>(v.lo, v.hi);
         w[r] = tw3[(t * 4 + r) & 1023];
     }
-    for (int it = 0; it < rounds; ++it) {
+    // (a pass folds a pure-sum output every few stages; here in every second round = every fourth stage.  Two rounds per loop
+    // iteration so that the choice is made at compile time: a per-lane select would be a VOP2 v_cndmask, 23 cycles on gfx950)
+    auto round = [&](auto fold) {
         const fq::F3 s0 = fq::add(x[0], x[2]), s1 = fq::add(x[1], x[3]);
         const fq::F3 d0 = fq::modmul<false>(fq::sub(x[0], x[2]), w[0]), d1 = fq::modmul<false>(fq::sub(x[1], x[3]), w[1]);
-        // (a pass folds a pure-sum output every few stages; here every second round = every fourth stage)
-        x[0] = (it & 1) ? normalise<true>(fq::add(s0, s1)) : normalise<false>(fq::add(s0, s1));
+        x[0] = normalise<decltype(fold)::value>(fq::add(s0, s1));
         x[1] = fq::modmul<true>(fq::sub(s0, s1), w[2]);
         x[2] = normalise<false>(fq::add(d0, d1));
         x[3] = fq::modmul<true>(fq::sub(d0, d1), w[3]);
-    }
+    };
+    int it = 0;
+    for (; it + 1 < rounds; it += 2) { round(std::false_type{}); round(std::true_type{}); }
+    if (it < rounds) round(std::false_type{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         Fe v;

@@ -5,12 +5,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd")); sys.path.insert(0, REPO)
 import torch
 import starkcore as sc
-import bench
+import workloads
 from fast_stark import DeviceTrace
 from sharded_stark import ShardedFastStark
 log_fri = 20
 sc.init(0); dev = torch.device("cuda", 0)
-field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, 40)
+field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, 40)
 stark = ShardedFastStark(field, 4, 40, 80, 2, T, 0, 1, dev)
 trace = DeviceTrace.from_packed(packed, field)
 tz, layer, root = stark.preprocess(device_resident=True)

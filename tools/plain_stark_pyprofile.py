@@ -5,12 +5,12 @@ import os, sys, cProfile, pstats
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd")); sys.path.insert(0, REPO)
 import starkcore as sc
-import bench
+import workloads
 from fast_stark import DeviceTrace, FastStark
 log_fri = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 proofs = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 sc.init(0)
-field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, 40)
+field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, 40)
 stark = FastStark(field, 4, 40, 80, 2, T)
 trace = DeviceTrace.from_packed(packed, field)
 tz, tzc, root = stark.preprocess(device_resident=True)

@@ -7,14 +7,14 @@ sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd"))
 sys.path.insert(0, REPO)
 import torch
 import starkcore as sc
-import bench
+import workloads
 from fast_stark import DeviceTrace
 from sharded_stark import ShardedFastStark
 log_fri = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 s = 40
 sc.init(0); dev = torch.device("cuda", 0)
 t0 = time.perf_counter()
-field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
 print("trace generated on the host in %.2f s (T = %d rows, 2 registers)" % (time.perf_counter() - t0, T))
 stark = ShardedFastStark(field, 4, s, 2 * s, 2, T, 0, 1, dev)
 trace = DeviceTrace.from_packed(packed, field)

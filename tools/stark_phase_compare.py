@@ -7,14 +7,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stark-anatomy_amd")); sys.path.insert(0, REPO)
 import torch
 import starkcore as sc
-import bench
+import workloads
 from fast_stark import DeviceTrace, FastStark
 from sharded_stark import ShardedFastStark
 log_fri = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 s = 40
 sc.init(0); dev = torch.device("cuda", 0)
-field, T, packed, air, boundary = bench.synthetic_stark_instance(log_fri, s)
+field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
 trace = DeviceTrace.from_packed(packed, field)
 provers = [("plain (fast_stark.FastStark)", FastStark(field, 4, s, 2 * s, 2, T)), ("sharded at world 1 (sharded_stark.ShardedFastStark)", ShardedFastStark(field, 4, s, 2 * s, 2, T, 0, 1, dev))]
 for name, stark in provers:
