@@ -30,6 +30,7 @@ import os
 import sys
 import time
 
+T0 = time.perf_counter()             # the process's start, for --budget-s
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, "stark-anatomy_amd")
 for p in (PKG, REPO):
@@ -140,6 +141,10 @@ def main():
                     help="send the block a rank keeps for itself through the collective as well (a one-rank world then exercises the whole RCCL path)")
     ap.add_argument("--no-native-exchange", action="store_true", help="do not probe the library's own RCCL communicator, only torch.distributed")
     ap.add_argument("--no-direct-store", action="store_true", help="do not probe the direct-store corner turn (HIP IPC, no collective)")
+    ap.add_argument("--budget-s", type=float, default=1200.0,
+                    help="N > 1: seconds this command may take in all (the driver allows 1800).  The legs behind the headline are started only "
+                         "while the time used is below a fraction of it -- the other member of strong/weak 0.35, the call census 0.5, the prover "
+                         "0.7 -- so they are dropped in that order, and the line says which were (config.legs); 0 = no limit")
     ap.add_argument("--allow-replicas", action="store_true",
                     help="N > 1: if the sharded path cannot be set up, time N independent single-GPU transforms instead of exiting non-zero")
     args = ap.parse_args()
@@ -330,18 +335,39 @@ def main():
         except Exception:       # noqa: BLE001  (no fixture: the round trip stays the guard)
             reference_sha = None
 
+    legs = {"seconds": {"set_up_probes_and_headline": round(time.perf_counter() - T0, 2)}, "dropped_for_the_budget": [], "budget_s": args.budget_s}
+
+    def leg(name, fraction):
+        """may the optional leg `name` start?  Decided on the slowest rank's clock so that every rank takes the same branch (the
+        legs are collective); leg_done(name) books its duration"""
+        used = time.perf_counter() - T0
+        if sharded and world > 1:
+            t = torch.tensor([used], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            used = float(t.item())
+        ok = args.budget_s <= 0 or used < fraction * args.budget_s
+        if not ok:
+            legs["dropped_for_the_budget"].append(name)
+        legs["_t"] = time.perf_counter()
+        return ok
+
+    def leg_done(name):
+        legs["seconds"][name] = round(time.perf_counter() - legs.pop("_t"), 2)
+
     stages = weak = None
     if sharded and args.workload == "ntt":
         # where the time of the sharded transform goes (per stage, max over ranks), and the OTHER member of the pair strong / weak:
         # the first multi-GPU run should need no second run to be read
+        leg("stage_breakdown", float("inf"))          # (always runs; booked like the others)
         try:
             stages = stage_breakdown(eng, (x, y, z), rank, world, dev, dist, backend, reps=3 if shared_gpus else 10)
         except Exception as e:       # noqa: BLE001
             stages = {"error": repr(e)[:300]}
+        leg_done("stage_breakdown")
         try:
             scaling_is_strong = args.scaling == "strong" and world > 1
             other_log2n = (20 + (world.bit_length() - 1) + 1) if scaling_is_strong else 24
-            if world > 1 and not args.log2n and other_log2n != log2n:
+            if world > 1 and not args.log2n and other_log2n != log2n and leg("other_member_of_strong_weak", 0.35):
                 other_steps = 5 if shared_gpus else 50
                 step2, eng2, xyz2, _, _ = sharded_setup(args, other_log2n, rank, world, dev, dist, backend, only=(corner_probes["chosen"], corner_probes["chosen_kwargs"]))
                 for _ in range(2 if shared_gpus else 5):
@@ -362,26 +388,33 @@ def main():
                     dist.barrier()
                     eng2.stages.release_direct()
                 del step2, eng2, xyz2
+                leg_done("other_member_of_strong_weak")
         except Exception as e:       # noqa: BLE001
             weak = {"error": repr(e)[:300]}
 
     census = prover = None
     if sharded and world > 1 and not args.no_extras:
         # the whole config-5 pipeline on the same ranks, once warm and once timed (all ranks take part; rank 0 reports)
-        try:
-            lf = 16 if shared_gpus else (args.log2n or (20 + (world.bit_length() - 1) + 1))
-            sharded_census(lf, rank, world, dev, stream)
-            times, info = sharded_census(lf, rank, world, dev, stream)
-            census = census_record(times, info, lf, world, dist, backend, dev)
-        except Exception as e:       # noqa: BLE001  side measurements never invalidate the headline
-            census = {"error": repr(e)[:300]}
-        try:
-            # ... and configs[4] as a prover at its stated size: ShardedFastStark.prove on the synthetic AIR, FRI domain 2^24 sharded
-            # over the ranks (2^14 when the ranks share GPUs: a functional run); the reference proves this workload byte for byte
-            # at 2^10 ... 2^16 (tests/golden/fast_stark_synth.json)
-            _, _, prover = stark_prove_measure(14 if shared_gpus else 24, 2, 1, rank, world, dev, dist, backend)
-        except Exception as e:       # noqa: BLE001
-            prover = {"error": repr(e)[:300]}
+        if leg("stark_census_sharded", 0.5):
+            try:
+                lf = 16 if shared_gpus else (args.log2n or (20 + (world.bit_length() - 1) + 1))
+                sharded_census(lf, rank, world, dev, stream)
+                times, info = sharded_census(lf, rank, world, dev, stream)
+                census = census_record(times, info, lf, world, dist, backend, dev)
+            except Exception as e:       # noqa: BLE001  side measurements never invalidate the headline
+                census = {"error": repr(e)[:300]}
+            leg_done("stark_census_sharded")
+        if leg("stark_prove_sharded", 0.7):
+            try:
+                # ... and configs[4] as a prover at its stated size: ShardedFastStark.prove on the synthetic AIR, FRI domain 2^24 sharded
+                # over the ranks (2^14 when the ranks share GPUs: a functional run); the reference proves this workload byte for byte
+                # at 2^10 ... 2^16 (tests/golden/fast_stark_synth.json)
+                _, _, prover = stark_prove_measure(14 if shared_gpus else 24, 2, 1, rank, world, dev, dist, backend)
+            except Exception as e:       # noqa: BLE001
+                prover = {"error": repr(e)[:300]}
+            leg_done("stark_prove_sharded")
+    legs.pop("_t", None)
+    legs["seconds"]["whole_command_so_far"] = round(time.perf_counter() - T0, 2)
 
     # what N means for the work: the N > 1 default is the north_star's strong-scaling series (2^24 for every N; its N = 1 member is
     # extras.ntt_2p24_strong of the N = 1 run, whose headline stays BASELINE configs[1] = 2^20); --scaling weak / replicas: work per GPU fixed
@@ -432,6 +465,7 @@ def main():
                                        "in stages_us (compute stages = ntt_pass_kernel launches, priced per launch in the N = 1 line; the exchange moves "
                                        "all_to_all_bytes_sent_per_rank_per_step / 2 bytes per transform over xGMI)")
             out["config"]["collective_backend"] = collective_label(backend, world, ngpu, shared_gpus)
+            out["config"]["legs"] = legs
             out["config"]["world_size"] = world
             out["config"]["corner_turn"] = corner_turn
             out["config"]["corner_turn_probes"] = corner_probes

@@ -441,12 +441,31 @@ def test_bench_two_ranks_print_the_north_star_record(sc):
     assert pre["passed"] is True and pre["this_rank_status"] == 0
     node = out["config"]["node"]
     assert "rccl_version" in node and node["visible_gpus"] >= 1 and len(node["can_access_peer"]) == node["visible_gpus"]
+    # what a reader of the driver's SCALE record needs from the line alone: the count, the rate, which collective library carried the
+    # corner turn (here: gloo, labelled; on a node with a GPU per rank the label names RCCL -- tests/test_sharded_cpu.py), the time
+    # every leg of the command took and which legs the time budget dropped (none at the default budget)
+    assert out["value"] > 0 and "gloo" in out["config"]["collective_backend"]
+    legs = out["config"]["legs"]
+    assert legs["dropped_for_the_budget"] == [] and legs["budget_s"] == 1200.0
+    assert {"set_up_probes_and_headline", "stage_breakdown", "other_member_of_strong_weak", "whole_command_so_far"} <= set(legs["seconds"])
     assert "n1 = 2^" in out["config"]["split"]
     other = out["extras"]["ntt_other_scaling"]
     assert other["log2n"] == 22 and other["roundtrip_bit_exact"] is True and "weak" in other["scaling"] and other["stages_us"]["forward"]["cols_us"] > 0
     # the weak series is still there on request
     weak = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--scaling", "weak"])
     assert weak["scaling"] == "weak" and weak["config"]["log2n"] == 22 and "ntt_2p24_strong" not in weak.get("extras", {})
+
+
+def test_bench_time_budget_drops_the_side_legs_in_the_stated_order(sc):
+    """`--budget-s`: the legs behind the headline start only while the command has used less than a fraction of its budget (other
+    member of strong / weak 0.35, census 0.5, prover 0.7), every rank taking the same branch; with a budget the set-up alone
+    exhausts all three are dropped and named, and the headline, its stage breakdown and the north_star record are still there."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--budget-s", "1"])
+    legs = out["config"]["legs"]
+    assert legs["dropped_for_the_budget"] == ["other_member_of_strong_weak", "stark_census_sharded", "stark_prove_sharded"]
+    assert "ntt_other_scaling" not in out["extras"] and "stark_census_sharded" not in out["extras"] and "stark_prove_sharded" not in out["extras"]
+    assert out["extras"]["ntt_2p24_strong"]["roundtrip_bit_exact"] is True and out["roofline"]["stages_us"]["forward"]["whole_us"] > 0
+    assert legs["seconds"]["whole_command_so_far"] >= legs["seconds"]["set_up_probes_and_headline"] > 1
 
 
 def test_bench_bare_launch_two_ranks_and_census_parity(sc):

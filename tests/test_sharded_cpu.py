@@ -72,3 +72,12 @@ def test_direct_store_preflight_agreement_gloo(case, tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     assert r.stdout.count("ok rank") == 2
+
+
+def test_the_line_of_a_run_with_a_gpu_per_rank_names_rccl():
+    """config.collective_backend of bench.py's N > 1 line: on a node where every rank owns a GPU the process group is "nccl", which
+    on ROCm IS RCCL, and the label says so; ranks sharing GPUs (every functional run on a 1-GPU box) are labelled as not a measurement"""
+    from sharded_setup import collective_label
+    assert collective_label("nccl", 8, 8, False) == "nccl (RCCL), 8 ranks on 8 GPUs"
+    shared = collective_label("gloo", 8, 1, True)
+    assert "gloo" in shared and "8 ranks sharing 1 GPU" in shared and "NOT a scaling measurement" in shared
