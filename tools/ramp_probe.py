@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-step GPU time of the 2^20 forward+inverse pair right after an idle period (dev tool): shows the two clock regimes of the
 board -- ~79 us per pair for the first milliseconds after idle (what a 20-step driver-style run sees), ~69 us once the GPU has been
-busy for tens of milliseconds (what tools/ab3.py reports as steady state)."""
+busy for tens of milliseconds (what tools/ab.py reports as steady state)."""
 import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stark-anatomy_amd"))
 import numpy as np, torch
