@@ -189,6 +189,8 @@ class FastStark:
     # objects pushed in the same order -- the proofs are byte-identical either way (tests/test_gpu_stark.py runs both settings
     # against the reference's golden proofs).
     DEVICE_MIN = 32
+    # True: every commitment waits for its root before the prover goes on (the reference's order of events; A/B of proof_objects.RootLater)
+    EAGER_COMMITS = False
 
     def _lde(self, polynomial):
         """Low-degree extension onto the FRI coset  generator * omega^i  (the LDE kernel)."""
@@ -294,9 +296,18 @@ class FastStark:
         self._mark("boundary quotients (division)")
         # commit to their low-degree extensions
         boundary_quotient_codewords = []
+        # a commitment whose codeword lives on the device is pushed as "the root of this tree, once it is built" (proof_objects.RootLater):
+        # the stream's first reader -- the Fiat-Shamir challenge below -- waits for it, the GPU queue never does
+        later = _po.lazy_objects(proof_stream) if on_device and not FastStark.EAGER_COMMITS else None
+
+        def commit(codeword):
+            if later is not None and isinstance(codeword, DeviceCodeword):
+                later.add(_po.RootLater(codeword.start_tree()))
+            else:
+                proof_stream.push(Merkle.commit(codeword))
         for s in registers:
             boundary_quotient_codewords.append(lde(boundary_quotients[s]))
-            proof_stream.push(Merkle.commit(boundary_quotient_codewords[s]))
+            commit(boundary_quotient_codewords[s])
         self._mark("boundary quotient LDEs + commitments")
 
         # transition polynomials: AIR evaluated symbolically in (X, trace(X), trace(omicron X)), then quotients
@@ -319,7 +330,7 @@ class FastStark:
             randomizer_polynomial = Polynomial([field.sample(os.urandom(17)) for i in range(max_degree + 1)])
         self._mark("randomizer polynomial: os.urandom / getrandom draws and Field.sample")
         randomizer_codeword = lde(randomizer_polynomial)
-        proof_stream.push(Merkle.commit(randomizer_codeword))
+        commit(randomizer_codeword)
         self._mark("randomizer polynomial: LDE, commitment")
 
         # Fiat-Shamir weights: 1 randomizer + 2 per transition quotient + 2 per boundary quotient

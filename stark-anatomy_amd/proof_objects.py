@@ -320,6 +320,28 @@ class _Real:
         return self.objects
 
 
+class RootLater:
+    """ONE object: the root of a Merkle tree whose build is only enqueued (starkcore.MerkleTree.from_device_async).  The prover pushes
+    the commitment and goes on enqueueing -- the next LDE stands in the queue right behind the tree -- and the root is waited for
+    when somebody needs the stream's bytes or objects: the next Fiat-Shamir challenge (fast_stark.py:125), serialization.  With
+    `Merkle.commit` returning the root at once the GPU stood idle after every commitment for as long as the host took to come back
+    with the next launch (tools/sync_points.py, tools/gap_report.py)."""
+    count = 1
+
+    def __init__(self, tree):
+        self.tree = tree
+
+    def ops(self, ctx):
+        root = self.tree.root                              # (waits for the build; the same bytes object from then on)
+        if id(root) in ctx.seen:
+            raise _Unsupported("the same object pushed twice")
+        ctx.seen.add(id(root))
+        return b"B" + len(root).to_bytes(4, "little") + root
+
+    def materialize(self):
+        return [self.tree.root]
+
+
 class LazyProofObjects:
     """`ProofStream.objects` once a prover has pushed device answers: a sequence that reads like the reference's list"""
 

@@ -6,7 +6,7 @@ runs this.  Output: small JSON fixtures next to this file.  Only DATA is written
 regenerated from seeds, outputs stored in full for small sizes and as SHA-256 of the packed
 16-byte-LE output for larger ones).  No reference source is copied.
 
-usage:  python tests/golden/make_golden.py [--big] [--fri-big] [--stark-synth [log_fri:s:seed ...]]     (--big adds 2^18 / 2^20 NTT digests, --fri-big 2^14 and 2^16 Fri.prove runs; minutes)
+usage:  python tests/golden/make_golden.py [--big] [--fri-big] [--host-mirror] [--stark-synth [log_fri:s:seed ...]]     (--big adds 2^18 / 2^20 NTT digests, --fri-big 2^14 and 2^16 Fri.prove runs; minutes)
 """
 import hashlib
 import json
@@ -383,6 +383,18 @@ def gen_stark():
     dump("fast_stark.json", out)
 
 
+def gen_host_mirror():
+    """tests/golden/host_mirror_cases.py run on the reference's own algebra / univariate / multivariate: digests per seeded case"""
+    import algebra as ref_algebra
+    import univariate as ref_univariate
+    import multivariate as ref_multivariate
+    sys.path.insert(0, HERE)
+    import host_mirror_cases
+    for m in (ref_algebra, ref_univariate, ref_multivariate):
+        assert m.__file__.startswith("/root/reference/"), m.__file__
+    dump("host_mirror.json", host_mirror_cases.run_cases(ref_algebra, ref_univariate, ref_multivariate))
+
+
 def gen_stark_synth(cases):
     """The workload bench.py times for BASELINE configs[4] -- workloads.synthetic_stark_instance: the 2-register AIR (a, b) -> (b, a*a + b),
     T = 2^(log_fri - 4) - 4 s rows, expansion factor 4, s colinearity checks, security level 2 s -- proven by the REFERENCE's
@@ -435,6 +447,8 @@ if __name__ == "__main__":
         # --stark-synth [log_fri:s:seed ...]; default: the sizes that take minutes in all
         given = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:] if ":" in a]
         gen_stark_synth(given or [(10, 8, 21), (12, 40, 22), (14, 40, 23)])
+    elif "--host-mirror" in sys.argv:
+        gen_host_mirror()
     elif "--stark" in sys.argv:
         gen_stark()
     elif "--poly" in sys.argv:

@@ -99,3 +99,24 @@ def test_divmod_golden_oracle_and_host():
         assert po.schoolbook_divmod(a, b) == (want_q, want_r)
         q, r = Polynomial.divide(poly(a), poly(b))
         assert (vals(q), vals(r)) == (want_q, want_r)
+
+
+def test_seeded_differential_cases_against_the_reference():
+    """tests/golden/host_mirror_cases.py: 400 + 200 + 200 + 200 seeded cases whose results the REFERENCE's own algebra / univariate /
+    multivariate produced (tests/golden/make_golden.py --host-mirror; digests in host_mirror.json) -- values, list lengths with
+    trailing zeros, the order of MPolynomial dictionaries, exception types of degenerate operands, repeated abscissas in
+    interpolate_domain (Field.inverse(0) = 0), `==` across lists of different length, str(), pickle bytes of FieldElement lists."""
+    import importlib
+    import os
+    import sys
+    from conftest import load_golden, REPO
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    import host_mirror_cases
+    algebra, univariate, multivariate = (importlib.import_module(m) for m in ("algebra", "univariate", "multivariate"))
+    assert all(os.path.dirname(m.__file__) == os.path.join(REPO, "stark-anatomy_amd") for m in (algebra, univariate, multivariate))
+    want = load_golden("host_mirror.json")
+    got = host_mirror_cases.run_cases(algebra, univariate, multivariate)
+    for group in ("field", "univariate", "interpolate", "multivariate"):
+        assert len(got[group]) == len(want[group]) > 0
+        differing = [i for i, (g, w) in enumerate(zip(got[group], want[group])) if g != w]
+        assert differing == [], (group, differing[:10])
