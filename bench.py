@@ -490,6 +490,13 @@ def main():
                 out["extras"] = extras(sc, lib, stream)
             except Exception as e:       # side measurements never invalidate the headline
                 out["extras"] = {"error": repr(e)}
+        two = out.get("extras", {}).get("ntt_fwd_inv_2p20_two_columns_two_streams") if isinstance(out.get("extras"), dict) else None
+        if two and "elements_per_s" in two:
+            # beside the headline (one transform at a time, BASELINE configs[1]): what the same kernels carry with two independent
+            # columns in flight on two HIP streams
+            out["two_columns_in_flight"] = {"value": two["elements_per_s"], "unit": "field-elements/s", "frac_of_hbm_roofline": two["frac"],
+                                            "gain_over_one_stream": two["gain"], "roundtrip_bit_exact": two["roundtrip_bit_exact"],
+                                            "note": "NOT the headline: two independent 2^20 forward+inverse transforms on two HIP streams; details in extras"}
         if not args.no_cpu_baseline and not sharded and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
         emit(out)
