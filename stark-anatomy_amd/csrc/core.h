@@ -111,6 +111,7 @@ struct Ctx {
     std::map<OuterKey, OuterTable> outers;
     uint64_t tick = 0;       // bumped by every table lookup
     bool foreign_streams = false;   // a caller-owned stream has been used (see pick_stream)
+    int small_divisor_direct = 1;    // coset_divide_core evaluates a divisor of <= 8 coefficients point by point instead of transforming it (sc_set_tuning("small_divisor_direct", 0): A/B and tests)
     std::vector<hipStream_t> seen_streams;   // those streams, most recent last (at most SEEN_STREAMS; more: device-wide waits)
     DevBuf scratch[8];       // 0: ntt work, 1..3: poly temporaries, 4: misc small, 5: merkle staging, 6: uploaded operands, 7: degree / exactness flag
     std::map<hipStream_t, DevBuf> ntt_work;   // the work buffer of a multi-pass transform, one per stream: transforms on DIFFERENT streams may be in flight together

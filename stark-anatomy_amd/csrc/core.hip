@@ -112,6 +112,19 @@ __global__ void __launch_bounds__(256) pointwise_div_kernel(const Fe* __restrict
     }
 }
 
+// out[i] = b(offset * root^i) for a SHORT polynomial b (nb <= SMALL_DIVISOR coefficients, canonical): what ntt(scale(b)) computes with
+// three passes over `order` elements, by Horner at every point -- the two- and three-coefficient boundary zerofiers of
+// fast_stark.py:93-98 are divided by on a 2^21-point coset twice per proof.  Same values (exact arithmetic), same place in the flow.
+constexpr uint64_t SMALL_DIVISOR = 8;
+__global__ void __launch_bounds__(256) short_poly_coset_kernel(const Fe* __restrict__ b, uint32_t nb, Fe off_m, const Fe* __restrict__ tl, const Fe* __restrict__ th, Fe* __restrict__ out, uint64_t order) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= order) return;
+    const Fe x_m = mont_mul(off_m, pow2level(tl, th, i));          // (offset * root^i) in Montgomery form
+    Fe acc = b[nb - 1];
+    for (uint32_t k = nb - 1; k-- > 0;) acc = fe_add(mont_mul(acc, x_m), b[k]);
+    out[i] = acc;
+}
+
 // out[i] = in[i] * base^i  (Polynomial.scale, code/univariate.py:153-154) via the two-level power table
 __global__ void __launch_bounds__(256) scale_pow_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, uint64_t n, const Fe* __restrict__ lo, const Fe* __restrict__ hi) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -852,6 +865,7 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "prune") g.tuning.prune = value;
     else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "fri_tail") g.fri_tail = value ? 1 : 0;
+    else if (k == "small_divisor_direct") g.small_divisor_direct = value ? 1 : 0;
     else if (k == "fri_tail_stall") g.fri_tail_stall = value;                               // tests only: see core.h
     else if (k == "pool_cap_mb") g_pool_cap = (size_t)(value < 0 ? 0 : value) << 20;       // what the free lists may keep from now on
     else if (k == "pool_trim") {                                                            // give everything in the free lists back to the device now
@@ -1276,8 +1290,15 @@ static int coset_divide_core(const Fe* d_a, uint64_t na, const Fe* d_b, uint64_t
     o.coset = pw;
     o.in_limit = na;
     SCCHK(ntt_device(d_a, (Fe*)da, logn, rt, false, o, st));
-    o.in_limit = nb;
-    SCCHK(ntt_device(d_b, (Fe*)db, logn, rt, false, o, st));
+    if (nb <= SMALL_DIVISOR && g.small_divisor_direct) {
+        PlanTables* pt;
+        SCCHK(get_plan(rt, logn, false, st, &pt));                 // (the numerator's transform has just used these tables)
+        hipLaunchKernelGGL(short_poly_coset_kernel, dim3((unsigned)((order + 255) / 256)), dim3(256), 0, st, d_b, (uint32_t)nb, to_mont(off), pt->tl, pt->th, (Fe*)db, order);
+        HIPCHK(hipGetLastError());
+    } else {
+        o.in_limit = nb;
+        SCCHK(ntt_device(d_b, (Fe*)db, logn, rt, false, o, st));
+    }
     SCCHK(pointwise_div_device((const Fe*)da, (const Fe*)db, (Fe*)dc, order, st));
     SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, root_inverse(rt, order), true, NttOpts{}, st));
     // unscale by offset^-1 (ntt.py:176)

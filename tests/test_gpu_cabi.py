@@ -299,6 +299,47 @@ def test_poly_mul_and_divide(sc):
     assert synth.unpack_ints(quo.raw) == synth.synth_ints(5, 9)
 
 
+def test_coset_divide_by_a_short_divisor_direct_and_transformed(sc):
+    """A divisor of at most 8 coefficients (the boundary zerofiers of fast_stark.py:93-98 have two or three) is evaluated on the coset
+    point by point (short_poly_coset_kernel) instead of being scaled and transformed: the same values, hence the same quotient as with
+    sc_set_tuning("small_divisor_direct", 0) and as the oracle's restatement of ntt.py:137-176 -- for exact and inexact divisions, one-
+    to eight- and nine-coefficient divisors (the last takes the transform either way), orders with one, two and three passes."""
+    lib = sc.lib()
+    try:
+        for k, (lq, ld, order) in enumerate([(9, 1, 16), (30, 2, 64), (700, 3, 1024), (3000, 8, 1 << 12), (3000, 9, 1 << 12), (50000, 3, 1 << 16), ((1 << 20) + 5, 2, 1 << 21)]):
+            q, d = synth.synth_ints(3000 + k, lq), synth.synth_ints(3100 + k, ld)
+            d[-1] = d[-1] or 1
+            root = po.primitive_nth_root(order)
+            if lq * ld <= 3000 * 9:
+                lhs = po.schoolbook_mul(q, d)
+            else:                                    # (exact product through the oracle's transforms)
+                big = order * 2
+                rb = po.primitive_nth_root(big)
+                ca = C.ntt(rb, synth.pack_ints(q) + bytes(16 * (big - lq)), big)
+                cb = C.ntt(rb, synth.pack_ints(d) + bytes(16 * (big - ld)), big)
+                lhs = synth.unpack_ints(C.intt(rb, C.pointwise_mul(ca, cb, big), big))[:lq + ld - 1]
+            for exact in (True, False):
+                num = list(lhs) if exact else [(v + 1) % P for v in lhs]       # an inexact division: what comes out is still the reference's
+                n_out = lq
+                got = {}
+                for direct in (1, 0):
+                    sc.set_tuning("small_divisor_direct", direct)
+                    out = ctypes.create_string_buffer(16 * n_out)
+                    sc._check(lib.sc_coset_divide(synth.pack_ints(num), len(num), synth.pack_ints(d), ld, sc.fe_bytes(po.GENERATOR), sc.fe_bytes(root), order, out, n_out))
+                    got[direct] = out.raw
+                assert got[1] == got[0], (lq, ld, order, exact)
+                if exact:
+                    assert synth.unpack_ints(got[1]) == q, (lq, ld, order)
+                elif order <= 1 << 12:
+                    # ntt.py:159-176 with the oracle's primitives: transform both on the coset, divide value by value, come back, unscale
+                    ca = C.coset_evaluate(synth.pack_ints(num), len(num), po.GENERATOR, root, order)
+                    cb = C.coset_evaluate(synth.pack_ints(d), ld, po.GENERATOR, root, order)
+                    back = C.scale(C.intt(root, C.pointwise_div(ca, cb, order), order), order, pow(po.GENERATOR, -1, P))
+                    assert got[1] == back[:16 * n_out], (lq, ld, order)
+    finally:
+        sc.set_tuning("small_divisor_direct", 1)
+
+
 def test_golden_multiply_divide_via_cabi_sizes(sc):
     g = load_golden("poly.json")
     rec = [r for r in g["multiply"] if r.get("order") == 1024][0]
