@@ -801,7 +801,7 @@ def extras(sc, lib, stream=None):
     # configs[4] as a real prover on ONE GPU: fast_stark.FastStark.prove (reference code/fast_stark.py:76-178) on the synthetic
     # 2-register AIR, 2^20-row randomized trace resident in HBM, FRI domain 2^24; verified outside the timed region
     try:
-        res["stark_prove_2p24_1gpu"] = plain_stark_prove_measure(24, 3)
+        res["stark_prove_2p24_1gpu"] = plain_stark_prove_measure(24, 8)
     except Exception as e:
         res["stark_prove_2p24_1gpu"] = {"error": repr(e)}
     return res

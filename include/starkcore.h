@@ -45,6 +45,7 @@ extern "C" {
 
 typedef struct sc_vec sc_vec_t;        /* device-resident vector of field elements */
 typedef struct sc_merkle sc_merkle_t;  /* device-resident BLAKE2b Merkle tree (all levels kept) */
+typedef struct sc_later sc_later_t;    /* a check whose words arrive behind the work that produces them (sc_*_later_dev, sc_later_wait) */
 typedef struct sc_polytree sc_polytree_t; /* device-resident subproduct tree over a list of points (all levels kept) */
 typedef struct sc_geodomain sc_geodomain_t; /* tables of a domain that is a geometric progression first * ratio^i */
 
@@ -202,6 +203,17 @@ int sc_coset_divide(const void* a, uint64_t na, const void* b, uint64_t nb, cons
  * quotient has fewer than n_out coefficients" that Polynomial.__truediv__ asserts (code/univariate.py:99-103) */
 int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order,
                         void* d_out, uint64_t n_out, int* exact, void* stream);
+/* The same division, and the pointwise division of code/ntt.py:172 on its own, with NOTHING waited for: what the reference asserts on
+ * the spot -- "divide by zero" (code/algebra.py:92) and, for the coset division, a zero remainder (code/univariate.py:99-103) -- is
+ * decided on the device and arrives in *later behind the work; sc_later_wait returns words_out[0] != 0: a divisor value was zero;
+ * words_out[1]: the highest index, counted from n_out, of a non-zero coefficient of the interpolant above the quotient, -1 iff the
+ * division is exact (always -1 for the pointwise form).  A prover collects its checks where it has to wait anyway (before the next
+ * Fiat-Shamir challenge) instead of idling the GPU at every division.  sc_later_wait frees the handle (it is also how one is abandoned).
+ * SC_ERR_UNSUPPORTED: no pinned slot free -- use the waiting forms. */
+int sc_coset_divide_later_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order,
+                              void* d_out, uint64_t n_out, sc_later_t** later, void* stream);
+int sc_pointwise_div_later_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, sc_later_t** later, void* stream);
+int sc_later_wait(sc_later_t* later, int64_t words_out[8]);
 /* Polynomial.degree (code/univariate.py:7-17) of a coefficient vector in HBM: index of the last non-zero entry, -1 if none (synchronous) */
 int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* stream);
 

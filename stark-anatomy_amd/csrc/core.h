@@ -40,6 +40,11 @@ struct sc_vec {
     uint64_t n;
     bool owned = true;    // false: a view of memory somebody else owns (sc_vec_wrap: a torch tensor's storage) -- sc_vec_free leaves it alone
 };
+struct sc_later {           // a few words a kernel will write to a pinned slot (deferred checks: include/starkcore.h sc_later_t)
+    int slot;
+    uint64_t seq;
+    hipStream_t st;
+};
 struct sc_merkle {
     uint64_t* d_levels;   // (2N-1) digests of 8 x u64
     uint64_t N;
@@ -203,6 +208,7 @@ int ntt_any(const Fe* d_in, Fe* d_out, uint64_t n, Fe root, bool inverse, const 
 int upload(void* d, const void* h, size_t bytes, hipStream_t st);
 int download(void* h, const void* d, size_t bytes, hipStream_t st);
 int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st);
+int pointwise_div_enqueue(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st, uint32_t** flag_dev);
 int gather_device(const Fe* v, const uint64_t* d_idx, uint64_t k, Fe* d_out, hipStream_t st);
 int read_small_polled(const void* d_src, size_t bytes, hipStream_t st, void* host_out);
 

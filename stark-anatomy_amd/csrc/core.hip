@@ -698,16 +698,24 @@ int download(void* h, const void* d, size_t bytes, hipStream_t st) {
     return SC_OK;
 }
 
-int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st) {
+// the division only enqueued: *flag_dev (a word of this stream's scratch, valid until the next division on the stream clears it)
+// becomes non-zero if a divisor is zero
+int pointwise_div_enqueue(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st, uint32_t** flag_dev) {
     void* fl;
     SCCHK(scratch(4, 256, &fl));
-    HIPCHK(hipMemsetAsync(fl, 0, 4, st));
+    HIPCHK(hipMemsetAsync(fl, 0, 8, st));
     static const int K = [] { const char* e = getenv("STARKCORE_DIV_K"); return e && atoi(e) == 8 ? 8 : 16; }();      // (A/B knob)
     const uint64_t threads = (n + K - 1) / K;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     if (K == 8) hipLaunchKernelGGL(pointwise_div_kernel<8>, dim3(blocks), dim3(256), 0, st, a, b, out, n, (uint32_t*)fl);
     else hipLaunchKernelGGL(pointwise_div_kernel<16>, dim3(blocks), dim3(256), 0, st, a, b, out, n, (uint32_t*)fl);
     HIPCHK(hipGetLastError());
+    *flag_dev = (uint32_t*)fl;
+    return SC_OK;
+}
+int pointwise_div_device(const Fe* a, const Fe* b, Fe* out, uint64_t n, hipStream_t st) {
+    uint32_t* fl;
+    SCCHK(pointwise_div_enqueue(a, b, out, n, st, &fl));
     uint64_t hflag = 0;
     SCCHK(read_small_polled(fl, 8, st, &hflag));                  // (the flag is the low 32 bits of a word of the scratch buffer)
     if ((uint32_t)hflag) return fail(SC_ERR_DIV_ZERO, "divide by zero");
@@ -755,6 +763,59 @@ int read_small_polled(const void* d_src, size_t bytes, hipStream_t st, void* hos
     if (landed) memcpy(host_out, (const void*)host, bytes);
     else (void)hipStreamSynchronize(st);                       // nothing may still write to the slot when it is reused
     g.free_root_slots.push_back(slot);
+    if (!landed) return fail(SC_ERR_HIP, hipGetErrorString(e));
+    return SC_OK;
+}
+
+// ---- checks that are read LATER (sc_later_t).  A division's "divide by zero" flag and the exactness of a coset division are only
+// ever asserted on; a prover that waits for each of them where the reference raises leaves the GPU idle a dozen times per proof
+// (tools/sync_points.py).  The flags travel like the roots of asynchronously built trees -- a one-wave kernel behind the work writes
+// them to a pinned slot, then a sequence number -- and the caller collects them where it has to wait anyway.
+//   words[0] != 0 : a divisor value was zero      words[1] : highest index of a non-zero coefficient above the quotient, -1 if none
+__global__ void __launch_bounds__(64) divide_flags_publish_kernel(const uint32_t* __restrict__ zero_flag, const long long* __restrict__ degree_slots,
+                                                                 volatile uint64_t* host, uint64_t seq) {
+    if (threadIdx.x == 0) {
+        long long m = -1;
+        if (degree_slots) for (int i = 0; i < DEGREE_SLOTS; ++i) m = degree_slots[i] > m ? degree_slots[i] : m;
+        host[0] = zero_flag ? (uint64_t)*zero_flag : 0ull;
+        host[1] = (uint64_t)m;
+        __threadfence_system();
+        host[8] = seq;
+    }
+}
+int divide_flags_later(const uint32_t* zero_flag, const long long* degree_slots, hipStream_t st, sc_later** out) {
+    const int slot = root_slot_get();
+    if (slot < 0) return fail(SC_ERR_UNSUPPORTED, "no pinned slot free for a deferred check");
+    sc_later* h = new sc_later{slot, ++g.root_seq, st};
+    volatile uint64_t* host = (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * slot);
+    hipLaunchKernelGGL(divide_flags_publish_kernel, dim3(1), dim3(64), 0, st, zero_flag, degree_slots, host, h->seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g.free_root_slots.push_back(slot); delete h; return fail(SC_ERR_HIP, hipGetErrorString(e)); }
+    *out = h;
+    return SC_OK;
+}
+int later_wait(sc_later* h, uint64_t words[8]) {
+    volatile uint64_t* host = (volatile uint64_t*)(g.root_slots + ROOT_SLOT_BYTES * h->slot);
+    bool landed = false;
+    hipError_t e = hipSuccess;
+    for (long spin = 0; spin < SPIN_POLLS; ++spin) {
+        if (__atomic_load_n(host + 8, __ATOMIC_ACQUIRE) == h->seq) { landed = true; break; }
+        if ((spin & 4095) == 4095) {
+            e = hipStreamQuery(h->st);
+            if (e != hipErrorNotReady) break;
+            (void)hipGetLastError();
+            e = hipSuccess;
+        }
+    }
+    if (!landed) {
+        (void)hipGetLastError();
+        e = hipStreamSynchronize(h->st);
+        landed = e == hipSuccess && __atomic_load_n(host + 8, __ATOMIC_ACQUIRE) == h->seq;
+        if (e == hipSuccess && !landed) e = hipErrorUnknown;
+    }
+    if (landed) memcpy(words, (const void*)host, 64);
+    g.free_root_slots.push_back(h->slot);
+    delete h;
     if (!landed) return fail(SC_ERR_HIP, hipGetErrorString(e));
     return SC_OK;
 }
@@ -1278,7 +1339,8 @@ int sc_poly_mul(const void* a, uint64_t na, const void* b, uint64_t nb, const ui
 // ---- coset divide
 // core of fast_coset_divide (code/ntt.py:159-176) on device operands: ALL `order` coefficients of the unscaled interpolant of
 // ntt(scale(a)) / ntt(scale(b)) land in scratch slot 2 (returned in *full)
-static int coset_divide_core(const Fe* d_a, uint64_t na, const Fe* d_b, uint64_t nb, Fe off, Fe rt, uint64_t order, Fe** full, hipStream_t st) {
+// zero_flag_dev != nullptr: the pointwise division is only enqueued and *zero_flag_dev names its "divide by zero" word (deferred check)
+static int coset_divide_core(const Fe* d_a, uint64_t na, const Fe* d_b, uint64_t nb, Fe off, Fe rt, uint64_t order, Fe** full, hipStream_t st, uint32_t** zero_flag_dev = nullptr) {
     void *da, *db, *dc;
     SCCHK(scratch(1, order * sizeof(Fe), &da));
     SCCHK(scratch(2, order * sizeof(Fe), &db));
@@ -1299,7 +1361,8 @@ static int coset_divide_core(const Fe* d_a, uint64_t na, const Fe* d_b, uint64_t
         o.in_limit = nb;
         SCCHK(ntt_device(d_b, (Fe*)db, logn, rt, false, o, st));
     }
-    SCCHK(pointwise_div_device((const Fe*)da, (const Fe*)db, (Fe*)dc, order, st));
+    if (zero_flag_dev) SCCHK(pointwise_div_enqueue((const Fe*)da, (const Fe*)db, (Fe*)dc, order, st, zero_flag_dev));
+    else SCCHK(pointwise_div_device((const Fe*)da, (const Fe*)db, (Fe*)dc, order, st));
     SCCHK(ntt_device((const Fe*)dc, (Fe*)da, logn, root_inverse(rt, order), true, NttOpts{}, st));
     // unscale by offset^-1 (ntt.py:176)
     Fe off_inv = from_mont(mont_inv(to_mont(off)));
@@ -1363,6 +1426,44 @@ int sc_coset_divide_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t 
         *exact = deg < 0 ? 1 : 0;
     }
     return SC_OK;
+}
+
+int sc_coset_divide_later_dev(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, const uint64_t offset[2], const uint64_t root[2], uint64_t order,
+                              void* d_out, uint64_t n_out, sc_later_t** later, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!later) return fail(SC_ERR_BAD_ARG, "null argument");
+    Fe rt, off;
+    SCCHK(coset_divide_args(na, nb, n_out, offset, root, order, &rt, &off));
+    hipStream_t st = pick_stream(stream);
+    Fe* full;
+    uint32_t* zero_flag = nullptr;
+    SCCHK(coset_divide_core((const Fe*)d_a, na, (const Fe*)d_b, nb, off, rt, order, &full, st, &zero_flag));
+    if (n_out) HIPCHK(hipMemcpyAsync(d_out, full, n_out * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+    void* fl;
+    SCCHK(scratch(7, 256, &fl));
+    HIPCHK(hipMemsetAsync(fl, 0xFF, DEGREE_SLOTS * sizeof(long long), st));
+    if (order > n_out) {
+        const uint64_t cnt = order - n_out;
+        hipLaunchKernelGGL(vec_degree_kernel, dim3(degree_blocks(cnt)), dim3(256), 0, st, (const Fe*)full + n_out, cnt, (long long*)fl);
+        HIPCHK(hipGetLastError());
+    }
+    return divide_flags_later(zero_flag, (const long long*)fl, st, later);
+}
+int sc_pointwise_div_later_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, sc_later_t** later, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    if (!later || !n) return fail(SC_ERR_BAD_ARG, "null argument");
+    hipStream_t st = pick_stream(stream);
+    uint32_t* zero_flag = nullptr;
+    SCCHK(pointwise_div_enqueue((const Fe*)d_a, (const Fe*)d_b, (Fe*)d_out, n, st, &zero_flag));
+    return divide_flags_later(zero_flag, nullptr, st, later);
+}
+int sc_later_wait(sc_later_t* later, int64_t words_out[8]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!later || !words_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    SCCHK(ensure_init());
+    return later_wait(later, (uint64_t*)words_out);
 }
 
 int sc_vec_degree_dev(const void* d_v, uint64_t n, int64_t* degree_out, void* stream) {

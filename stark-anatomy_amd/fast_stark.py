@@ -274,6 +274,11 @@ class FastStark:
                 columns = [DeviceCodeword.from_list([row[s] for row in trace], field) for s in registers]
         interpolants = self.boundary_interpolants(boundary)
         zerofiers = self.boundary_zerofiers(boundary)
+        # Checks the reference makes on the spot and nothing but an assertion reads -- a zero remainder of the boundary divisions
+        # (univariate.py:99-103), "divide by zero" in the pointwise divisions (algebra.py:92) -- are decided on the device and COLLECTED
+        # here; they are run where the prover has to wait for the device anyway, before the Fiat-Shamir challenge below, and raise
+        # there what the reference raises at the division (the proof stream then holds the commitments pushed so far).
+        pending = [] if on_device and not FastStark.EAGER_COMMITS else None
         if on_device:
             # Polynomials live in HBM from here on (DevicePolynomial): interpolation, boundary quotients (exact coset division,
             # exactness decided on the device), the AIR substitution in the value domain, the transition quotients, the LDEs and
@@ -283,7 +288,7 @@ class FastStark:
             self._mark("trace interpolation")
             zerofiers_dev = [DevicePolynomial.from_polynomial(z, field) for z in zerofiers]
             boundary_quotients = [coset_divide_device(trace_polynomials[s].minus(interpolants[s]), zerofiers_dev[s], self.generator, self.omicron,
-                                                      self.omicron_domain_length, exact=True) for s in registers]
+                                                      self.omicron_domain_length, exact=True, later=pending) for s in registers]
             lde = lambda poly: poly.coset_evaluate(self.generator, self.omega, self.fri_domain_length)
         else:
             # trace polynomials through {omicron^i}
@@ -315,7 +320,7 @@ class FastStark:
         point = [DevicePolynomial.from_polynomial(x, field) if on_device else x] + trace_polynomials + \
                 [tp.scaled_later(self.omicron) if on_device else tp.scale(self.omicron) for tp in trace_polynomials]
         if on_device:
-            transition_quotients = self._transition_quotients_on_device(transition_constraints, point, self._lift(transition_zerofier))
+            transition_quotients = self._transition_quotients_on_device(transition_constraints, point, self._lift(transition_zerofier), pending)
         else:
             transition_polynomials = [a.evaluate_symbolic(point) for a in transition_constraints]
             transition_quotients = [fast_coset_divide(tp, transition_zerofier, self.generator, self.omicron, self.omicron_domain_length) for tp in transition_polynomials]
@@ -333,6 +338,8 @@ class FastStark:
         commit(randomizer_codeword)
         self._mark("randomizer polynomial: LDE, commitment")
 
+        for verdict in pending or ():                    # the collected checks: the device has long decided them
+            verdict()
         # Fiat-Shamir weights: 1 randomizer + 2 per transition quotient + 2 per boundary quotient
         weights = self.sample_weights(1 + 2 * len(transition_quotients) + 2 * len(boundary_quotients), proof_stream.prover_fiat_shamir())
         tq_bounds = self.transition_quotient_degree_bounds(transition_constraints)
@@ -393,7 +400,7 @@ class FastStark:
         self._mark("proof serialization (host pickle)")
         return proof
 
-    def _transition_quotients_on_device(self, constraints, point, tz_dev):
+    def _transition_quotients_on_device(self, constraints, point, tz_dev, pending=None):
         """fast_stark.py:107-113 -- `a.evaluate_symbolic(point)` divided by the transition zerofier -- without ever building the
         transition polynomial: on the coset g * <root'> (root' of the order code/ntt.py:155-157 shrinks to, taken from the degree
         BOUND) the point polynomials are evaluated once for all constraints of that order, the AIR is evaluated value by value
@@ -464,7 +471,7 @@ class FastStark:
                 tvals, whole = DeviceVector(order), DeviceVector(order)
                 _sc._check(lib.sc_mpoly_eval_rot_dev(vals.ptr, nvars, order, exps, coefs, len(terms), tvals.ptr, converted, var_src, var_rot, None))
                 converted = 1
-                _sc._check(lib.sc_pointwise_div_dev(tvals.ptr, zvals.ptr, tvals.ptr, order, None))      # "divide by zero" like algebra.py:92
+                self._pointwise_divide(tvals, zvals, order, pending)                                    # "divide by zero" like algebra.py:92
                 _sc._check(lib.sc_ntt_dev(tvals.ptr, whole.ptr, order, rt, 1, None))
                 _sc._check(lib.sc_scale_dev(whole.ptr, whole.ptr, order, _sc.fe_bytes(self.generator.inverse().value), None))
                 quotient = DevicePolynomial(whole, field, order)
@@ -474,6 +481,23 @@ class FastStark:
                 out[i] = DevicePolynomial(whole, field, degree + 1) if degree >= 0 else DevicePolynomial(DeviceVector(1), field, 0)
                 out[i]._degree = degree                                  # just read: the degree check of fast_stark.py:124 need not ask the device again
         return [q if q is not None else reference_way(a) for q, a in zip(out, constraints)]
+
+    @staticmethod
+    def _pointwise_divide(numerator, denominator, count, pending):
+        """numerator[i] /= denominator[i] on the device; with a list of pending checks the "divide by zero" verdict is collected, not waited for"""
+        lib = _sc.lib()
+        if pending is not None:
+            handle = ctypes.c_void_p()
+            rc = lib.sc_pointwise_div_later_dev(numerator.ptr, denominator.ptr, numerator.ptr, count, ctypes.byref(handle), None)
+            if rc != _sc.SC_ERR_UNSUPPORTED:
+                _sc._check(rc)
+                check = _sc.Later(handle)
+
+                def verdict():
+                    assert(not check.wait()[0]), "divide by zero"
+                pending.append(verdict)
+                return
+        _sc._check(lib.sc_pointwise_div_dev(numerator.ptr, denominator.ptr, numerator.ptr, count, None))
 
     def _randomized_columns(self, trace, raw):
         """the columns of a DeviceTrace with the randomizer rows appended (fast_stark.py:79-81): `raw` holds the draws of

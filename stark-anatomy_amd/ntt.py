@@ -290,6 +290,10 @@ class DevicePolynomial:
         out = self.copy(max(self.n, len(coeffs)))
         if coeffs:
             out.vec.axpy_shift(DeviceVector.from_bytes(_pack(coeffs)), 0, self.field.p - 1)
+        # a subtrahend of lower degree leaves the degree alone: asked of `self` (once, and remembered there -- the prover needs the
+        # trace polynomials' degrees again for the transition quotients) instead of of the difference
+        if polynomial.degree() < self.degree():
+            out._degree = self._degree
         return out
 
     def scale(self, factor):
@@ -352,9 +356,12 @@ class _View:
         self.ptr, self.n = vec.ptr, n
 
 
-def coset_divide_device(lhs, rhs, offset, primitive_root, root_order, exact=False):
+def coset_divide_device(lhs, rhs, offset, primitive_root, root_order, exact=False, later=None):
     """fast_coset_divide (code/ntt.py:137-176) on DevicePolynomials: lhs.degree() - rhs.degree() + 1 coefficients, in HBM.
-    exact=True additionally asserts what Polynomial.__truediv__ asserts (a zero remainder), decided on the device."""
+    exact=True additionally asserts what Polynomial.__truediv__ asserts (a zero remainder), decided on the device.
+    later (a list, with exact=True): the division is only enqueued and a check is appended to the list -- a callable that waits for
+    the device's verdict and raises what this call would have raised ("divide by zero", a non-zero remainder); the caller runs its
+    checks where it has to wait anyway.  The quotient's degree is what an exact division leaves, which the check confirms."""
     _check_root(primitive_root, root_order)
     assert(not rhs.is_zero()), "cannot divide by zero polynomial"
     field = lhs.field
@@ -365,6 +372,22 @@ def coset_divide_device(lhs, rhs, offset, primitive_root, root_order, exact=Fals
     root, order = _shrink_order(primitive_root, root_order, max(dl, dr))
     n_out = dl - dr + 1
     out = DeviceVector(n_out)
+    if exact and later is not None:
+        handle = ctypes.c_void_p()
+        rc = _sc.lib().sc_coset_divide_later_dev(lhs.vec.ptr, dl + 1, rhs.vec.ptr, dr + 1, _sc.fe_bytes(offset.value), _sc.fe_bytes(root.value), order,
+                                                 out.ptr, n_out, ctypes.byref(handle), None)
+        if rc != _sc.SC_ERR_UNSUPPORTED:
+            _sc._check(rc)
+            check = _sc.Later(handle)
+
+            def verdict():
+                zero_divisor, remainder = check.wait()
+                assert(not zero_divisor), "divide by zero"
+                assert(not remainder), "cannot perform polynomial division because remainder is not zero"
+            later.append(verdict)
+            quotient = DevicePolynomial(out, field, n_out)
+            quotient._degree = dl - dr
+            return quotient
     flag = ctypes.c_int(0)
     _sc._check(_sc.lib().sc_coset_divide_dev(lhs.vec.ptr, dl + 1, rhs.vec.ptr, dr + 1, _sc.fe_bytes(offset.value), _sc.fe_bytes(root.value), order,
                                              out.ptr, n_out, ctypes.byref(flag) if exact else None, None))

@@ -84,6 +84,9 @@ SIGNATURES = {
     "sc_vec_degree_dev": (_int, [_vp, _u64, ctypes.POINTER(ctypes.c_int64), _vp]),
     "sc_pointwise_mul_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "sc_pointwise_div_dev": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "sc_coset_divide_later_dev": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "sc_pointwise_div_later_dev": (_int, [_vp, _vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "sc_later_wait": (_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "sc_scale_dev": (_int, [_vp, _vp, _u64, _vp, _vp]),
     "sc_axpy_shift_dev": (_int, [_vp, _u64, _vp, _u64, _u64, _vp, _vp]),
     "sc_scale_slab_dev": (_int, [_vp, _vp, _u64, _u64, _u64, _u64, _vp, _vp]),
@@ -395,6 +398,29 @@ class _HostMemory:
         p, self.ptr = getattr(self, "ptr", None), None
         if p is not None and _lib is not None:
             _lib.sc_host_free(p)
+
+
+class Later:
+    """A check that is read later (include/starkcore.h sc_later_t): the flags of a division enqueued with sc_*_later_dev.  `wait()`
+    -> (a divisor value was zero, the division left a remainder), once; a handle nobody waited for is collected when it is dropped."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def wait(self):
+        words = (ctypes.c_int64 * 8)()
+        h, self._h = self._h, None
+        _check(lib().sc_later_wait(h, words))
+        return words[0] != 0, words[1] >= 0
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            try:
+                words = (ctypes.c_int64 * 8)()
+                lib().sc_later_wait(self._h, words)
+            except Exception:      # noqa: BLE001  (interpreter shutdown)
+                pass
+            self._h = None
 
 
 class HostBuffer:

@@ -251,7 +251,8 @@ def plain_stark_prove_measure(log_fri, steps):
     tz, tz_codeword, root = stark.preprocess(device_resident=True)
     sc.synchronize()
     preprocess_s = time.perf_counter() - t0
-    stark.prove(trace, air, boundary, tz, tz_codeword)
+    for _ in range(4):                                 # untimed: pool, tables, plans and the board's clock settle over the first few proofs
+        stark.prove(trace, air, boundary, tz, tz_codeword)
     runs, proof = [], None
     for _ in range(steps):
         sc.synchronize()
@@ -261,7 +262,7 @@ def plain_stark_prove_measure(log_fri, steps):
         runs.append(time.perf_counter() - t0)
     t0 = time.perf_counter()
     verifies = bool(stark.verify(proof, air, boundary, root))
-    return {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_1gpu" % (log_fri - 4, log_fri), "ms_per_proof": 1e3 * min(runs),
+    return {"workload": "faststark_prove_synthetic_air_trace_2^%d_fri_2^%d_1gpu" % (log_fri - 4, log_fri), "ms_per_proof": 1e3 * min(runs), "median_ms": 1e3 * sorted(runs)[len(runs) // 2],
             "runs_ms": [round(1e3 * r, 3) for r in runs], "registers": 2, "colinearity_checks": s, "expansion_factor": 4,
             "trace": "device-resident columns (fast_stark.DeviceTrace)", "proof_bytes": len(proof), "verify_accepts": verifies,
             "verify_s": time.perf_counter() - t0, "preprocess_s": preprocess_s,
