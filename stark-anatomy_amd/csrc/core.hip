@@ -14,8 +14,12 @@ __global__ void __launch_bounds__(PassThreads<LOGE>::value) ntt_pass_kernel(cons
     Fe* lds = reinterpret_cast<Fe*>(smem_raw);
     // XCD-aware tile mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of tiles so
     // that neighbouring tiles (which share twiddle rows and adjacent memory) stay within one L2.
-    uint32_t tile = blockIdx.x;
-    if (xcd_remap) tile = (blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3);
+    // (a launch over several columns -- P.col_enable -- repeats the same mapping column after column: ntiles is per column)
+    uint32_t wg = blockIdx.x, colbits = 0;
+    if (P.col_enable) { colbits = (wg >> P.col_tiles_log) << P.col_tiles_log; wg -= colbits; }
+    uint32_t tile = wg;
+    if (xcd_remap) tile = (wg & 7u) * (ntiles >> 3) + (wg >> 3);
+    tile |= colbits;
     Fe* tw = lds + (1u << (P.logR + P.logC));
     tile_twiddles_to_lds(P, P.logR, threadIdx.x, blockDim.x, tw);
     __syncthreads();
@@ -45,8 +49,11 @@ __global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed
             if ((threadIdx.x & 63u) == 0) { trow[0] = __builtin_amdgcn_s_memtime(); trow[15] = __builtin_amdgcn_s_memrealtime(); }
         }
     }
-    uint32_t tile = blockIdx.x;
-    if (xcd_remap) tile = (blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3);
+    uint32_t wg = blockIdx.x, colbits = 0;
+    if (P.col_enable) { colbits = (wg >> P.col_tiles_log) << P.col_tiles_log; wg -= colbits; }
+    uint32_t tile = wg;
+    if (xcd_remap) tile = (wg & 7u) * (ntiles >> 3) + (wg >> 3);
+    tile |= colbits;
     Fe* tw = lds + (1u << (GLR + GLC));
     auto stamp = [&](int i) {
         if constexpr (TRACE) {
@@ -584,7 +591,7 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
         if (g.fixed_shapes) {
             const int lr = pd.p.logR, lc = pd.p.logC;
 #define SC_LAUNCH_FIXED(LR, LC, TR, ALT) \
-    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, TR, ALT>), dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local)
+    hipLaunchKernelGGL((ntt_pass_kernel_fixed<2, LR, LC, TR, ALT>), dim3(pd.ntiles * pd.cols), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local)
             // (a launch with a second destination -- the column stage of the sharded transform -- has its own instantiation; it
             // is never traced: the generic kernel serves that combination)
 #define SC_FIXED(LR, LC)                                                          \
@@ -598,15 +605,15 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
 #undef SC_FIXED
         }
     }
-    hipLaunchKernelGGL(ntt_pass_kernel<LOGE>, dim3(pd.ntiles), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap);
+    hipLaunchKernelGGL(ntt_pass_kernel<LOGE>, dim3(pd.ntiles * pd.cols), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap);
 }
 
 int run_plan(NttPlanDesc& d, hipStream_t st) {
     size_t trace_off = 0;    // diagnostics: pass i writes its stamps behind those of the passes before it
     for (int i = 0; i < d.npasses; ++i) {
-        d.pass[i].p.prio_balance = g.prio_balance >= 0 ? g.prio_balance : (d.pass[i].ntiles <= (uint32_t)g.num_cus ? 1 : 0);
+        d.pass[i].p.prio_balance = g.prio_balance >= 0 ? g.prio_balance : (d.pass[i].ntiles * d.pass[i].cols <= (uint32_t)g.num_cus ? 1 : 0);
         d.pass[i].p.trace = g.trace ? g.trace + trace_off : nullptr;
-        trace_off += (size_t)d.pass[i].ntiles * (d.pass[i].threads >> 6) * TRACE_STAMPS;
+        trace_off += (size_t)d.pass[i].ntiles * d.pass[i].cols * (d.pass[i].threads >> 6) * TRACE_STAMPS;
         switch (d.pass[i].loge) {
             case 1: launch_pass<1>(d.pass[i], st); break;
             case 2: launch_pass<2>(d.pass[i], st); break;
@@ -630,8 +637,8 @@ int ntt_device(const Fe* d_in, Fe* d_out, int logn, Fe root, bool inverse_scale,
     tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
     tb.th_scaled = (inverse_scale && m > 1) ? pt->th_ninv : nullptr;
     NttIo io;
-    io.in = d_in; io.out = d_out; io.in_limit = o.in_limit;
-    if (m > 1) { void* w; SCCHK(ntt_work_buffer(st, n * sizeof(Fe), &w)); io.work = (Fe*)w; }
+    io.in = d_in; io.out = d_out; io.in_limit = o.in_limit; io.cols = o.cols;
+    if (m > 1) { void* w; SCCHK(ntt_work_buffer(st, n * o.cols * sizeof(Fe), &w)); io.work = (Fe*)w; }
     if (o.coset) { io.ol = o.coset->lo; io.oh = o.coset->hi; }
     if (inverse_scale && m == 1) { io.scale_last = true; io.scale = mont_inv(to_mont(Fe{n, 0})); }
     NttPlanDesc d;
@@ -1199,6 +1206,32 @@ int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2]
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
     return ntt_any((const Fe*)d_in, (Fe*)d_out, n, fe_from(root), inverse != 0, NttOpts{}, pick_stream(stream));
+}
+
+// `cols` independent transforms of length n, column c at element c * n, in ONE set of launches (NttIo::cols): the workgroups of one
+// column start while those of another finish.  At most COLS_PER_LAUNCH columns per set, so that the intermediate vector stays bounded.
+constexpr uint64_t COLS_PER_LAUNCH = 64;
+int sc_ntt_columns_dev(const void* d_in, void* d_out, uint64_t n, uint64_t cols, const uint64_t root[2], int inverse, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (cols == 0) return SC_OK;
+    if (n > 1 && !is_pow2(n)) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    if (n <= 1) {
+        if (n == 1 && d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, cols * sizeof(Fe), hipMemcpyDeviceToDevice, st));
+        return SC_OK;
+    }
+    const Fe* in = (const Fe*)d_in;
+    Fe* out = (Fe*)d_out;
+    // a set of launches covers at most 2^31 tiles' worth of workgroups and 2^28 elements of intermediate vector
+    uint64_t per = COLS_PER_LAUNCH;
+    while (per > 1 && per * n > (1ull << 28)) per >>= 1;
+    for (uint64_t done = 0; done < cols; done += per) {
+        NttOpts o;
+        o.cols = (uint32_t)(cols - done < per ? cols - done : per);
+        SCCHK(ntt_any(in + done * n, out + done * n, n, fe_from(root), inverse != 0, o, st));
+    }
+    return SC_OK;
 }
 
 int sc_ntt(const void* in, void* out, uint64_t n, const uint64_t root[2], int inverse) {

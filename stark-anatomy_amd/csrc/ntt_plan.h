@@ -49,7 +49,8 @@ inline uint32_t tile_twiddle_bytes(int logR) { return logR > 0 ? (uint32_t)sizeo
 struct NttPassDesc {
     PassParams p;
     int loge;
-    uint32_t ntiles;
+    uint32_t ntiles;         // per column
+    uint32_t cols = 1;       // the grid is cols * ntiles workgroups
     uint32_t threads;
     uint32_t lds_bytes;
 };
@@ -70,6 +71,10 @@ struct NttIo {
     const Fe* oh = nullptr;
     bool scale_last = false; // multiply outputs by `scale` in the last pass (used when there is no four-step twiddle to fold it into)
     Fe scale = Fe{0, 0};
+    // `cols` independent transforms of length n in ONE set of launches (sc_ntt_columns_dev): column c of in / work / out starts
+    // at element c * n, every pass is launched over cols x its tiles, and workgroup b works on column b / tiles, tile b % tiles
+    // (PassParams::col_enable).  Twiddles and tables are shared by the columns; zero padding and coset scaling apply to each.
+    uint32_t cols = 1;
 };
 
 inline int plan_num_passes(int logn, const NttTuning& tu_in) {
@@ -86,6 +91,7 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
     d.logn = logn;
     const int m = plan_num_passes(logn, tu);
     if (m > 4) return false;
+    if (io.cols < 1 || io.cols > 65536) return false;
     d.npasses = m;
     {
         int base = logn / m, extra = logn % m;
@@ -188,6 +194,13 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
         pd.loge = loge;
         pd.threads = 1u << (logT - loge);
         pd.lds_bytes = ((uint32_t)sizeof(Fe) << logT) + tile_twiddle_bytes(pd.p.logR);   // the tile, then its twiddles
+        pd.cols = io.cols;
+        if (io.cols > 1) {
+            p.col_enable = 1;
+            p.col_tiles_log = 0;
+            while ((1u << p.col_tiles_log) < pd.ntiles) ++p.col_tiles_log;               // tiles per column: a power of two
+            p.col_stride = n;
+        }
         logA += logR;
     }
     if (tu.prune && io.in_limit < n && m > 1) {

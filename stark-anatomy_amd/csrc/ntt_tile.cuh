@@ -90,6 +90,11 @@ struct PassParams {
     int blk_log;
     uint32_t blk_row_k, blk_row_mid;
     Fe* out_blk[SC_MAX_BLOCKS];
+    // several independent transforms in one launch (NttIo::cols, sc_ntt_columns_dev): tile index = column * 2^col_tiles_log + the
+    // tile of that column's own pass; the column only shifts the element index into `in` and `out` by column * col_stride.
+    int col_enable;
+    int col_tiles_log;
+    uint64_t col_stride;
     // diagnostics (tools/pass_trace.py): per-wave s_memtime stamps of the phases of a workgroup; nullptr in production
     unsigned long long* trace;
 };
@@ -152,12 +157,18 @@ struct Round {
     uint32_t rr[G];   // per group: row bits outside the field, packed (rrem)
     uint32_t cc[G];   // per group: column
     uint32_t t_lo, t_mid, t_hi;
+    uint64_t col_off;  // first element of this workgroup's column (0 unless the launch covers several transforms)
     int logR, logC;
 
     SC_HD void setup(const PassParams& P, bool first, uint32_t tile, uint32_t tid) {
         logR = (GLR >= 0) ? GLR : P.logR;
         logC = (GLC >= 0) ? GLC : P.logC;
         const uint32_t T = 1u << (logR + logC - LOGE);   // threads per workgroup
+        col_off = 0;
+        if (P.col_enable) {
+            col_off = (uint64_t)(tile >> P.col_tiles_log) * P.col_stride;
+            tile &= (1u << P.col_tiles_log) - 1u;
+        }
         t_lo = tile & ((1u << P.lo_log) - 1u);
         t_mid = (tile >> P.lo_log) & ((1u << P.mid_log) - 1u);
         t_hi = tile >> (P.lo_log + P.mid_log);
@@ -195,7 +206,7 @@ struct Round {
         for (int i = 0; i < E; ++i) {
             const uint64_t j = in_index(P, i, sh);
             Fe v = fe_zero();
-            if (j < P.in_limit) v = P.in[j];
+            if (j < P.in_limit) v = P.in[col_off + j];
             x[i] = v;
             if (P.twd_in) tin[i] = P.twd_in[j & P.twd_in_mask];
         }
@@ -386,9 +397,9 @@ struct Round {
                 // the block of the natural row picks the destination (same element index everywhere)
                 const uint32_t nat = k * P.blk_row_k + t_mid * P.blk_row_mid;
                 Fe* dst = P.out_blk[nat >> P.blk_log];
-                dst[j] = v[i];
+                dst[col_off + j] = v[i];
             } else {
-                P.out[j] = v[i];
+                P.out[col_off + j] = v[i];
             }
         }
     }

@@ -51,6 +51,7 @@ SIGNATURES = {
     "sc_urandom_prefetch": (_int, [_u64, ctypes.c_uint32]),
     "sc_ntt": (_int, [_vp, _vp, _u64, _vp, _int]),
     "sc_ntt_dev": (_int, [_vp, _vp, _u64, _vp, _int, _vp]),
+    "sc_ntt_columns_dev": (_int, [_vp, _vp, _u64, _u64, _vp, _int, _vp]),
     "sc_ntt_batch_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp]),
     "sc_ntt_batch_ex_dev": (_int, [_vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _u64, _int, _u64, _vp]),
     "sc_ntt_rows_t_ld_dev": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _vp]),

@@ -35,14 +35,14 @@ static void run_pass(const NttPassDesc& pd) {
     if constexpr (LOGE == 2) {
 #define EMU_FIXED(LR, LC)                                                                                   \
         if (P.logR == LR && P.logC == LC) {                                                                 \
-            for (uint32_t tile = 0; tile < pd.ntiles; ++tile) run_fixed_rounds<2, LR, LC>(pd, tile, lds.data(), tw); \
+            for (uint32_t tile = 0; tile < pd.ntiles * pd.cols; ++tile) run_fixed_rounds<2, LR, LC>(pd, tile, lds.data(), tw); \
             return;                                                                                         \
         }
         EMU_FIXED(8, 3) EMU_FIXED(7, 4) EMU_FIXED(10, 2) EMU_FIXED(6, 5) EMU_FIXED(9, 3) EMU_FIXED(8, 4)
 #undef EMU_FIXED
     }
     RoundSched rs = make_rounds(P.logR, LOGE);
-    for (uint32_t tile = 0; tile < pd.ntiles; ++tile)
+    for (uint32_t tile = 0; tile < pd.ntiles * pd.cols; ++tile)
         for (int r = 0; r < rs.nrounds; ++r)
             for (uint32_t tid = 0; tid < pd.threads; ++tid)
                 ntt_round_dispatch<LOGE>(P, rs.s[r], rs.sh[r], r == 0, tile, tid, lds.data(), tw);
@@ -82,6 +82,62 @@ extern "C" int emu_ntt(const uint64_t* in, uint64_t* out, int logn, const uint64
         fill_table(oh, (cnt >> 12) + 1, o_m, 4096, fe_mont_one());
         io.ol = ol.data(); io.oh = oh.data();
     }
+    io.scale_last = inverse && m == 1;
+    io.scale = scale_m;
+    NttPlanDesc d;
+    if (!plan_ntt(d, logn, tb, io, tu)) return -1;
+    std::vector<Fe> twd[4];
+    if (direct_tw && d.npasses > 1) {
+        int logA = 0;
+        for (int i = 0; i + 1 < d.npasses; ++i) {
+            const int logR = d.digits[i], logB = logn - logA - logR;
+            const uint64_t count = 1ull << (logR + logB);
+            twd[i].resize(count);
+            const Fe* thp = (i == 0 && tb.th_scaled) ? tb.th_scaled : tb.th;
+            for (uint64_t q = 0; q < count; ++q) {
+                uint64_t k = q >> logB, b = q & ((1ull << logB) - 1);
+                twd[i][q] = pow2level(tb.tl, thp, b * k * (1ull << logA));
+            }
+            tb.twd[i] = twd[i].data();
+            logA += logR;
+        }
+        if (!plan_ntt(d, logn, tb, io, tu)) return -1;
+    }
+    for (int i = 0; i < d.npasses; ++i) {
+        switch (d.pass[i].loge) {
+            case 1: run_pass<1>(d.pass[i]); break;
+            case 2: run_pass<2>(d.pass[i]); break;
+            case 3: run_pass<3>(d.pass[i]); break;
+            case 4: run_pass<4>(d.pass[i]); break;
+            default: return -2;
+        }
+    }
+    return d.npasses;
+}
+
+// `cols` independent transforms in one set of launches (NttIo::cols, sc_ntt_columns_dev): in / out are [cols][n]
+extern "C" int emu_ntt_columns(const uint64_t* in, uint64_t* out, int logn, int cols, const uint64_t* root, int inverse, int direct_tw) {
+    const uint64_t n = 1ull << logn;
+    Fe r_m = to_mont(Fe{root[0], root[1]});
+    Fe scale_m = fe_mont_one();
+    if (inverse) {
+        r_m = mont_pow(r_m, n - 1);
+        scale_m = mont_inv(to_mont(Fe{n, 0}));
+    }
+    NttTuning tu;
+    const int m = plan_num_passes(logn, tu);
+    NttTables tb;
+    std::vector<Fe> mt, tl, th, ths;
+    tb.mt_log = logn < 12 ? logn : 12;
+    fill_table(mt, 1ull << (tb.mt_log - 1), r_m, n >> tb.mt_log, fe_mont_one());
+    fill_table(tl, n < 4096 ? n : 4096, r_m, 1, fe_mont_one());
+    fill_table(th, n > 4096 ? n >> 12 : 1, r_m, 4096, fe_mont_one());
+    fill_table(ths, n > 4096 ? n >> 12 : 1, r_m, 4096, scale_m);
+    tb.mt = mt.data(); tb.tl = tl.data(); tb.th = th.data(); tb.th_scaled = (inverse && m > 1) ? ths.data() : nullptr;
+    std::vector<Fe> work(n * cols);
+    NttIo io;
+    io.in = (const Fe*)in; io.work = work.data(); io.out = (Fe*)out;
+    io.cols = (uint32_t)cols;
     io.scale_last = inverse && m == 1;
     io.scale = scale_m;
     NttPlanDesc d;

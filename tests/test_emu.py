@@ -285,3 +285,26 @@ def test_emu_fourstep_stages(emu, log2n, world, blocks, defer, diag):
     zs = direction(ys, n2, n1, pow(root, n - 1, P), 1)
     for g_ in range(G):
         assert zs[g_].tobytes() == np.ascontiguousarray(xs[g_]).tobytes(), ("inverse", g_)
+
+
+# (logn, cols): one pass (<= 2^11), two passes (default plans up to 2^20), three passes (above)
+COLUMNS = [(6, 5), (11, 2), (12, 7), (14, 3), (16, 2), (21, 2)]
+
+
+@pytest.mark.parametrize("cfg", COLUMNS)
+def test_emu_column_batches(emu, cfg):
+    """NttIo::cols (sc_ntt_columns_dev): several transforms in one set of launches equal the oracle column by column,
+    forward and inverse, with the direct four-step tables (2: at the store) and with the two-level lookup (0)."""
+    logn, cols = cfg
+    n = 1 << logn
+    emu.emu_ntt_columns.restype = ctypes.c_int
+    emu.emu_ntt_columns.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    data = synth.synth_packed(300 + logn, n * cols).tobytes()
+    root = po.primitive_nth_root(n)
+    for inverse in (0, 1):
+        want = b"".join((po.C.intt if inverse else po.C.ntt)(root, data[16 * n * c:16 * n * (c + 1)], n) for c in range(cols))
+        for direct in ((2, 0) if logn <= 16 else (2,)):
+            out = ctypes.create_string_buffer(16 * n * cols)
+            rc = emu.emu_ntt_columns(data, out, logn, cols, int(root).to_bytes(16, "little"), inverse, direct)
+            assert rc == (1 if logn <= 11 else 2 if logn <= 20 else 3), rc
+            assert out.raw == want, (cfg, inverse, direct)

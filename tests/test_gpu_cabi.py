@@ -64,6 +64,60 @@ def test_ntt_vs_oracle(sc, logn):
         assert gpu_ntt(sc, data, n, other) == C.ntt(other, data, n)
 
 
+@pytest.mark.parametrize("logn,cols", [(1, 3), (5, 9), (11, 4), (12, 5), (14, 70), (16, 3), (18, 2), (20, 3), (21, 2), (22, 1)])
+def test_ntt_columns_vs_oracle(sc, logn, cols):
+    """sc_ntt_columns_dev: `cols` independent transforms (code/ntt.py:3-30 once per column) in one set of launches -- one, two and three
+    passes, column counts that are not powers of two, more columns than one set of launches takes (70 > 64) -- equal the oracle column by
+    column, forward and inverse, out of place and in place."""
+    import torch
+    dev = torch.device("cuda", 0)
+    lib = sc.lib()
+    n = 1 << logn
+    root = po.primitive_nth_root(n)
+    rt = sc.fe_bytes(root)
+    data = packed(1200 + logn, n * cols)
+    x = torch.from_numpy(np.frombuffer(data, dtype=np.int64).copy()).to(dev)
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    sc._check(lib.sc_ntt_columns_dev(x.data_ptr(), y.data_ptr(), n, cols, rt, 0, None))
+    sc._check(lib.sc_ntt_columns_dev(y.data_ptr(), z.data_ptr(), n, cols, rt, 1, None))
+    sc.synchronize()
+    got = y.cpu().numpy().tobytes()
+    for c in range(cols):
+        assert got[16 * n * c:16 * n * (c + 1)] == C.ntt(root, data[16 * n * c:16 * n * (c + 1)], n), (logn, cols, c)
+    assert z.cpu().numpy().tobytes() == data
+    # in place, and the inverse against the oracle's own
+    w = x.clone()
+    sc._check(lib.sc_ntt_columns_dev(w.data_ptr(), w.data_ptr(), n, cols, rt, 1, None))
+    sc.synchronize()
+    got = w.cpu().numpy().tobytes()
+    for c in range(0, cols, max(1, cols // 3)):
+        assert got[16 * n * c:16 * n * (c + 1)] == C.intt(root, data[16 * n * c:16 * n * (c + 1)], n), (logn, cols, c)
+    # the reference's assertions (ntt.py:10-11) and zero columns
+    assert lib.sc_ntt_columns_dev(x.data_ptr(), y.data_ptr(), n, 0, rt, 0, None) == 0
+    if logn >= 2:
+        assert lib.sc_ntt_columns_dev(x.data_ptr(), y.data_ptr(), n, cols, sc.fe_bytes(pow(root, 2, P)), 0, None) != 0
+        assert b"primitive" in lib.sc_last_error()
+
+
+def test_ntt_columns_full_size_round_trip(sc):
+    """BASELINE configs[1] as a batch: 16 columns of 2^20 (what bench.py times per step): the first and the last column equal sc_ntt_dev's
+    transform of that column alone, and the whole batch round-trips bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    lib = sc.lib()
+    n, cols = 1 << 20, 16
+    rt = sc.fe_bytes(po.primitive_nth_root(n))
+    x = torch.from_numpy(synth.synth_packed(77, n * cols).view(np.int64).reshape(-1)).to(dev)
+    y, z, one = torch.empty_like(x), torch.empty_like(x), torch.empty(2 * n, dtype=torch.int64, device=dev)
+    sc._check(lib.sc_ntt_columns_dev(x.data_ptr(), y.data_ptr(), n, cols, rt, 0, None))
+    sc._check(lib.sc_ntt_columns_dev(y.data_ptr(), z.data_ptr(), n, cols, rt, 1, None))
+    for c in (0, cols - 1):
+        sc._check(lib.sc_ntt_dev(x.data_ptr() + 16 * n * c, one.data_ptr(), n, rt, 0, None))
+        sc.synchronize()
+        assert torch.equal(one, y[2 * n * c:2 * n * (c + 1)]), c
+    assert torch.equal(z, x)
+
+
 def test_transforms_in_flight_on_two_streams(sc):
     """Two independent columns transformed side by side (one per HIP stream, many times over, never waiting in between): every
     multi-pass transform keeps its intermediate vector in a buffer of ITS stream (csrc/core.hip ntt_work_buffer), so the results are
