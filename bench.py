@@ -4,9 +4,12 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N = 1: workload = BASELINE configs[1]: forward + inverse 2^20-point NTT, data resident in HBM.
-       One step = one forward + one inverse transform;  value = 2 * n * K / elapsed  (field elements / s).
-       `extras.ntt_2p24_strong` carries the N = 1 member of the north_star series (forward + inverse at 2^24, with `frac`).
+N = 1: workload = BASELINE configs[1]: forward + inverse 2^20-point NTT, data resident in HBM, over one BATCH of independent
+       columns per step (--columns, default 64: the registers of a trace, code/fast_stark.py:84-104; 1 GiB per vector, well past
+       the 256 MiB Infinity Cache) through sc_ntt_columns_dev -- one set of launches per direction;
+       value = 2 * n * columns * K / elapsed  (field elements / s).  `one_column_at_a_time` carries the same transforms issued one
+       column after the other with sc_ntt_dev (--columns 1 makes that the step: the headline of rounds 1-5),
+       `extras.ntt_2p24_strong` the N = 1 member of the north_star series (forward + inverse at 2^24, with `frac`).
 N > 1: the north_star line: forward + inverse 2^24-point NTT as a four-step transform sharded over the ranks (STRONG scaling:
        the same 2^24 for every N; `--scaling weak` times 2^21 elements per GPU instead, `--log2n` any size), one corner turn per
        transform (stark-anatomy_amd/sharded.py).  A bare `python bench.py --gpus N` re-launches itself under
@@ -42,6 +45,16 @@ from workloads import (nth_root, sharded_census, stark_census, census_record, st
                        plain_stark_prove_measure)
 from sharded_setup import (HBM_PEAK_GBS, BYTES_PER_ELEMENT_PER_TRANSFORM, strong_record, sharded_setup,    # noqa: E402
                            stage_breakdown, node_facts, collective_label)
+
+COLS_PER_LAUNCH = 64       # csrc/core.hip sc_ntt_columns_dev: columns one set of launches covers (halved while columns x n > 2^28)
+
+
+def column_launch_sets(n, cols):
+    per = COLS_PER_LAUNCH
+    while per > 1 and per * n > (1 << 28):
+        per >>= 1
+    return (cols + per - 1) // per
+
 
 CLOCK_RAMP_MS = 150.0      # untimed load between the contract's window (`value`) and its repetition (`clock_ramp.steady_state`)
 
@@ -131,6 +144,9 @@ def main():
                     help="ntt (headline, BASELINE configs[1]; N > 1: the sharded four-step transform), stark_census (the polynomial-core call census of "
                          "BASELINE configs[4] on the sharded layout) or stark_prove (sharded_stark.ShardedFastStark.prove on a synthetic AIR: configs[4] as a prover)")
     ap.add_argument("--log2n", type=int, default=None, help="override the transform size (ntt) / the FRI domain (stark_census)")
+    ap.add_argument("--columns", type=int, default=None,
+                    help="N = 1: independent columns per step (default 64 at 2^20, fewer above so that a vector stays at 1 GiB; 1 = one "
+                         "transform at a time through sc_ntt_dev, the step of rounds 1-5)")
     ap.add_argument("--cpu-sample-log2n", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the Fri.prove / LDE / census side measurements")
@@ -166,10 +182,11 @@ def main():
     # One rank per GPU over RCCL is the production shape.  With fewer GPUs than ranks (functional runs on a 1-GPU box) the ranks
     # share devices and the collectives go through gloo, staged over the host: correct, labelled, and not a scaling measurement.
     shared_gpus = world > ngpu
+    batch_default = world == 1 and not args.force_sharded and args.workload == "ntt" and args.columns != 1
     if args.steps is None:
-        args.steps = 10 if shared_gpus else 2000
+        args.steps = 10 if shared_gpus else (200 if batch_default else 2000)
     if args.warmup is None:
-        args.warmup = 2 if shared_gpus else 200
+        args.warmup = 2 if shared_gpus else (20 if batch_default else 200)
     dev_index = local_rank % ngpu
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -234,23 +251,36 @@ def main():
         log2n = args.log2n or (20 if world == 1 else 21)
         n = 1 << log2n
         root = sc.fe_bytes(nth_root(n))
-        host = synth.synth_packed(1, n)
-        x = torch.from_numpy(host.view(np.int64)).to(dev)
+        cols = args.columns if args.columns else (max(1, (1 << 26) >> log2n) if world == 1 else 1)
+        # column 0 is the vector of rounds 1-5 (synth seed 1: the reference's own transform of it is pinned in tests/golden/ntt_big.json)
+        x = torch.empty(2 * n * cols, dtype=torch.int64, device=dev)
+        for c in range(cols):        # (a column at a time: the host never holds more than one)
+            x[2 * n * c:2 * n * (c + 1)] = torch.from_numpy(synth.synth_packed(1, n, start=c * n).view(np.int64).reshape(-1)).to(dev)
         y = torch.empty_like(x)
         z = torch.empty_like(x)
 
-        def step():
+        if cols > 1:
+            def step():
+                sc._check(lib.sc_ntt_columns_dev(x.data_ptr(), y.data_ptr(), n, cols, root, 0, sptr))
+                sc._check(lib.sc_ntt_columns_dev(y.data_ptr(), z.data_ptr(), n, cols, root, 1, sptr))
+            launches_per_step = 2 * int(lib.sc_ntt_num_passes(n)) * column_launch_sets(n, cols)
+        else:
+            def step():
+                sc._check(lib.sc_ntt_dev(x.data_ptr(), y.data_ptr(), n, root, 0, sptr))
+                sc._check(lib.sc_ntt_dev(y.data_ptr(), z.data_ptr(), n, root, 1, sptr))
+            launches_per_step = 2 * int(lib.sc_ntt_num_passes(n))
+
+        def one_column_pair():
             sc._check(lib.sc_ntt_dev(x.data_ptr(), y.data_ptr(), n, root, 0, sptr))
             sc._check(lib.sc_ntt_dev(y.data_ptr(), z.data_ptr(), n, root, 1, sptr))
 
-        launches_per_step = 2 * int(lib.sc_ntt_num_passes(n))
         if world == 1:
             workload = "ntt_fwd_inv_2^%d_1gpu" % log2n
             parallelism = "single"
         else:
             workload = "ntt_fwd_inv_2^%d_x%d_independent_replicas" % (log2n, world)
             parallelism = "replicas (sharded path failed: %s); value = n_gpus x rank-0 rate" % replicas_reason
-        total_n = n * world
+        total_n = n * cols * world
 
     def barrier():
         if sharded:
@@ -290,6 +320,31 @@ def main():
 
     # correctness guard inside the bench: the round trip must reproduce the input bit for bit
     ok = bool(torch.equal(z, x))
+    one_column = None
+    if not sharded and cols > 1 and not args.no_extras:
+        # (a side leg like `extras`: --no-extras, which the profiling commands use, keeps every launch of the run a launch of the batch)
+        # the same kernels with the columns issued one after the other (sc_ntt_dev on column 0: the step of rounds 1-5), at the clock
+        # the windows above have brought the board to
+        pairs = max(200, min(4000, int(0.1 / (elapsed / args.steps / cols))))
+        for _ in range(50):
+            one_column_pair()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(pairs):
+            one_column_pair()
+        e1.record(stream)
+        barrier()
+        dt1 = time.perf_counter() - t0
+        lps1 = 2 * int(lib.sc_ntt_num_passes(n))
+        one_column = {"value": 2.0 * n * pairs / dt1, "unit": "field-elements/s", "us_per_pair": 1e6 * dt1 / pairs, "pairs_timed": pairs,
+                      "avg_launch_us": e0.elapsed_time(e1) * 1e3 / (pairs * lps1),
+                      "roofline_frac": BYTES_PER_ELEMENT_PER_TRANSFORM * n / (lps1 // 2) / (e0.elapsed_time(e1) * 1e-3 / (pairs * lps1)) / 1e9 / HBM_PEAK_GBS,
+                      "roundtrip_bit_exact": bool(torch.equal(z[:2 * n], x[:2 * n])),
+                      "note": "sc_ntt_dev, one 2^%d forward + inverse after the other on one stream (what `value` was in rounds 1-5; --columns 1 times it as the step)" % log2n}
+        step()           # leave y and z as the batch left them (the checks below read them)
+        barrier()
     if sharded and args.workload == "ntt":
         direct = bool(corner_probes["chosen_kwargs"].get("direct_store"))
         if direct:
@@ -330,7 +385,7 @@ def main():
             gold = json.load(open(os.path.join(REPO, "tests", "golden", "ntt_big.json")))
             want = [r["sha256"] for r in gold["ntt"] if r["logn"] == log2n and r["seed"] == 1 and int(r["root"]) == nth_root(n)]
             if want:
-                reference_sha = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest() == want[0]
+                reference_sha = hashlib.sha256(y[:2 * n].cpu().numpy().tobytes()).hexdigest() == want[0]       # column 0
                 ok = ok and reference_sha
         except Exception:       # noqa: BLE001  (no fixture: the round trip stays the guard)
             reference_sha = None
@@ -427,19 +482,21 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         # dominant kernel: ntt_pass_kernel (every launch in the timed region is one pass of it).
         # algorithmic bytes per launch = 32 B/element/transform * n elements / passes-per-transform
-        passes = launches_per_step // 2
+        passes = launches_per_step // 2 if sharded else int(lib.sc_ntt_num_passes(n))
         avg_launch_s = (ev_ms * 1e-3) / (args.steps * launches_per_step)
         if sharded:
             passes = None
             alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * (total_n / world)     # per rank, per transform
         else:
-            alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * (total_n / world) / passes
+            # (a launch of the batch covers every column of its set: per launch = 32 B x n x columns / passes, spread over the sets)
+            alg_bytes_per_launch = BYTES_PER_ELEMENT_PER_TRANSFORM * (total_n / world) / (launches_per_step // 2)
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9
+        pmc_key = None if sharded else ("%d" % log2n if cols == 1 else "%dx%d" % (log2n, cols))     # profiles/rNN/traffic.json, pmc_summary.json
         out = {
             "metric": "ntt_field_elements_per_sec", "value": value, "unit": "field-elements/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": scaling_label, "vs_baseline": None, "dtype": "u128", "data": "synthetic",
-            "config": {"workload": workload, "log2n": log2n, "elements_per_step": 2 * total_n, "parallelism": parallelism,
+            "config": {"workload": workload, "log2n": log2n, "columns_per_step": (cols if not sharded else 1), "elements_per_step": 2 * total_n, "parallelism": parallelism,
                        "passes_per_transform": passes, "roundtrip_bit_exact": ok, "forward_sha256_equals_reference_output": reference_sha},
             "clock_ramp": {"untimed_steps_between_windows": ramp_steps, "target_ms": CLOCK_RAMP_MS,
                            "steady_state": {"value": 2.0 * total_n * args.steps / steady_elapsed, "ms_per_step": 1e3 * steady_elapsed / args.steps,
@@ -447,12 +504,14 @@ def main():
                                             "roofline_frac": alg_bytes_per_launch / ((steady_ev_ms * 1e-3) / (args.steps * launches_per_step)) / 1e9 / HBM_PEAK_GBS},
                            "note": "information only: the same W + K window repeated after the board has clocked up (`value` is the first window, straight after start-up)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(log2n) if not sharded else None, "kernel": "ntt_pass_kernel" if not sharded else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
+                         "traffic": measured_traffic(pmc_key) if not sharded else None, "kernel": "ntt_pass_kernel" if not sharded else "whole sharded transform (per rank)", "avg_launch_us": avg_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
-                         "valu_insts_per_launch": measured_valu(log2n) if not sharded else None,
+                         "valu_insts_per_launch": measured_valu(pmc_key) if not sharded else None,
                          "pmc_collected_with_these_kernel_sources": pmc_figures_are_current(),
                          "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 and valu_insts (SQ_INSTS_VALU, wave-level) per launch from profiles/ (PMC passes); "
-                                 "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor (13 of 17.5 us at 2^20), see DESIGN.md 3.1"},
+                                 "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor -- 6.56 M per 2^20 column and pass = 12.8 us at the "
+                                 "2.1 GHz the board holds under this load (13.3 us per column in a launch over 64 columns; 17.4 us for a lone column, one "
+                                 "workgroup per CU with every CU in the same phase), see DESIGN.md 3.1"},
         }
         if sharded:
             # the N > 1 line prices a rank's WHOLE transform (column stage, corner turn, row stage), not one launch of one kernel: no
@@ -497,6 +556,8 @@ def main():
             out["two_columns_in_flight"] = {"value": two["elements_per_s"], "unit": "field-elements/s", "frac_of_hbm_roofline": two["frac"],
                                             "gain_over_one_stream": two["gain"], "roundtrip_bit_exact": two["roundtrip_bit_exact"],
                                             "note": "NOT the headline: two independent 2^20 forward+inverse transforms on two HIP streams; details in extras"}
+        if one_column is not None:
+            out["one_column_at_a_time"] = one_column
         if not args.no_cpu_baseline and not sharded and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2n)
         emit(out)
@@ -815,7 +876,7 @@ def measured_valu(log2n):
         try:
             d = json.load(open(f))
             for run, kernels in d.items():
-                if not run.endswith("_%d" % log2n):
+                if not run.endswith("_%s" % log2n):
                     continue
                 for name, ctrs in kernels.items():
                     if "ntt_pass" in name and "SQ_INSTS_VALU" in ctrs:

@@ -408,8 +408,18 @@ def test_bench_headline_line_is_the_contract_and_matches_the_reference(sc):
     assert out["config"]["workload"] == "ntt_fwd_inv_2^20_1gpu" and out["config"]["roundtrip_bit_exact"] is True
     assert out["config"]["forward_sha256_equals_reference_output"] is True
     r = out["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > r["alg_bytes_per_launch"]
-    assert abs(out["value"] - 2 * (1 << 20) * 5 / (out["ms_per_step"] * 5e-3)) < 1e-3 * out["value"]
+    cols = out["config"]["columns_per_step"]
+    assert cols == 64 and out["config"]["elements_per_step"] == 2 * cols << 20           # one step = one batch of columns (sc_ntt_columns_dev)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["alg_bytes_per_launch"] == 32 * cols * (1 << 20) / out["config"]["passes_per_transform"]
+    assert r["traffic"] is None or r["traffic"] > r["alg_bytes_per_launch"]
+    assert abs(out["value"] - 2 * cols * (1 << 20) * 5 / (out["ms_per_step"] * 5e-3)) < 1e-3 * out["value"]
+    assert "one_column_at_a_time" not in out                                                # a side leg, off with --no-extras
+    # ... and --columns 1 makes that the step again
+    out1 = _run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--columns", "1"])
+    assert out1["config"]["columns_per_step"] == 1 and out1["config"]["forward_sha256_equals_reference_output"] is True
+    assert "one_column_at_a_time" not in out1 and out1["roofline"]["traffic"] > out1["roofline"]["alg_bytes_per_launch"]
+    assert abs(out1["value"] - 2 * (1 << 20) * 5 / (out1["ms_per_step"] * 5e-3)) < 1e-3 * out1["value"]
 
 
 def test_bench_two_ranks_print_the_north_star_record(sc):
