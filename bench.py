@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--columns", type=int, default=None,
                     help="N = 1: independent columns per step (default 64 at 2^20, fewer above so that a vector stays at 1 GiB; 1 = one "
                          "transform at a time through sc_ntt_dev, the step of rounds 1-5)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="sc_set_tuning(KEY, VALUE) before anything runs (A/B of a library knob in bench conditions; the line carries it in config.tune)")
     ap.add_argument("--cpu-sample-log2n", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the Fri.prove / LDE / census side measurements")
@@ -195,6 +196,8 @@ def main():
     import synth
     sc.init(dev_index)
     lib = sc.lib()
+    for kv in args.tune:
+        sc.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 
     sharded = world > 1 or args.force_sharded or args.workload in ("stark_census", "stark_prove")
 
@@ -497,7 +500,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": scaling_label, "vs_baseline": None, "dtype": "u128", "data": "synthetic",
             "config": {"workload": workload, "log2n": log2n, "columns_per_step": (cols if not sharded else 1), "elements_per_step": 2 * total_n, "parallelism": parallelism,
-                       "passes_per_transform": passes, "roundtrip_bit_exact": ok, "forward_sha256_equals_reference_output": reference_sha},
+                       "passes_per_transform": passes, "roundtrip_bit_exact": ok, "forward_sha256_equals_reference_output": reference_sha,
+                       **({"tune": args.tune} if args.tune else {})},
             "clock_ramp": {"untimed_steps_between_windows": ramp_steps, "target_ms": CLOCK_RAMP_MS,
                            "steady_state": {"value": 2.0 * total_n * args.steps / steady_elapsed, "ms_per_step": 1e3 * steady_elapsed / args.steps,
                                             "avg_launch_us": steady_ev_ms * 1e3 / (args.steps * launches_per_step),

@@ -123,7 +123,7 @@ struct Ctx {
     int num_cus = 256;
     int xcd_remap = 1;
     int fixed_shapes = 1;    // use the geometry-specialised kernel instantiations where one matches
-    int prio_balance = -1;   // -1: on for launches of at most one workgroup per CU, 0 / 1: force
+    int prio_balance = -1;   // -1: 1 for launches of at most one workgroup per CU, 2 for long grids (>= 8 workgroups per CU; >= 2 of 2^10 x 4 tiles), else 0; 0 / 1 / 2: force (PassParams::prio_balance)
     int wave_local = 1;      // wave-level fences instead of workgroup barriers once a tile's exchanges stay inside one wave
     unsigned long long* trace = nullptr;   // diagnostics: phase stamps of the next fixed-shape pass launches (sc_debug_trace)
     int merkle_big_nlev = 2; // levels fused per launch for Merkle levels wider than FUSE_MAX_W (0: one level kernel per level)

@@ -611,7 +611,10 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
 int run_plan(NttPlanDesc& d, hipStream_t st) {
     size_t trace_off = 0;    // diagnostics: pass i writes its stamps behind those of the passes before it
     for (int i = 0; i < d.npasses; ++i) {
-        d.pass[i].p.prio_balance = g.prio_balance >= 0 ? g.prio_balance : (d.pass[i].ntiles * d.pass[i].cols <= (uint32_t)g.num_cus ? 1 : 0);
+        const uint32_t grid = d.pass[i].ntiles * d.pass[i].cols;
+        d.pass[i].p.prio_balance = g.prio_balance >= 0 ? g.prio_balance
+                                 : grid <= (uint32_t)g.num_cus ? 1
+                                 : grid >= ((d.pass[i].p.logR == 10 && d.pass[i].p.logC == 2) ? 2u : 8u) * (uint32_t)g.num_cus ? 2 : 0;
         d.pass[i].p.trace = g.trace ? g.trace + trace_off : nullptr;
         trace_off += (size_t)d.pass[i].ntiles * d.pass[i].cols * (d.pass[i].threads >> 6) * TRACE_STAMPS;
         switch (d.pass[i].loge) {

@@ -343,6 +343,17 @@ __device__ __forceinline__ void store_digests_coalesced(uint4* sm, const uint64_
     }
 }
 
+// Priority of a workgroup's ENTRY (its global loads): in a long grid new waves arrive while others hash; at top priority until their
+// loads are issued, the loads leave at once instead of queueing behind that arithmetic (the transforms: PassParams::prio_balance = 2).
+#ifndef SC_MERKLE_ENTRY_PRIO
+#define SC_MERKLE_ENTRY_PRIO 1
+#endif
+__device__ __forceinline__ void entry_prio(bool on) {
+#if SC_MERKLE_ENTRY_PRIO
+    if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 __global__ void __launch_bounds__(256) merkle_leaf_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ digests, uint64_t N) {
     __shared__ uint4 sm[256 * 4];
     const uint64_t base = (uint64_t)blockIdx.x * 256u;
@@ -350,7 +361,10 @@ __global__ void __launch_bounds__(256) merkle_leaf_kernel(const Fe* __restrict__
     const bool active = threadIdx.x < n_here;
     uint64_t m[16], h[8];
     if (active) {
-        uint32_t len = leaf_message(elems[base + threadIdx.x], m);
+        entry_prio(true);
+        const Fe e = elems[base + threadIdx.x];
+        entry_prio(false);
+        uint32_t len = leaf_message(e, m);
         blake2b_single_block(m, len, h);
     }
     store_digests_coalesced(sm, h, active, digests, base, n_here);
@@ -374,11 +388,13 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __res
     const uint64_t base = (uint64_t)blockIdx.x * 256u;
     const uint32_t n_here = (uint32_t)((count - base) < 256u ? (count - base) : 256u);
     const uint4* src = reinterpret_cast<const uint4*>(in + 16 * base);
+    entry_prio(true);
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
         const uint32_t q = j * 256u + t;              // coalesced: lane l reads chunk q of the 32 KiB block
         if (q < n_here * 8u) sm[msg_slot(q >> 3, q & 7u)] = src[q];
     }
+    entry_prio(false);
     __syncthreads();
     const bool active = t < n_here;
     uint64_t m[16], h[8];
@@ -435,6 +451,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
     const uint64_t wg = blockIdx.x;
     auto level_off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
     uint64_t h[8];
+    entry_prio(true);
     if (LEAVES) {
         uint64_t m[16];
         Fe e;
@@ -444,6 +461,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         } else {
             e = elems[wg * 256u + t];
         }
+        entry_prio(false);
 #if SC_LEAF_LDS
         uint32_t len = leaf_message_lds(e, m, reinterpret_cast<uint8_t*>(cur) + LEAF_SLOT_BYTES * t);
         blake2b_single_block(m, len, h);
@@ -456,6 +474,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         const ulonglong2* s = reinterpret_cast<const ulonglong2*>(levels + 8 * (level_off(lvl0) + wg * 256u + t));
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ulonglong2 v = s[k]; h[2 * k] = v.x; h[2 * k + 1] = v.y; }
+        entry_prio(false);
     }
     uint32_t width = 256;
     int l = 0;

@@ -74,9 +74,12 @@ struct PassParams {
     // prune_log stages every butterfly has v = 0 and degenerates to (u, u * w): no add/sub, and nothing at all where u is a
     // zero row too (whole waves skip).  0 = off.
     int prune_log;
-    // the grid is a single wave of workgroups (<= one per CU, e.g. 2^20): a wave lowers its priority as it advances through a
+    // 1: the grid is a single wave of workgroups (<= one per CU, e.g. 2^20): a wave lowers its priority as it advances through a
     // round, so the waves of a SIMD reach the barrier together instead of the oldest always winning the VALU arbitration and
-    // the youngest finishing alone at half the issue rate (+2-4 % at 2^20; -3..5 % when other workgroups fill the gaps anyway)
+    // the youngest finishing alone at half the issue rate (+2-4 % at 2^20; -3..5 % when other workgroups fill the gaps anyway).
+    // 2: a long grid (a batch of 2^20 columns, a 2^22 or 2^24 transform: the waves of the next workgroup arrive one by one while
+    // others are computing): a wave runs at top priority until its first-round loads are issued, so they leave at once instead
+    // of queueing behind that arithmetic (2^20 x 16-64 columns +3.5-6 %, 2^24 +3.5-4.5 %, 2^22 +1.6 %; -2..4 % on grids of 4 per CU)
     int prio_balance;
     // optional DESTINATION TABLE for the natural output rows (column stage of the multi-GPU four-step): the rows are cut into
     // blocks of 2^blk_log rows, block h = what rank h receives in the corner turn, and an element of natural row
@@ -471,8 +474,10 @@ struct FixedRounds {
         if constexpr (ROUND == 0) {
             Fe tin[E];
             Fe twv = fe_zero();
+            if (P.prio_balance == 2) Round<LOGE, S, GLR, GLC>::set_prio(1, 3);
             if (tid < TW_COUNT) twv = P.mt[(uint64_t)tid << P.mt_shift];
             R.gather_global(P, SH, x, tin);
+            if (P.prio_balance == 2) Round<LOGE, S, GLR, GLC>::set_prio(1, 0);
             if (tid < TW_COUNT) tw[tid] = twv;
             stamp(1);
             sync();
@@ -491,7 +496,7 @@ struct FixedRounds {
         }
         // the degenerate stages of a zero-padded input lie in the first two rounds (the planner caps prune_log accordingly)
         const int prune = (ROUND <= 1) ? P.prune_log : 0;
-        R.butterflies(SH, x, tw, 0, prune, ROUND + 1 == NR ? 1 : 0, P.prio_balance);
+        R.butterflies(SH, x, tw, 0, prune, ROUND + 1 == NR ? 1 : 0, P.prio_balance == 1 ? 1 : 0);
         stamp(3 + 2 * ROUND);
         if constexpr (ROUND + 1 < NR) {
             R.scatter_lds(SH, x, lds);
