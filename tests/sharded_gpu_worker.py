@@ -182,10 +182,11 @@ def stark_check(rank, world, dev):
     return ok
 
 
-def stark_reference_goldens(rank, world, dev, max_log_fri=14):
+def stark_reference_goldens(rank, world, dev, max_log_fri=18, max_log_fri_host_rows=14):
     """The workload bench.py times for BASELINE configs[4] (workloads.synthetic_stark_instance), as the REFERENCE's FastStark proved it
     (tests/golden/fast_stark_synth.json, written by make_golden.py --stark-synth with the same seeded os.urandom): every rank must
-    end with those bytes, from the host-list trace and from device-resident columns."""
+    end with those bytes, from the host-list trace (up to FRI 2^14: above that the lists only cost time) and from device-resident
+    columns (every size the fixture holds: the reference needs 20 minutes for the 2^16 proof and hours for 2^18)."""
     import hashlib
     import json
     import random
@@ -203,7 +204,7 @@ def stark_reference_goldens(rank, world, dev, max_log_fri=14):
                 continue
             field, T, packed, air, boundary = workloads.synthetic_stark_instance(log_fri, s)
             stark = ShardedFastStark(field, 4, s, rec["security_level"], 2, T, rank, world, dev)
-            for resident in (False, True):
+            for resident in ((False, True) if log_fri <= max_log_fri_host_rows else (True,)):
                 rng = random.Random(rec["urandom_seed"])
                 fast_stark.os.urandom = lambda k, rng=rng: bytes(rng.getrandbits(8) for _ in range(k))
                 tz, layer, root = stark.preprocess(device_resident=resident)
