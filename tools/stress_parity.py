@@ -15,7 +15,7 @@ stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream); sptr = ct
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
 rng = random.Random(os.getpid())
 DEF = dict(fixed_shapes=1, loge=2, max_tile_log=-1, max_digit_log=-1, wave_local=1, prio_balance=-1)
-ALTS = [dict(fixed_shapes=0, loge=3), dict(max_tile_log=10), dict(wave_local=0, prio_balance=1), dict(fixed_shapes=0, loge=2)]
+ALTS = [dict(fixed_shapes=0, loge=3), dict(max_tile_log=10), dict(wave_local=0, prio_balance=1), dict(fixed_shapes=0, loge=2), dict(prio_balance=2), dict(prio_balance=0)]
 def tune(d):
     for k, v in DEF.items(): sc.set_tuning(k, v)
     for k, v in d.items(): sc.set_tuning(k, v)
@@ -43,6 +43,15 @@ while time.time() < t_end:
         outs.append(y)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), ("plans disagree", lg, seed, inv)
+    # the same vector as column 1 of a batch of three (sc_ntt_columns_dev: one set of launches), in place, under one of the plans
+    if lg <= 20 and rng.random() < 0.5:
+        tune(rng.choice([dict()] + ALTS))
+        flat = x.reshape(-1)
+        three = torch.cat([torch.roll(flat, 2), flat, torch.roll(flat, 4)]).contiguous()
+        sc._check(lib.sc_ntt_columns_dev(three.data_ptr(), three.data_ptr(), n, 3, root, inv, sptr))
+        torch.cuda.synchronize()
+        assert torch.equal(three[flat.numel():2 * flat.numel()], outs[0].reshape(-1)), ("columns call disagrees", lg, seed, inv)
+        count += 3
     if lg <= 15:
         raw = host.tobytes()
         want = po.C.intt(po.primitive_nth_root(n), raw, n) if inv else po.C.ntt(po.primitive_nth_root(n), raw, n)
