@@ -67,7 +67,7 @@ def test_synthetic_air_reference_golden_proofs(device_min, monkeypatch):
     """The workload bench.py TIMES for BASELINE configs[4] (workloads.synthetic_stark_instance: 2-register AIR (a, b) -> (b, a*a + b),
     T = 2^(log_fri - 4) - 4 s rows, expansion factor 4, s colinearity checks) as the REFERENCE's FastStark.prove proved it with the
     same seeded os.urandom (tests/golden/fast_stark_synth.json, make_golden.py --stark-synth; code/fast_stark.py:76-178): FRI domains
-    2^10 ... 2^16, i.e. the multi-pass LDE plans, the progression interpolation, the value-domain transition quotients and the
+    2^10 ... 2^17 (2.2 hours of reference time for the last), i.e. the multi-pass LDE plans, the progression interpolation, the value-domain transition quotients and the
     library commit loop at sizes where they are the code that runs -- byte for byte, from host rows and from device-resident columns."""
     import workloads
     import synth
