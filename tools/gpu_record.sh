@@ -42,9 +42,9 @@ for lg in ("20x64", "20", "24"):
     if f is not None and w is not None:
         out[lg] = {"hbm_bytes_per_launch": (2 * f + w) * 1024, "fetch_size_kb": f, "write_size_kb": w,
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md)"}
-sys.path.insert(0, ".")
-import bench
-out["kernel_source_sha256_16"] = bench.kernel_source_digest()      # bench.py flags PMC figures that predate a change to the kernel's sources
+sys.path.insert(0, "tools")
+import pmc_records
+out["kernel_source_sha256_16"] = pmc_records.kernel_source_digest()      # bench.py flags PMC figures that predate a change to the kernel's sources
 json.dump(out, open(O + "/traffic.json", "w"), indent=1)
 for f in sorted(glob.glob(O + "/bench*.json")):
     try:
