@@ -48,13 +48,11 @@ from sharded_setup import (HBM_PEAK_GBS, BYTES_PER_ELEMENT_PER_TRANSFORM, strong
 sys.path.insert(0, os.path.join(REPO, "tools"))
 from pmc_records import measured_valu, measured_traffic, pmc_figures_are_current, kernel_source_digest       # noqa: E402,F401  (what profiles/ holds)
 
-COLS_PER_LAUNCH = 64       # csrc/core.hip sc_ntt_columns_dev: columns one set of launches covers (halved while columns x n > 2^28)
+COLS_ELEMS_PER_LAUNCH = 1 << 26       # csrc/core.hip sc_ntt_columns_dev: elements one set of launches covers (64 columns of 2^20)
 
 
 def column_launch_sets(n, cols):
-    per = COLS_PER_LAUNCH
-    while per > 1 and per * n > (1 << 28):
-        per >>= 1
+    per = max(1, min(65536, COLS_ELEMS_PER_LAUNCH // n))
     return (cols + per - 1) // per
 
 

@@ -1212,8 +1212,9 @@ int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2]
 }
 
 // `cols` independent transforms of length n, column c at element c * n, in ONE set of launches (NttIo::cols): the workgroups of one
-// column start while those of another finish.  At most COLS_PER_LAUNCH columns per set, so that the intermediate vector stays bounded.
-constexpr uint64_t COLS_PER_LAUNCH = 64;
+// column start while those of another finish.  A set of launches covers at most COLS_ELEMS_PER_LAUNCH elements (64 columns of 2^20,
+// 4 096 of 2^14: the grid of a set must be long whatever the length of a column), which bounds the intermediate vector at 1 GiB.
+constexpr uint64_t COLS_ELEMS_PER_LAUNCH = 1ull << 26;
 int sc_ntt_columns_dev(const void* d_in, void* d_out, uint64_t n, uint64_t cols, const uint64_t root[2], int inverse, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     SCCHK(ensure_init());
@@ -1226,9 +1227,9 @@ int sc_ntt_columns_dev(const void* d_in, void* d_out, uint64_t n, uint64_t cols,
     }
     const Fe* in = (const Fe*)d_in;
     Fe* out = (Fe*)d_out;
-    // a set of launches covers at most 2^31 tiles' worth of workgroups and 2^28 elements of intermediate vector
-    uint64_t per = COLS_PER_LAUNCH;
-    while (per > 1 && per * n > (1ull << 28)) per >>= 1;
+    uint64_t per = COLS_ELEMS_PER_LAUNCH / n;
+    if (per < 1) per = 1;
+    if (per > 65536) per = 65536;
     for (uint64_t done = 0; done < cols; done += per) {
         NttOpts o;
         o.cols = (uint32_t)(cols - done < per ? cols - done : per);

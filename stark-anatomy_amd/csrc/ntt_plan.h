@@ -87,11 +87,20 @@ inline int plan_num_passes(int logn, const NttTuning& tu_in) {
 // Fill the pass descriptors for a length-2^logn transform.  Returns false if unsupported.
 inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo& io, const NttTuning& tu_in) {
     if (logn < 1 || logn > 32) return false;
-    const NttTuning tu = resolve_tuning(tu_in, logn);
+    NttTuning tu = resolve_tuning(tu_in, logn);
     d.logn = logn;
     const int m = plan_num_passes(logn, tu);
     if (m > 4) return false;
     if (io.cols < 1 || io.cols > 65536) return false;
+    // a batch of columns is one long grid whatever the length of a column: short columns then take the 2^11-element tiles of the
+    // long transforms (three workgroups per CU; shapes (7,4), (6,5), (8,3), which have geometry-specialised kernels) instead of the
+    // tiles a lone short transform shrinks to in order to cover the machine (2^14 x 256 columns: 27 -> 4x G elements/s)
+    int cols_log = 0;
+    while ((2u << cols_log) <= io.cols) ++cols_log;
+    if (io.cols > 1 && logn <= 16) {
+        if (tu_in.max_tile_log < 0) tu.max_tile_log = 11;
+        if (tu_in.max_col_log < 0) tu.max_col_log = 6;
+    }
     d.npasses = m;
     {
         int base = logn / m, extra = logn % m;
@@ -103,7 +112,7 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
         int maxdigit = 0;
         for (int i = 0; i < m; ++i) maxdigit = d.digits[i] > maxdigit ? d.digits[i] : maxdigit;
         const int floor_log = maxdigit + 2 < tu.max_tile_log ? maxdigit + 2 : tu.max_tile_log;    // keep >= 4 columns per tile
-        while (tile_cap > floor_log && logn - tile_cap < tu.min_tiles_log && m > 1) --tile_cap;
+        while (tile_cap > floor_log && logn + cols_log - tile_cap < tu.min_tiles_log && m > 1) --tile_cap;
     }
 
     int logA = 0;                         // log2 of the product of the digits already transformed

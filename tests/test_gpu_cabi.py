@@ -67,8 +67,8 @@ def test_ntt_vs_oracle(sc, logn):
 @pytest.mark.parametrize("logn,cols", [(1, 3), (5, 9), (11, 4), (12, 5), (14, 70), (16, 3), (18, 2), (20, 3), (21, 2), (22, 1)])
 def test_ntt_columns_vs_oracle(sc, logn, cols):
     """sc_ntt_columns_dev: `cols` independent transforms (code/ntt.py:3-30 once per column) in one set of launches -- one, two and three
-    passes, column counts that are not powers of two, more columns than one set of launches takes (70 > 64) -- equal the oracle column by
-    column, forward and inverse, out of place and in place."""
+    passes, column counts that are not powers of two, short columns on the long transforms' tiles -- equal the oracle column by column,
+    forward and inverse, out of place and in place."""
     import torch
     dev = torch.device("cuda", 0)
     lib = sc.lib()
@@ -100,18 +100,19 @@ def test_ntt_columns_vs_oracle(sc, logn, cols):
 
 
 def test_ntt_columns_full_size_round_trip(sc):
-    """BASELINE configs[1] as a batch: 16 columns of 2^20 (what bench.py times per step): the first and the last column equal sc_ntt_dev's
-    transform of that column alone, and the whole batch round-trips bit for bit."""
+    """BASELINE configs[1] as a batch: 66 columns of 2^20 (what bench.py times per step, and two more: a set of launches covers 2^26
+    elements, so the last two columns are a second set): columns of both sets equal sc_ntt_dev's transform of that column alone, and
+    the whole batch round-trips bit for bit."""
     import torch
     dev = torch.device("cuda", 0)
     lib = sc.lib()
-    n, cols = 1 << 20, 16
+    n, cols = 1 << 20, 66
     rt = sc.fe_bytes(po.primitive_nth_root(n))
     x = torch.from_numpy(synth.synth_packed(77, n * cols).view(np.int64).reshape(-1)).to(dev)
     y, z, one = torch.empty_like(x), torch.empty_like(x), torch.empty(2 * n, dtype=torch.int64, device=dev)
     sc._check(lib.sc_ntt_columns_dev(x.data_ptr(), y.data_ptr(), n, cols, rt, 0, None))
     sc._check(lib.sc_ntt_columns_dev(y.data_ptr(), z.data_ptr(), n, cols, rt, 1, None))
-    for c in (0, cols - 1):
+    for c in (0, 63, 64, cols - 1):
         sc._check(lib.sc_ntt_dev(x.data_ptr() + 16 * n * c, one.data_ptr(), n, rt, 0, None))
         sc.synchronize()
         assert torch.equal(one, y[2 * n * c:2 * n * (c + 1)]), c
