@@ -61,7 +61,7 @@ int sc_stream(void** stream_out);
 int sc_stream_join(void* other_stream);
 /* tuning knobs for experiments (defaults are the measured optimum; -1 = choose by size where applicable): key in
  * {"max_tile_log","loge","max_col_log","min_tiles_log","single_pass_max_log","max_digit_log","direct_tw_max_log",
- *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","tw_on_load","prune","fri_tail","fri_tail_stall","small_divisor_direct"}.  Plans are re-derived on the next
+ *  "xcd_remap","fixed_shapes","merkle_big_nlev","wave_local","prio_balance","loge_cols","tw_on_load","prune","fri_tail","fri_tail_stall","small_divisor_direct"}.  Plans are re-derived on the next
  * call; results never depend on the tuning ("fri_tail_stall" = k >= 0 is a test hook: the host withholds the challenge after round k of
  * the persistent tail kernel, whose wait then gives up after 2^13 polls; -1 = off; "small_divisor_direct" = 0: sc_coset_divide* transforms a
  * divisor of <= 8 coefficients like any other instead of evaluating it point by point).  Two keys manage the device-memory pool instead (freed vectors and trees are kept

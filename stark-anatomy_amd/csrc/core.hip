@@ -71,6 +71,26 @@ __global__ void __launch_bounds__(1 << (GLR + GLC - LOGE)) ntt_pass_kernel_fixed
     }
 }
 
+// The 2^12-element shapes with EIGHT elements per thread, for the batches of columns (NttTuning::loge_cols): 512 threads, three stages per
+// round, and the register budget of four waves per SIMD (128 VGPRs, one spilled), so that two workgroups share a CU and one computes
+// while the other loads or drains.  No trace, no second destination (those launches take the generic kernel).
+template <int GLR, int GLC>
+__global__ void __launch_bounds__(1 << (GLR + GLC - 3)) __attribute__((amdgpu_waves_per_eu(4)))
+ntt_pass_kernel_fixed8(const PassParams P, uint32_t ntiles, int xcd_remap, int wave_local) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Fe* lds = reinterpret_cast<Fe*>(smem_raw);
+    uint32_t wg = blockIdx.x, colbits = 0;
+    if (P.col_enable) { colbits = (wg >> P.col_tiles_log) << P.col_tiles_log; wg -= colbits; }
+    uint32_t tile = wg;
+    if (xcd_remap) tile = (wg & 7u) * (ntiles >> 3) + (wg >> 3);
+    tile |= colbits;
+    Fe* tw = lds + (1u << (GLR + GLC));
+    auto stamp = [](int) {};
+    auto sync = [] { __syncthreads(); };
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    FixedRounds<3, GLR, GLC, 0, false>::run(P, tile, threadIdx.x, lds, tw, sync, wsync, stamp, wave_local != 0);
+}
+
 __global__ void __launch_bounds__(256) pow_table_kernel(Fe* out, uint64_t count, Fe base_m, uint64_t step, Fe scale_m) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = pow_table_entry(base_m, i, step, scale_m);
@@ -605,6 +625,14 @@ void launch_pass(const NttPassDesc& pd, hipStream_t st) {
 #undef SC_FIXED
         }
     }
+    if constexpr (LOGE == 3) {
+        if (g.fixed_shapes && !pd.p.trace && !pd.p.blk_enable) {
+            const int lr = pd.p.logR, lc = pd.p.logC;
+#define SC_FIXED8(LR, LC) if (lr == LR && lc == LC) { hipLaunchKernelGGL((ntt_pass_kernel_fixed8<LR, LC>), dim3(pd.ntiles * pd.cols), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap, g.wave_local); return; }
+            SC_FIXED8(10, 2) SC_FIXED8(9, 3) SC_FIXED8(8, 4)
+#undef SC_FIXED8
+        }
+    }
     hipLaunchKernelGGL(ntt_pass_kernel<LOGE>, dim3(pd.ntiles * pd.cols), dim3(pd.threads), pd.lds_bytes, st, pd.p, pd.ntiles, remap);
 }
 
@@ -932,6 +960,7 @@ int sc_set_tuning(const char* key, int value) {
     else if (k == "fixed_shapes") g.fixed_shapes = value;
     else if (k == "wave_local") g.wave_local = value;
     else if (k == "prio_balance") g.prio_balance = value;
+    else if (k == "loge_cols") g.tuning.loge_cols = value;
     else if (k == "tw_on_load") g.tuning.tw_on_load = value;
     else if (k == "prune") g.tuning.prune = value;
     else if (k == "merkle_big_nlev") g.merkle_big_nlev = value < 0 ? 0 : (value > 8 ? 8 : value);

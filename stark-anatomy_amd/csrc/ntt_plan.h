@@ -22,6 +22,12 @@ struct NttTuning {
     // last round, at-store wins everywhere (2^22 +3 %, LDE 2^18 -> 2^21 71 -> 63.5 us, 2^20 +8 %).  Kept as an option.
     int tw_on_load = 0;
     int prune = 1;               // skip the degenerate top stages of a zero-padded first pass (PassParams::prune_log)
+    // elements per thread (log2) for the 2^12-element tiles -- (10,2), (9,3), (8,4) -- of a BATCH of columns (NttIo::cols > 1).  With four
+    // elements a thread such a tile is a 1024-thread workgroup and exactly one fits a CU; with eight it is 512 threads, three stages per
+    // round instead of two (four rounds instead of five for 2^10 points), and -- built for the registers of four waves per SIMD
+    // (ntt_pass_kernel_fixed8: 128 VGPRs) -- TWO fit, so one computes while the other loads or drains: 2^20 x 64 columns +7 %, 2^18 x 64
+    // +18 %.  A lone transform keeps four (its single workgroup per CU loses occupancy with eight: -9 %); the 2^11-element tiles too.
+    int loge_cols = 3;
 };
 
 inline NttTuning resolve_tuning(const NttTuning& in, int logn) {
@@ -194,6 +200,7 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
         }
         int loge = tu.loge;
         const int logT = p.logR + p.logC;
+        if (io.cols > 1 && loge == 2 && tu.loge_cols == 3 && logT == 12 && (p.logR == 10 || p.logR == 9 || p.logR == 8)) loge = 3;
         if (loge > logT) loge = logT;
         // threads per workgroup: <= 1024 (loge 1,2), 512 (loge 3), 256 (loge 4) -- matches the kernels' launch bounds
         while (logT - loge > (loge >= 4 ? 8 : (loge == 3 ? 9 : 10))) ++loge;

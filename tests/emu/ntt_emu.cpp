@@ -41,6 +41,15 @@ static void run_pass(const NttPassDesc& pd) {
         EMU_FIXED(8, 3) EMU_FIXED(7, 4) EMU_FIXED(10, 2) EMU_FIXED(6, 5) EMU_FIXED(9, 3) EMU_FIXED(8, 4)
 #undef EMU_FIXED
     }
+    if constexpr (LOGE == 3) {          // the batches' eight-elements-per-thread kernels (ntt_pass_kernel_fixed8)
+#define EMU_FIXED8(LR, LC)                                                                                  \
+        if (P.logR == LR && P.logC == LC) {                                                                 \
+            for (uint32_t tile = 0; tile < pd.ntiles * pd.cols; ++tile) run_fixed_rounds<3, LR, LC>(pd, tile, lds.data(), tw); \
+            return;                                                                                         \
+        }
+        EMU_FIXED8(10, 2) EMU_FIXED8(9, 3) EMU_FIXED8(8, 4)
+#undef EMU_FIXED8
+    }
     RoundSched rs = make_rounds(P.logR, LOGE);
     for (uint32_t tile = 0; tile < pd.ntiles * pd.cols; ++tile)
         for (int r = 0; r < rs.nrounds; ++r)

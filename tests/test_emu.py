@@ -288,7 +288,7 @@ def test_emu_fourstep_stages(emu, log2n, world, blocks, defer, diag):
 
 
 # (logn, cols): one pass (<= 2^11), two passes (default plans up to 2^20), three passes (above)
-COLUMNS = [(6, 5), (11, 2), (12, 7), (12, 64), (13, 32), (14, 3), (14, 16), (15, 8), (16, 2), (16, 4), (21, 2)]
+COLUMNS = [(6, 5), (11, 2), (12, 7), (12, 64), (13, 32), (14, 3), (14, 16), (15, 8), (16, 2), (16, 4), (17, 3), (19, 2), (21, 2)]
 
 
 @pytest.mark.parametrize("cfg", COLUMNS)

@@ -13,7 +13,7 @@ log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cols = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 n = 1 << log2n
 sc.init(0); lib = sc.lib(); dev = torch.device("cuda", 0)
-sc.set_tuning("stream_tiles", 0)
+sc.set_tuning("loge_cols", 2)          # the TRACE build exists for the four-elements-per-thread kernels
 root = sc.fe_bytes(nth_root(n))
 x = torch.from_numpy(synth.synth_packed(3, n * cols).view(np.int64).reshape(-1)).to(dev); y = torch.empty_like(x)
 npass = int(lib.sc_ntt_num_passes(n))
