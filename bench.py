@@ -513,8 +513,9 @@ def main():
                          "valu_insts_per_launch": measured_valu(pmc_key) if not sharded else None,
                          "pmc_collected_with_these_kernel_sources": pmc_figures_are_current(),
                          "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 and valu_insts (SQ_INSTS_VALU, wave-level) per launch from profiles/ (PMC passes); "
-                                 "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles is its issue floor -- 6.56 M per 2^20 column and pass = 12.8 us at the "
-                                 "2.1 GHz the board holds under this load (13.3 us per column in a launch over 64 columns; 17.4 us for a lone column, one "
+                                 "the kernel is VALU-bound: valu_insts / 1024 SIMDs x ~4.2 cycles at the 2.1 GHz the board holds under this load is its issue time -- "
+                                 "12.3 us per 2^20 column of a launch over 64 columns (eight elements per thread, two workgroups per CU: 12.0 measured); "
+                                 "12.8 us for the lone column's kernel, which takes 17.4: one "
                                  "workgroup per CU with every CU in the same phase), see DESIGN.md 3.1"},
         }
         if sharded:
