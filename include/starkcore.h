@@ -108,8 +108,9 @@ int sc_ntt_dev(const void* d_in, void* d_out, uint64_t n, const uint64_t root[2]
 /* The same transform for `cols` independent vectors of length n -- the registers of a trace, the loops over columns of
  * code/fast_stark.py:84-90 and :100-104 -- column c at element c * n of d_in and of d_out (d_in == d_out is allowed): one set of
  * launches covers up to 2^26 elements (64 columns of 2^20), every pass over cols x its tiles, so the workgroups of one column start
- * while those of another finish (a lone 2^20 transform is one workgroup per CU with every CU in the same phase: 30 G elements/s;
- * 16-64 columns: 38-41; 64 columns of 2^16: 45 against 3.4 one at a time -- DESIGN.md 3.1). */
+ * while those of another finish, and the 2^12-element tiles of a batch run two workgroups per CU (a lone 2^20 transform is one
+ * workgroup per CU with every CU in the same phase: 30 G elements/s; 16-64 columns: 43-44; 64 columns of 2^16: 45-49 against 3.4
+ * one at a time -- DESIGN.md 3.1). */
 int sc_ntt_columns_dev(const void* d_in, void* d_out, uint64_t n, uint64_t cols, const uint64_t root[2], int inverse, void* stream);
 
 /* ---- building blocks of the multi-GPU four-step NTT (no reference counterpart: the reference is single-process;

@@ -100,7 +100,7 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
     if (io.cols < 1 || io.cols > 65536) return false;
     // a batch of columns is one long grid whatever the length of a column: short columns then take the 2^11-element tiles of the
     // long transforms (three workgroups per CU; shapes (7,4), (6,5), (8,3), which have geometry-specialised kernels) instead of the
-    // tiles a lone short transform shrinks to in order to cover the machine (2^14 x 256 columns: 27 -> 4x G elements/s)
+    // tiles a lone short transform shrinks to in order to cover the machine (2^14 x 256 columns: 27 -> 49 G elements/s)
     int cols_log = 0;
     while ((2u << cols_log) <= io.cols) ++cols_log;
     if (io.cols > 1 && logn <= 16) {
