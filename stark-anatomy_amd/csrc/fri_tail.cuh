@@ -81,10 +81,7 @@ __device__ __forceinline__ void blake2b_block_4lane(const uint64_t* msg, uint32_
     uint64_t a = h0, b = iv_b, c = iv_a, d = iv_b;
     if (j == 0) d ^= (uint64_t)len;   // t0 = message length
     if (j == 2) d = ~d;               // final block
-    B2_ROUND4(0x76543210u, 0xfedcba98u); B2_ROUND4(0x6df984aeu, 0x357b20c1u); B2_ROUND4(0xdf250c8bu, 0x491763eau);
-    B2_ROUND4(0xebcd1397u, 0x8f04a562u); B2_ROUND4(0xfa427509u, 0xd386cb1eu); B2_ROUND4(0x38b0a6c2u, 0x91ef57d4u);
-    B2_ROUND4(0xa4def15cu, 0xb8293670u); B2_ROUND4(0x931ce7bdu, 0xa2684f05u); B2_ROUND4(0x803b9ef6u, 0x5a417d2cu);
-    B2_ROUND4(0x5167482au, 0x0dc3e9bfu); B2_ROUND4(0x76543210u, 0xfedcba98u); B2_ROUND4(0x6df984aeu, 0x357b20c1u);
+    B2_ROUNDS4();
     h_lo = h0 ^ a ^ c;
     h_hi = iv_b ^ b ^ d;
 }

@@ -103,14 +103,50 @@ template <int CTRL> __device__ __forceinline__ uint64_t quad_perm64(uint64_t x) 
         b = rotr64(b ^ c, 63);           \
     } while (0)
 
-#define B2_ROUND4(COL, DIA)                                                          \
+// The message words of a round -- two per G, per-lane addresses from the packed sigma constants -- are REQUESTED from LDS one round
+// ahead and waited for at the top of their round.  Written as loads in C++ the compiler sinks them to their first use (register
+// pressure), and every round then exposes an LDS round trip on the dependent chain of the compression -- which is all a narrow
+// level's time is made of; so the four ds_read_b64 are one asm statement (the hardware counts them in lgkmcnt like the compiler's
+// own: its waits only become stricter), and the wait is an asm statement the words pass THROUGH, so nothing that uses them can
+// move above it.  msg must be an LDS address (the low half of its flat address is the LDS offset).
+#define B2_MSG4_REQUEST(COL, DIA, X0, Y0, X1, Y1)                                    \
     do {                                                                             \
-        const uint32_t bc = ((uint32_t)(COL) >> sh) & 0xFFu;                         \
-        B2_G4(msg[bc & 15u], msg[bc >> 4]);                                          \
+        const uint32_t bc_ = ((uint32_t)(COL) >> sh) & 0xFFu, bd_ = ((uint32_t)(DIA) >> sh) & 0xFFu; \
+        const uint32_t a0_ = mbase + ((bc_ & 15u) << 3), a1_ = mbase + ((bc_ >> 4) << 3), a2_ = mbase + ((bd_ & 15u) << 3), a3_ = mbase + ((bd_ >> 4) << 3); \
+        /* (`a` passes through the request and `b` through the wait: the round's arithmetic starts with a and ends with b, so  */ \
+        /* the compiler can neither move a round's arithmetic above the request nor the wait above the previous round's)        */ \
+        asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %6\n\tds_read_b64 %2, %7\n\tds_read_b64 %3, %8"           \
+                     : "=&v"(X0), "=&v"(Y0), "=&v"(X1), "=&v"(Y1), "+v"(a) : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory"); \
+    } while (0)
+#define B2_MSG4_ARRIVED(X0, Y0, X1, Y1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(Y0), "+v"(X1), "+v"(Y1), "+v"(b))
+#define B2_ROUND4_BODY()                                                             \
+    do {                                                                             \
+        B2_G4(mx0, my0);                                                             \
         b = quad_perm64<0x39>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x93>(d); \
-        const uint32_t bd = ((uint32_t)(DIA) >> sh) & 0xFFu;                         \
-        B2_G4(msg[bd & 15u], msg[bd >> 4]);                                          \
+        B2_G4(mx1, my1);                                                             \
         b = quad_perm64<0x93>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x39>(d); \
+    } while (0)
+// one round, given the NEXT round's sigma constants
+#define B2_ROUND4_NEXT(NCOL, NDIA)                                                   \
+    do {                                                                             \
+        uint64_t nx0, ny0, nx1, ny1;                                                 \
+        B2_MSG4_ARRIVED(mx0, my0, mx1, my1);                                         \
+        B2_MSG4_REQUEST(NCOL, NDIA, nx0, ny0, nx1, ny1);                             \
+        B2_ROUND4_BODY();                                                            \
+        mx0 = nx0; my0 = ny0; mx1 = nx1; my1 = ny1;                                  \
+    } while (0)
+// the twelve rounds (sigma of rounds 10 and 11 = sigma of rounds 0 and 1)
+#define B2_ROUNDS4()                                                                 \
+    do {                                                                             \
+        const uint32_t mbase = (uint32_t)(uintptr_t)(msg);                           \
+        uint64_t mx0, my0, mx1, my1;                                                 \
+        B2_MSG4_REQUEST(0x76543210u, 0xfedcba98u, mx0, my0, mx1, my1);               \
+        B2_ROUND4_NEXT(0x6df984aeu, 0x357b20c1u); B2_ROUND4_NEXT(0xdf250c8bu, 0x491763eau); B2_ROUND4_NEXT(0xebcd1397u, 0x8f04a562u); \
+        B2_ROUND4_NEXT(0xfa427509u, 0xd386cb1eu); B2_ROUND4_NEXT(0x38b0a6c2u, 0x91ef57d4u); B2_ROUND4_NEXT(0xa4def15cu, 0xb8293670u); \
+        B2_ROUND4_NEXT(0x931ce7bdu, 0xa2684f05u); B2_ROUND4_NEXT(0x803b9ef6u, 0x5a417d2cu); B2_ROUND4_NEXT(0x5167482au, 0x0dc3e9bfu); \
+        B2_ROUND4_NEXT(0x76543210u, 0xfedcba98u); B2_ROUND4_NEXT(0x6df984aeu, 0x357b20c1u);                                           \
+        B2_MSG4_ARRIVED(mx0, my0, mx1, my1);                                         \
+        B2_ROUND4_BODY();                                                            \
     } while (0)
 
 // single-block BLAKE2b-512 of the 128-byte message msg[0..16) (LDS), computed by the 4 lanes j = 0..3 of a quad (all four must
@@ -122,10 +158,7 @@ __device__ __forceinline__ void blake2b_node_4lane(const uint64_t* msg, uint32_t
     uint64_t a = h0, b = iv_b, c = iv_a, d = iv_b;
     if (j == 0) d ^= 128ull;          // t0 = message length
     if (j == 2) d = ~d;               // final block
-    B2_ROUND4(0x76543210u, 0xfedcba98u); B2_ROUND4(0x6df984aeu, 0x357b20c1u); B2_ROUND4(0xdf250c8bu, 0x491763eau);
-    B2_ROUND4(0xebcd1397u, 0x8f04a562u); B2_ROUND4(0xfa427509u, 0xd386cb1eu); B2_ROUND4(0x38b0a6c2u, 0x91ef57d4u);
-    B2_ROUND4(0xa4def15cu, 0xb8293670u); B2_ROUND4(0x931ce7bdu, 0xa2684f05u); B2_ROUND4(0x803b9ef6u, 0x5a417d2cu);
-    B2_ROUND4(0x5167482au, 0x0dc3e9bfu); B2_ROUND4(0x76543210u, 0xfedcba98u); B2_ROUND4(0x6df984aeu, 0x357b20c1u);
+    B2_ROUNDS4();
     h_lo = h0 ^ a ^ c;
     h_hi = iv_b ^ b ^ d;
 }
