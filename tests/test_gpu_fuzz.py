@@ -208,3 +208,38 @@ def test_fuzz_progressions(sc):
         dom = sc.GeoDomain.create(c, q, n)
         assert dom is not None and synth.unpack_ints(dom.interpolate(sc.DeviceVector.from_bytes(synth.pack_ints(vals))).to_bytes()) == po.fast_interpolate(pts, vals, root, order)
         dom.free()
+
+
+def test_fuzz_column_batches(sc):
+    """sc_ntt_columns_dev against sc_ntt_dev column by column (the single transform is pinned to the oracle and the reference's goldens
+    elsewhere): random lengths 2^1 ... 2^21, column counts that are not powers of two, random primitive roots, forward and inverse,
+    in place and out of place -- the one-pass plans, the short columns on the long transforms' tiles, the eight-elements-per-thread
+    kernels of the 2^12-element tiles (2^17 ... 2^20), the three-pass plans, and a batch that needs two sets of launches."""
+    import numpy as np
+    import torch
+    rng = random.Random(103)
+    lib = sc.lib()
+    dev = torch.device("cuda", 0)
+    cases = [(rng.randrange(1, 22), None) for _ in range(36)] + [(17, 5), (18, 3), (19, 2), (20, 2), (12, 70), (16, 33), (21, 33)]
+    for logn, cols in cases:
+        n = 1 << logn
+        if cols is None:
+            cols = rng.randrange(1, max(2, min(40, (1 << 23) >> logn)) + 1)
+        root = sc.fe_bytes(rand_root(rng, n))
+        inv = rng.randrange(2)
+        host = synth.synth_packed(rng.randrange(1 << 30), n * cols)
+        for i in range(0, n * cols, max(1, (n * cols) // 64)):                       # edge residues sprinkled in
+            v = rng.choice((0, 1, P - 1, (1 << 64) - 1, 1 << 64))
+            host[i, 0], host[i, 1] = v & ((1 << 64) - 1), v >> 64
+        x = torch.from_numpy(host.view(np.int64).reshape(-1)).to(dev)
+        want = torch.empty_like(x)
+        for c in range(cols):
+            sc._check(lib.sc_ntt_dev(x.data_ptr() + 16 * n * c, want.data_ptr() + 16 * n * c, n, root, inv, None))
+        if rng.random() < 0.5:
+            got = x.clone()
+            sc._check(lib.sc_ntt_columns_dev(got.data_ptr(), got.data_ptr(), n, cols, root, inv, None))
+        else:
+            got = torch.empty_like(x)
+            sc._check(lib.sc_ntt_columns_dev(x.data_ptr(), got.data_ptr(), n, cols, root, inv, None))
+        sc.synchronize()
+        assert torch.equal(got, want), (logn, cols, inv)
