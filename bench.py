@@ -689,6 +689,17 @@ def extras(sc, lib, stream=None):
     outv = sc.DeviceVector(order)
     best = device_time(lambda: sc._check(lib.sc_coset_evaluate_dev(coeffs.ptr, m, sc.fe_bytes(GEN), sc.fe_bytes(om.value), order, outv.ptr, sptr)), 50)
     res["lde_2p18_to_2p21"] = {"ms": best * 1e3, "alg_GBps": 16 * (m + order) / best / 1e9, "timing": "HIP events, 50 calls back to back, best of 3"}
+    # ... and eight such columns in one set of launches (sc_coset_evaluate_columns_dev: the registers of a trace, fast_stark.py:100-104)
+    try:
+        k = 8
+        coeffs8 = sc.DeviceVector.from_bytes(synth.synth_packed(5, m * k).tobytes())
+        out8 = sc.DeviceVector(order * k)
+        best8 = device_time(lambda: sc._check(lib.sc_coset_evaluate_columns_dev(coeffs8.ptr, m, k, sc.fe_bytes(GEN), sc.fe_bytes(om.value), order, out8.ptr, sptr)), 20)
+        same = out8.to_bytes(0, order) == outv.to_bytes()
+        res["lde_2p18_to_2p21_x8_columns"] = {"ms_per_column": best8 * 1e3 / k, "alg_GBps": 16 * (m + order) * k / best8 / 1e9, "column_0_equals_the_single_call": same}
+        del coeffs8, out8
+    except Exception as e:       # noqa: BLE001
+        res["lde_2p18_to_2p21_x8_columns"] = {"error": repr(e)}
     # configs[3]: Fri.prove, N = 2^22
     N = 1 << 22
     om = field.primitive_nth_root(N)

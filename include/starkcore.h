@@ -196,6 +196,9 @@ int sc_twiddle_matrix_dev(void* d_data, uint64_t rows, uint64_t cols, uint64_t r
 /* out[i] = sum_{j<m} coeffs[j] * (offset * generator^i)^j, i < order; m <= order. */
 int sc_coset_evaluate(const void* coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* out);
 int sc_coset_evaluate_dev(const void* d_coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* d_out, void* stream);
+/* The same for `cols` polynomials of m >= 1 coefficients each -- the loop over registers of code/fast_stark.py:100-104 -- polynomial c at
+ * element c * m of d_coeffs, its values at element c * order of d_out; one set of launches (sc_ntt_columns_dev). */
+int sc_coset_evaluate_columns_dev(const void* d_coeffs, uint64_t m, uint64_t cols, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* d_out, void* stream);
 
 /* ---- NTT core of fast_multiply : code/ntt.py:51-64 ----------------------------------------- */
 /* out[0..n_out) = intt(root, ntt(root, a||0) * ntt(root, b||0))[0..n_out); na, nb, n_out <= order.

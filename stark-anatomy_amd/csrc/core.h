@@ -162,6 +162,7 @@ struct NttOpts {
     uint64_t in_limit = ~0ull;
     const PowTables* coset = nullptr;
     uint32_t cols = 1;       // independent transforms in one set of launches, column c at element c * n of in / out (NttIo::cols)
+    uint64_t col_stride_in = 0;   // ... of `in` at c * col_stride_in instead (0 = n)
 };
 
 // Climb from level `lvl` (already in the tree, `N >> lvl` nodes) to the root.  Levels wider than FUSE_MAX_W nodes are

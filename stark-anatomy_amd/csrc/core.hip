@@ -668,7 +668,7 @@ int ntt_device(const Fe* d_in, Fe* d_out, int logn, Fe root, bool inverse_scale,
     tb.mt = pt->mt; tb.mt_log = pt->mt_log; tb.tl = pt->tl; tb.th = pt->th;
     tb.th_scaled = (inverse_scale && m > 1) ? pt->th_ninv : nullptr;
     NttIo io;
-    io.in = d_in; io.out = d_out; io.in_limit = o.in_limit; io.cols = o.cols;
+    io.in = d_in; io.out = d_out; io.in_limit = o.in_limit; io.cols = o.cols; io.col_stride_in = o.col_stride_in;
     if (m > 1) { void* w; SCCHK(ntt_work_buffer(st, n * o.cols * sizeof(Fe), &w)); io.work = (Fe*)w; }
     if (o.coset) { io.ol = o.coset->lo; io.oh = o.coset->hi; }
     if (inverse_scale && m == 1) { io.scale_last = true; io.scale = mont_inv(to_mont(Fe{n, 0})); }
@@ -1304,6 +1304,35 @@ int sc_coset_evaluate_dev(const void* d_coeffs, uint64_t m, const uint64_t offse
     o.in_limit = m;
     o.coset = pw;
     return ntt_device((const Fe*)d_coeffs, (Fe*)d_out, ilog2(order), gen, false, o, st);
+}
+
+// the same for `cols` polynomials of m coefficients each (polynomial c at element c * m of d_coeffs, its values at c * order of d_out):
+// zero padding and coset scaling apply per column, one set of launches covers COLS_ELEMS_PER_LAUNCH values
+int sc_coset_evaluate_columns_dev(const void* d_coeffs, uint64_t m, uint64_t cols, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    SCCHK(ensure_init());
+    hipStream_t st = pick_stream(stream);
+    if (cols == 0) return SC_OK;
+    if (m == 0 || m > order) return fail(SC_ERR_BAD_ARG, m ? "more coefficients than the evaluation order" : "a batch of empty polynomials");
+    if (!is_pow2(order)) return fail(SC_ERR_NOT_POW2, "cannot compute ntt of non-power-of-two sequence");
+    if (order < 2) return fail(SC_ERR_BAD_ARG, "evaluation order below 2");
+    Fe gen = fe_from(generator), off = fe_from(offset);
+    SCCHK(check_root(gen, order));
+    if (fe_ge_p(off)) return fail(SC_ERR_BAD_ARG, "offset is not a canonical residue");
+    PowTables* pw;
+    SCCHK(get_pow(off, m, st, &pw));
+    uint64_t per = COLS_ELEMS_PER_LAUNCH / order;
+    if (per < 1) per = 1;
+    if (per > 65536) per = 65536;
+    for (uint64_t done = 0; done < cols; done += per) {
+        NttOpts o;
+        o.in_limit = m;
+        o.coset = pw;
+        o.cols = (uint32_t)(cols - done < per ? cols - done : per);
+        o.col_stride_in = m;
+        SCCHK(ntt_device((const Fe*)d_coeffs + done * m, (Fe*)d_out + done * order, ilog2(order), gen, false, o, st));
+    }
+    return SC_OK;
 }
 
 int sc_coset_evaluate(const void* coeffs, uint64_t m, const uint64_t offset[2], const uint64_t generator[2], uint64_t order, void* out) {

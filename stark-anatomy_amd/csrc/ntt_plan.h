@@ -81,6 +81,7 @@ struct NttIo {
     // at element c * n, every pass is launched over cols x its tiles, and workgroup b works on column b / tiles, tile b % tiles
     // (PassParams::col_enable).  Twiddles and tables are shared by the columns; zero padding and coset scaling apply to each.
     uint32_t cols = 1;
+    uint64_t col_stride_in = 0;   // elements between the columns of `in` (0 = n; a batch of zero-padded inputs: the m coefficients of a column)
 };
 
 inline int plan_num_passes(int logn, const NttTuning& tu_in) {
@@ -216,6 +217,7 @@ inline bool plan_ntt(NttPlanDesc& d, int logn, const NttTables& tb, const NttIo&
             p.col_tiles_log = 0;
             while ((1u << p.col_tiles_log) < pd.ntiles) ++p.col_tiles_log;               // tiles per column: a power of two
             p.col_stride = n;
+            p.col_stride_in = (i == 0 && io.col_stride_in) ? io.col_stride_in : n;
         }
         logA += logR;
     }

@@ -94,10 +94,11 @@ struct PassParams {
     uint32_t blk_row_k, blk_row_mid;
     Fe* out_blk[SC_MAX_BLOCKS];
     // several independent transforms in one launch (NttIo::cols, sc_ntt_columns_dev): tile index = column * 2^col_tiles_log + the
-    // tile of that column's own pass; the column only shifts the element index into `in` and `out` by column * col_stride.
+    // tile of that column's own pass; the column only shifts the element index: by column * col_stride into `out`, by column *
+    // col_stride_in into `in` (they differ in the first pass of a batch of zero-padded inputs: m coefficients in, n values out).
     int col_enable;
     int col_tiles_log;
-    uint64_t col_stride;
+    uint64_t col_stride, col_stride_in;
     // diagnostics (tools/pass_trace.py): per-wave s_memtime stamps of the phases of a workgroup; nullptr in production
     unsigned long long* trace;
 };
@@ -160,16 +161,17 @@ struct Round {
     uint32_t rr[G];   // per group: row bits outside the field, packed (rrem)
     uint32_t cc[G];   // per group: column
     uint32_t t_lo, t_mid, t_hi;
-    uint64_t col_off;  // first element of this workgroup's column (0 unless the launch covers several transforms)
+    uint64_t col_off, col_off_in;  // first element of this workgroup's column in `out` / `in` (0 unless the launch covers several transforms)
     int logR, logC;
 
     SC_HD void setup(const PassParams& P, bool first, uint32_t tile, uint32_t tid) {
         logR = (GLR >= 0) ? GLR : P.logR;
         logC = (GLC >= 0) ? GLC : P.logC;
         const uint32_t T = 1u << (logR + logC - LOGE);   // threads per workgroup
-        col_off = 0;
+        col_off = col_off_in = 0;
         if (P.col_enable) {
             col_off = (uint64_t)(tile >> P.col_tiles_log) * P.col_stride;
+            col_off_in = (uint64_t)(tile >> P.col_tiles_log) * P.col_stride_in;
             tile &= (1u << P.col_tiles_log) - 1u;
         }
         t_lo = tile & ((1u << P.lo_log) - 1u);
@@ -209,7 +211,7 @@ struct Round {
         for (int i = 0; i < E; ++i) {
             const uint64_t j = in_index(P, i, sh);
             Fe v = fe_zero();
-            if (j < P.in_limit) v = P.in[col_off + j];
+            if (j < P.in_limit) v = P.in[col_off_in + j];
             x[i] = v;
             if (P.twd_in) tin[i] = P.twd_in[j & P.twd_in_mask];
         }

@@ -79,6 +79,7 @@ SIGNATURES = {
     "sc_twiddle_matrix_dev": (_int, [_vp, _u64, _u64, _u64, _u64, _vp, _u64, _vp, _vp]),
     "sc_coset_evaluate": (_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     "sc_coset_evaluate_dev": (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
+    "sc_coset_evaluate_columns_dev": (_int, [_vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
     "sc_poly_mul": (_int, [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64]),
     "sc_coset_divide": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64]),
     "sc_coset_divide_dev": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_int), _vp]),

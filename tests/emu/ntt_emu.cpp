@@ -125,7 +125,15 @@ extern "C" int emu_ntt(const uint64_t* in, uint64_t* out, int logn, const uint64
 }
 
 // `cols` independent transforms in one set of launches (NttIo::cols, sc_ntt_columns_dev): in / out are [cols][n]
+static int emu_columns_impl(const uint64_t* in, uint64_t* out, int logn, int cols, const uint64_t* root, int inverse, int direct_tw, uint64_t m, const uint64_t* offset);
 extern "C" int emu_ntt_columns(const uint64_t* in, uint64_t* out, int logn, int cols, const uint64_t* root, int inverse, int direct_tw) {
+    return emu_columns_impl(in, out, logn, cols, root, inverse, direct_tw, 0, nullptr);
+}
+// the batched LDE (sc_coset_evaluate_columns_dev): `cols` polynomials of m coefficients each (in: [cols][m]) -> [cols][n] values on offset * <root>
+extern "C" int emu_coset_evaluate_columns(const uint64_t* in, uint64_t* out, int logn, int cols, const uint64_t* root, uint64_t m, const uint64_t* offset) {
+    return emu_columns_impl(in, out, logn, cols, root, 0, 2, m, offset);
+}
+static int emu_columns_impl(const uint64_t* in, uint64_t* out, int logn, int cols, const uint64_t* root, int inverse, int direct_tw, uint64_t m_coeffs, const uint64_t* offset) {
     const uint64_t n = 1ull << logn;
     Fe r_m = to_mont(Fe{root[0], root[1]});
     Fe scale_m = fe_mont_one();
@@ -147,6 +155,15 @@ extern "C" int emu_ntt_columns(const uint64_t* in, uint64_t* out, int logn, int 
     NttIo io;
     io.in = (const Fe*)in; io.work = work.data(); io.out = (Fe*)out;
     io.cols = (uint32_t)cols;
+    std::vector<Fe> ol, oh;
+    if (offset) {
+        Fe o_m = to_mont(Fe{offset[0], offset[1]});
+        fill_table(ol, 4096, o_m, 1, fe_mont_one());
+        fill_table(oh, (m_coeffs >> 12) + 1, o_m, 4096, fe_mont_one());
+        io.ol = ol.data(); io.oh = oh.data();
+        io.in_limit = m_coeffs;
+        io.col_stride_in = m_coeffs;
+    }
     io.scale_last = inverse && m == 1;
     io.scale = scale_m;
     NttPlanDesc d;

@@ -308,3 +308,21 @@ def test_emu_column_batches(emu, cfg):
             rc = emu.emu_ntt_columns(data, out, logn, cols, int(root).to_bytes(16, "little"), inverse, direct)
             assert rc == (1 if logn <= 11 else 2 if logn <= 20 else 3), rc
             assert out.raw == want, (cfg, inverse, direct)
+
+
+@pytest.mark.parametrize("cfg", [(8, 3, 100), (12, 5, 1024), (14, 3, 2048), (15, 4, 4096), (18, 3, 1 << 15), (21, 2, 1 << 18)])
+def test_emu_lde_column_batches(emu, cfg):
+    """sc_coset_evaluate_columns_dev (NttIo::col_stride_in): `cols` polynomials of m coefficients each, zero-padded, scaled by offset^j and
+    transformed in one set of launches -- one, two and three passes, the pruned first pass, the eight-element kernels -- equal the oracle's
+    fast_coset_evaluate column by column."""
+    logn, cols, m = cfg
+    n = 1 << logn
+    emu.emu_coset_evaluate_columns.restype = ctypes.c_int
+    emu.emu_coset_evaluate_columns.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    data = synth.synth_packed(400 + logn, m * cols).tobytes()
+    root = po.primitive_nth_root(n)
+    out = ctypes.create_string_buffer(16 * n * cols)
+    rc = emu.emu_coset_evaluate_columns(data, out, logn, cols, int(root).to_bytes(16, "little"), m, int(po.GENERATOR).to_bytes(16, "little"))
+    assert rc > 0, rc
+    want = b"".join(po.C.coset_evaluate(data[16 * m * c:16 * m * (c + 1)], m, po.GENERATOR, root, n) for c in range(cols))
+    assert out.raw == want, cfg

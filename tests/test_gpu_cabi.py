@@ -119,6 +119,33 @@ def test_ntt_columns_full_size_round_trip(sc):
     assert torch.equal(z, x)
 
 
+@pytest.mark.parametrize("logn,cols,m", [(4, 3, 16), (10, 5, 100), (12, 9, 1024), (14, 3, 2048), (16, 6, 1 << 13), (18, 3, 1 << 15), (21, 3, 1 << 18)])
+def test_coset_evaluate_columns_vs_oracle(sc, logn, cols, m):
+    """sc_coset_evaluate_columns_dev: the LDE of `cols` polynomials in one set of launches (fast_coset_evaluate, code/ntt.py:132-135, once per
+    column: the loop of code/fast_stark.py:100-104) -- zero padding and coset scaling per column, the pruned first pass, one to three passes,
+    the configs[2] shape 2^18 -> 2^21 -- equals the oracle column by column, and sc_coset_evaluate_dev of each column alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    lib = sc.lib()
+    n = 1 << logn
+    root = po.primitive_nth_root(n)
+    rt, off = sc.fe_bytes(root), sc.fe_bytes(po.GENERATOR)
+    data = packed(1300 + logn, m * cols)
+    x = torch.from_numpy(np.frombuffer(data, dtype=np.int64).copy()).to(dev)
+    y = torch.empty(2 * n * cols, dtype=torch.int64, device=dev)
+    one = torch.empty(2 * n, dtype=torch.int64, device=dev)
+    sc._check(lib.sc_coset_evaluate_columns_dev(x.data_ptr(), m, cols, off, rt, n, y.data_ptr(), None))
+    sc.synchronize()
+    got = y.cpu().numpy().tobytes()
+    for c in range(cols):
+        if logn <= 18 or c == cols - 1:
+            assert got[16 * n * c:16 * n * (c + 1)] == C.coset_evaluate(data[16 * m * c:16 * m * (c + 1)], m, po.GENERATOR, root, n), (logn, cols, c)
+        sc._check(lib.sc_coset_evaluate_dev(x.data_ptr() + 16 * m * c, m, off, rt, n, one.data_ptr(), None))
+        sc.synchronize()
+        assert torch.equal(one, y[2 * n * c:2 * n * (c + 1)]), (logn, cols, c)
+    assert lib.sc_coset_evaluate_columns_dev(x.data_ptr(), n + 1, 1, off, rt, n, y.data_ptr(), None) != 0      # more coefficients than points
+
+
 def test_transforms_in_flight_on_two_streams(sc):
     """Two independent columns transformed side by side (one per HIP stream, many times over, never waiting in between): every
     multi-pass transform keeps its intermediate vector in a buffer of ITS stream (csrc/core.hip ntt_work_buffer), so the results are
