@@ -87,6 +87,7 @@ def test_ntt_columns_vs_oracle(sc, logn, cols):
     assert z.cpu().numpy().tobytes() == data
     # in place, and the inverse against the oracle's own
     w = x.clone()
+    torch.cuda.synchronize()                # (torch's copy and the library's stream are ordered by nothing else)
     sc._check(lib.sc_ntt_columns_dev(w.data_ptr(), w.data_ptr(), n, cols, rt, 1, None))
     sc.synchronize()
     got = w.cpu().numpy().tobytes()

@@ -237,6 +237,7 @@ def test_fuzz_column_batches(sc):
             sc._check(lib.sc_ntt_dev(x.data_ptr() + 16 * n * c, want.data_ptr() + 16 * n * c, n, root, inv, None))
         if rng.random() < 0.5:
             got = x.clone()
+            torch.cuda.synchronize()        # (the copy runs on torch's stream, the library call on the library's: nothing else orders them)
             sc._check(lib.sc_ntt_columns_dev(got.data_ptr(), got.data_ptr(), n, cols, root, inv, None))
         else:
             got = torch.empty_like(x)

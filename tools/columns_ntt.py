@@ -65,7 +65,7 @@ def timed(fn, *a):
 # correctness first
 one_at_a_time(False); torch.cuda.synchronize()
 ok_one = torch.equal(z, x)
-z.zero_(); batch(False); torch.cuda.synchronize()
+z.zero_(); torch.cuda.synchronize(); batch(False); torch.cuda.synchronize()
 ok = torch.equal(z, x) and torch.equal(y, y1) and ok_one
 res = {}
 for name, fn, two in (("one at a time, one stream", one_at_a_time, False), ("one at a time, two streams", one_at_a_time, True),
