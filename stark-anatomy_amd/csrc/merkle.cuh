@@ -79,74 +79,105 @@ __device__ __forceinline__ void blake2b_single_block(const uint64_t m[16], uint3
 }
 
 // ---- four lanes per hash ---------------------------------------------------------------------------------------------
-// Levels narrower than the machine are pure latency: a lone wave issues one VALU instruction per ~5.5 cycles, ~5 us for the
-// ~1950 instructions of a compression, whatever the level's width.  There the state is spread over a quad: lane j of the
-// quad holds column j (a, b, c, d) = (v[j], v[4+j], v[8+j], v[12+j]) and runs ONE G per half-round instead of four; the
-// diagonal step rotates b, c, d by 1, 2, 3 lanes inside the quad (DPP quad_perm, no LDS).  The message words are read from LDS
-// with per-lane addresses: COL/DIA pack, per round, byte j = sigma[2j] | sigma[2j+1] << 4 resp. sigma[8+2j] | sigma[9+2j] << 4.
-// ~800 instructions per lane and compression: ~2.7x shorter dependent chain.
+// Levels narrower than the machine are pure latency: a lone wave issues one VALU instruction per ~5 cycles and a DEPENDENT one
+// every ~8.7 (profiles/r06/blake2b_quad_ubench.txt), whatever the level's width.  There the state is spread over a quad: lane j
+// holds column j (a, b, c, d) = (v[j], v[4+j], v[8+j], v[12+j]) and runs ONE G per half-round instead of four.  What is written
+// below is written for the LENGTH OF THE DEPENDENT CHAIN of a compression, which is all a narrow level's time is made of:
+//   * b -- the LAST value a G produces and the first the next G consumes -- never changes lanes: between the column and the
+//     diagonal step the quad rotates a, c and d instead (DPP quad_perm, no LDS), so lane L runs diagonal L - 1 (its message words
+//     are picked with `shd`), and no DPP move stands between one G and the next;
+//   * a + b + x is (a + x) + b: a is final five steps before b, so a + x is formed early, off the chain.  hipcc re-associates plain
+//     C++ into (b + x) + a -- two adds behind b -- so the EARLY add is an asm statement (b2_add64_early; the wait state the hazard
+//     recogniser puts behind an asm definition lands a dozen instructions before its use) and only the late add is C++;
+//   * a rotated word is put together as a two-element vector (rotr64v): written as (hi << 32) | lo, hipcc adds the two halves of a
+//     freshly rotated d to c one after the other (c + zext(lo) + (hi << 32): a seventh 64-bit add per G, on the chain).
+// 584 VALU instructions per lane and compression; 2 960 cycles per compression in a lone wave (tools/microbench/blake2b_quad_ubench.hip:
+// 3 290 before these three; bit-identical digests).
 template <int CTRL> __device__ __forceinline__ uint64_t quad_perm64(uint64_t x) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xF, 0xF, true);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xF, 0xF, true);
     return ((uint64_t)hi << 32) | lo;
 }
+typedef uint32_t b2_u32x2 __attribute__((ext_vector_type(2)));
+template <int R> __device__ __forceinline__ uint64_t rotr64v(uint64_t x) {
+    if (R == 32) return ((uint64_t)(uint32_t)x << 32) | (uint32_t)(x >> 32);       // (a renaming of registers as long as it is written this way)
+    const b2_u32x2 v = __builtin_bit_cast(b2_u32x2, x);
+    b2_u32x2 r;
+    if (R < 32) { r.x = __builtin_amdgcn_alignbit(v.y, v.x, R); r.y = __builtin_amdgcn_alignbit(v.x, v.y, R); }
+    else { r.x = __builtin_amdgcn_alignbit(v.x, v.y, R - 32); r.y = __builtin_amdgcn_alignbit(v.y, v.x, R - 32); }
+    return __builtin_bit_cast(uint64_t, r);
+}
+__device__ __forceinline__ uint64_t b2_add64_early(uint64_t p, uint64_t q) {
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(p), "v"(q));
+    return r;
+}
 
-#define B2_G4(x, y)                      \
-    do {                                 \
-        a = a + b + (x);                 \
-        d = rotr64(d ^ a, 32);           \
-        c = c + d;                       \
-        b = rotr64(b ^ c, 24);           \
-        a = a + b + (y);                 \
-        d = rotr64(d ^ a, 16);           \
-        c = c + d;                       \
-        b = rotr64(b ^ c, 63);           \
+// One G on (a, b, c, d) with `an` = a + x formed beforehand.  Leaves an = (a moved by PA) + xnext (just a, moved, after the LAST G of a
+// compression), c and d moved by PC / PD, b where it is.
+#define B2_G4(y, PA, PC, PD, xnext, LASTG)                 \
+    do {                                                   \
+        a = an + b;                                        \
+        d = rotr64v<32>(d ^ a);                            \
+        const uint64_t ay_ = b2_add64_early(a, (y));       \
+        c = c + d;                                         \
+        b = rotr64v<24>(b ^ c);                            \
+        a = ay_ + b;                                       \
+        d = rotr64v<16>(d ^ a);                            \
+        an = quad_perm64<PA>(a);                           \
+        if (!(LASTG)) an = b2_add64_early(an, (xnext));    \
+        c = c + d;                                         \
+        b = rotr64v<63>(b ^ c);                            \
+        d = quad_perm64<PD>(d);                            \
+        c = quad_perm64<PC>(c);                            \
     } while (0)
 
-// The message words of a round -- two per G, per-lane addresses from the packed sigma constants -- are REQUESTED from LDS one round
-// ahead and waited for at the top of their round.  Written as loads in C++ the compiler sinks them to their first use (register
-// pressure), and every round then exposes an LDS round trip on the dependent chain of the compression -- which is all a narrow
-// level's time is made of; so the four ds_read_b64 are one asm statement (the hardware counts them in lgkmcnt like the compiler's
-// own: its waits only become stricter), and the wait is an asm statement the words pass THROUGH, so nothing that uses them can
-// move above it.  msg must be an LDS address (the low half of its flat address is the LDS offset).
+// The message words of a round -- two per G, per-lane addresses from the packed sigma constants: COL/DIA pack, per round, byte j =
+// sigma[2j] | sigma[2j+1] << 4 resp. sigma[8+2j] | sigma[9+2j] << 4; a lane reads the column byte at `sh` and the diagonal byte at `shd`
+// -- are REQUESTED from LDS one round ahead and waited for in the middle of the round before theirs.  Written as loads in C++ the compiler
+// sinks them to their first use (register pressure), and every round then exposes an LDS round trip on the dependent chain; so the four
+// ds_read_b64 are one asm statement (the hardware counts them in lgkmcnt like the compiler's own: its waits only become stricter), and
+// the wait is an asm statement the words pass THROUGH, so nothing that uses them can move above it.  msg must be an LDS address (the
+// low half of its flat address is the LDS offset).
 #define B2_MSG4_REQUEST(COL, DIA, X0, Y0, X1, Y1)                                    \
     do {                                                                             \
-        const uint32_t bc_ = ((uint32_t)(COL) >> sh) & 0xFFu, bd_ = ((uint32_t)(DIA) >> sh) & 0xFFu; \
+        const uint32_t bc_ = ((uint32_t)(COL) >> sh) & 0xFFu, bd_ = ((uint32_t)(DIA) >> shd) & 0xFFu; \
         const uint32_t a0_ = mbase + ((bc_ & 15u) << 3), a1_ = mbase + ((bc_ >> 4) << 3), a2_ = mbase + ((bd_ & 15u) << 3), a3_ = mbase + ((bd_ >> 4) << 3); \
-        /* (`a` passes through the request and `b` through the wait: the round's arithmetic starts with a and ends with b, so  */ \
-        /* the compiler can neither move a round's arithmetic above the request nor the wait above the previous round's)        */ \
+        /* (`an` passes through the request and `b` through the wait: a G starts with an and ends with b, so the compiler can   */ \
+        /* neither move a round's arithmetic above the request nor the wait above the column step in front of it)                */ \
         asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %6\n\tds_read_b64 %2, %7\n\tds_read_b64 %3, %8"           \
-                     : "=&v"(X0), "=&v"(Y0), "=&v"(X1), "=&v"(Y1), "+v"(a) : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory"); \
+                     : "=&v"(X0), "=&v"(Y0), "=&v"(X1), "=&v"(Y1), "+v"(an) : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory"); \
     } while (0)
 #define B2_MSG4_ARRIVED(X0, Y0, X1, Y1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(Y0), "+v"(X1), "+v"(Y1), "+v"(b))
-#define B2_ROUND4_BODY()                                                             \
-    do {                                                                             \
-        B2_G4(mx0, my0);                                                             \
-        b = quad_perm64<0x39>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x93>(d); \
-        B2_G4(mx1, my1);                                                             \
-        b = quad_perm64<0x93>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x39>(d); \
-    } while (0)
-// one round, given the NEXT round's sigma constants
+// one round, given the NEXT round's sigma constants.  Column step in lane j = column j; then a comes from lane j - 1, c from j + 1, d from
+// j + 2 (frame of the diagonal step: lane L holds a[L-1], b[L], c[L+1], d[L+2] = diagonal L - 1); after it a from lane j + 1, c from
+// j - 1, d from j + 2 (columns again)
 #define B2_ROUND4_NEXT(NCOL, NDIA)                                                   \
     do {                                                                             \
         uint64_t nx0, ny0, nx1, ny1;                                                 \
-        B2_MSG4_ARRIVED(mx0, my0, mx1, my1);                                         \
         B2_MSG4_REQUEST(NCOL, NDIA, nx0, ny0, nx1, ny1);                             \
-        B2_ROUND4_BODY();                                                            \
+        B2_G4(my0, 0x93, 0x39, 0x4E, mx1, false);                                    \
+        B2_MSG4_ARRIVED(nx0, ny0, nx1, ny1);                                         \
+        B2_G4(my1, 0x39, 0x93, 0x4E, nx0, false);                                    \
         mx0 = nx0; my0 = ny0; mx1 = nx1; my1 = ny1;                                  \
     } while (0)
-// the twelve rounds (sigma of rounds 10 and 11 = sigma of rounds 0 and 1)
+// the twelve rounds (sigma of rounds 10 and 11 = sigma of rounds 0 and 1); expects a, b, c, d, sh (= 8 j) and msg in scope
 #define B2_ROUNDS4()                                                                 \
     do {                                                                             \
         const uint32_t mbase = (uint32_t)(uintptr_t)(msg);                           \
+        const uint32_t shd = (sh + 24u) & 31u;          /* 8 * ((j + 3) & 3): lane j runs diagonal j - 1 */ \
         uint64_t mx0, my0, mx1, my1;                                                 \
+        uint64_t an = a;                                                             \
         B2_MSG4_REQUEST(0x76543210u, 0xfedcba98u, mx0, my0, mx1, my1);               \
+        B2_MSG4_ARRIVED(mx0, my0, mx1, my1);                                         \
+        an = b2_add64_early(a, mx0);                                                 \
         B2_ROUND4_NEXT(0x6df984aeu, 0x357b20c1u); B2_ROUND4_NEXT(0xdf250c8bu, 0x491763eau); B2_ROUND4_NEXT(0xebcd1397u, 0x8f04a562u); \
         B2_ROUND4_NEXT(0xfa427509u, 0xd386cb1eu); B2_ROUND4_NEXT(0x38b0a6c2u, 0x91ef57d4u); B2_ROUND4_NEXT(0xa4def15cu, 0xb8293670u); \
         B2_ROUND4_NEXT(0x931ce7bdu, 0xa2684f05u); B2_ROUND4_NEXT(0x803b9ef6u, 0x5a417d2cu); B2_ROUND4_NEXT(0x5167482au, 0x0dc3e9bfu); \
         B2_ROUND4_NEXT(0x76543210u, 0xfedcba98u); B2_ROUND4_NEXT(0x6df984aeu, 0x357b20c1u);                                           \
-        B2_MSG4_ARRIVED(mx0, my0, mx1, my1);                                         \
-        B2_ROUND4_BODY();                                                            \
+        B2_G4(my0, 0x93, 0x39, 0x4E, mx1, false);                                    \
+        B2_G4(my1, 0x39, 0x93, 0x4E, 0ull, true);                                    \
+        a = an;                                          /* (back in its column) */  \
     } while (0)
 
 // single-block BLAKE2b-512 of the 128-byte message msg[0..16) (LDS), computed by the 4 lanes j = 0..3 of a quad (all four must

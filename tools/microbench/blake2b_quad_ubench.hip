@@ -1,16 +1,14 @@
 // blake2b_quad_ubench.hip -- what bounds a narrow Merkle level: four lanes per BLAKE2b compression in a LONE wave (dev tool, round 6).
 // One workgroup of 256 threads per CU-sized grid slot, i.e. one wave per SIMD, each wave running REPS compressions back to back
 // (the digest of one feeds a word of the next message, like the levels of a tree), timed with s_memtime (shader cycles).
-//   library  : csrc/merkle.cuh blake2b_node_4lane -- the message word index derived from the packed sigma constants at every read
-//              (here the message does not move, so the compiler hoists that arithmetic out of the loop; in the tree kernels it
-//              is paid per level: 117 VALU + 40 SALU of ~890 issue slots)
-//   quad     : the experiment of round 6, kept in this file only -- 40 per-lane LDS addresses computed once per kernel, the words
-//              of a round requested one round ahead (pinned with sched_barrier), a + b + x computed as (a + x) + b, and the quad
-//              rotating a, c, d instead of b, c, d between the column and the diagonal step (b is the last value a G produces:
-//              no DPP move then stands between one G and the next).  Bit-identical; see profiles/r06/blake2b_quad_ubench.txt
-//              for what it did and did not buy.
+//   before   : the function as the library had it until the last session of round 6 (kept here, macros B2O_*): b, c, d rotate between
+//              the column and the diagonal step; hipcc computes a + b + x as (b + x) + a and adds a freshly rotated d to c in two adds
+//   library  : csrc/merkle.cuh blake2b_node_4lane as it is now: b stays in its lane, the early add of the a-chain an asm statement,
+//              rotated words put together as vectors
 // and the dependent-issue cost of the instruction kinds a compression is made of (a chain of N dependent instructions of one kind
-// in a lone wave, and the same with two independent chains interleaved):
+// in a lone wave, and the same with two independent chains interleaved).  profiles/r06/blake2b_quad_ubench.txt has the numbers of every
+// intermediate form (the experiment file of the first session, fixed message slots, opaque asm; this session's asm adds, vector
+// rotations, chain cut) -- `git log -- tools/microbench/blake2b_quad_ubench.hip` has their sources.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I stark-anatomy_amd/csrc -o tools/microbench/blake2b_quad_ubench tools/microbench/blake2b_quad_ubench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -22,88 +20,76 @@ using namespace sc;
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-// ---- the experiment (not in the library)
-// Where lane j of the quad that hashes node n finds its message words: the LDS byte offsets, from the start of a lin array, of the
-// 40 words it consumes (rounds 0..9 -- 10 and 11 repeat 0 and 1 -- each: column step x, y, diagonal step x, y).  A lane hashes the
-// same node number on every level of a climb and the sigma schedule does not depend on the data, so these are computed ONCE per
-// kernel: a read is then `ds_read_b64 v, a[k]` and nothing else (the library's B2_ROUND4 derives the word index from the packed sigma
-// constants for every read: 117 VALU + 40 SALU of the ~890 issue slots of a compression).
-struct QuadWords { uint32_t a[40]; };
-__device__ __forceinline__ void quad_words(uint32_t n, uint32_t j, QuadWords& W) {
-    constexpr uint32_t COL[10] = {0x76543210u, 0x6df984aeu, 0xdf250c8bu, 0xebcd1397u, 0xfa427509u, 0x38b0a6c2u, 0xa4def15cu, 0x931ce7bdu, 0x803b9ef6u, 0x5167482au};
-    constexpr uint32_t DIA[10] = {0xfedcba98u, 0x357b20c1u, 0x491763eau, 0x8f04a562u, 0xd386cb1eu, 0x91ef57d4u, 0xb8293670u, 0xa2684f05u, 0x5a417d2cu, 0x0dc3e9bfu};
-    const uint32_t sh = 8u * j, shd = 8u * ((j + 3u) & 3u), base = 17u * 8u * n;     // (lane j runs diagonal j - 1: see blake2b_quad)
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t bc = (COL[r] >> sh) & 0xFFu, bd = (DIA[r] >> shd) & 0xFFu;
-        W.a[4 * r + 0] = base + 8u * (bc & 15u);
-        W.a[4 * r + 1] = base + 8u * (bc >> 4);
-        W.a[4 * r + 2] = base + 8u * (bd & 15u);
-        W.a[4 * r + 3] = base + 8u * (bd >> 4);
-    }
-}
+// ---- the function before this round's last session (not in the library any more)
+#define B2O_G4(x, y)                      \
+    do {                                 \
+        a = a + b + (x);                 \
+        d = rotr64(d ^ a, 32);           \
+        c = c + d;                       \
+        b = rotr64(b ^ c, 24);           \
+        a = a + b + (y);                 \
+        d = rotr64(d ^ a, 16);           \
+        c = c + d;                       \
+        b = rotr64(b ^ c, 63);           \
+    } while (0)
 
-// Single-block BLAKE2b-512 by the four lanes of a quad, the message found through QuadWords (`lin`: the lin array).  Lane j returns
-// digest words j (h_lo) and 4 + j (h_hi).  The chain is what is cut here: a + b + x is computed as (a + x) + b (a is final five
-// steps before b), and between the column and the diagonal step the quad rotates a, c and d -- b, the LAST value a G produces,
-// stays where it is (lane L then runs diagonal L - 1; quad_words accounts for it): 18 dependent instructions per G instead of 22.
-// The four words of a round are requested one round ahead and the request is pinned where it stands (sched_barrier).
-#ifndef B2_OPAQUE_ASM
-#define B2_OPAQUE_ASM 0
-#endif
-#if B2_OPAQUE_ASM
-#define B2_OPAQUE(v) asm("" : "+v"(v))      // keeps (a + x) apart from + b, at the price of register-pair copies
-#else
-#define B2_OPAQUE(v) ((void)0)              // hipcc then sinks (a + x) back in front of + b
-#endif
-template <uint32_t SWEEP = 0>
-__device__ __forceinline__ void blake2b_quad(const uint64_t* lin, const QuadWords& W, uint32_t len, uint32_t j, uint64_t& h_lo, uint64_t& h_hi) {
+// The message words of a round -- two per G, per-lane addresses from the packed sigma constants -- are REQUESTED from LDS one round
+// ahead and waited for at the top of their round.  Written as loads in C++ the compiler sinks them to their first use (register
+// pressure), and every round then exposes an LDS round trip on the dependent chain of the compression -- which is all a narrow
+// level's time is made of; so the four ds_read_b64 are one asm statement (the hardware counts them in lgkmcnt like the compiler's
+// own: its waits only become stricter), and the wait is an asm statement the words pass THROUGH, so nothing that uses them can
+// move above it.  msg must be an LDS address (the low half of its flat address is the LDS offset).
+#define B2O_MSG4_REQUEST(COL, DIA, X0, Y0, X1, Y1)                                    \
+    do {                                                                             \
+        const uint32_t bc_ = ((uint32_t)(COL) >> sh) & 0xFFu, bd_ = ((uint32_t)(DIA) >> sh) & 0xFFu; \
+        const uint32_t a0_ = mbase + ((bc_ & 15u) << 3), a1_ = mbase + ((bc_ >> 4) << 3), a2_ = mbase + ((bd_ & 15u) << 3), a3_ = mbase + ((bd_ >> 4) << 3); \
+        /* (`a` passes through the request and `b` through the wait: the round's arithmetic starts with a and ends with b, so  */ \
+        /* the compiler can neither move a round's arithmetic above the request nor the wait above the previous round's)        */ \
+        asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %6\n\tds_read_b64 %2, %7\n\tds_read_b64 %3, %8"           \
+                     : "=&v"(X0), "=&v"(Y0), "=&v"(X1), "=&v"(Y1), "+v"(a) : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory"); \
+    } while (0)
+#define B2O_MSG4_ARRIVED(X0, Y0, X1, Y1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(Y0), "+v"(X1), "+v"(Y1), "+v"(b))
+#define B2O_ROUND4_BODY()                                                             \
+    do {                                                                             \
+        B2O_G4(mx0, my0);                                                             \
+        b = quad_perm64<0x39>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x93>(d); \
+        B2O_G4(mx1, my1);                                                             \
+        b = quad_perm64<0x93>(b); c = quad_perm64<0x4E>(c); d = quad_perm64<0x39>(d); \
+    } while (0)
+// one round, given the NEXT round's sigma constants
+#define B2O_ROUND4_NEXT(NCOL, NDIA)                                                   \
+    do {                                                                             \
+        uint64_t nx0, ny0, nx1, ny1;                                                 \
+        B2O_MSG4_ARRIVED(mx0, my0, mx1, my1);                                         \
+        B2O_MSG4_REQUEST(NCOL, NDIA, nx0, ny0, nx1, ny1);                             \
+        B2O_ROUND4_BODY();                                                            \
+        mx0 = nx0; my0 = ny0; mx1 = nx1; my1 = ny1;                                  \
+    } while (0)
+// the twelve rounds (sigma of rounds 10 and 11 = sigma of rounds 0 and 1)
+#define B2O_ROUNDS4()                                                                 \
+    do {                                                                             \
+        const uint32_t mbase = (uint32_t)(uintptr_t)(msg);                           \
+        uint64_t mx0, my0, mx1, my1;                                                 \
+        B2O_MSG4_REQUEST(0x76543210u, 0xfedcba98u, mx0, my0, mx1, my1);               \
+        B2O_ROUND4_NEXT(0x6df984aeu, 0x357b20c1u); B2O_ROUND4_NEXT(0xdf250c8bu, 0x491763eau); B2O_ROUND4_NEXT(0xebcd1397u, 0x8f04a562u); \
+        B2O_ROUND4_NEXT(0xfa427509u, 0xd386cb1eu); B2O_ROUND4_NEXT(0x38b0a6c2u, 0x91ef57d4u); B2O_ROUND4_NEXT(0xa4def15cu, 0xb8293670u); \
+        B2O_ROUND4_NEXT(0x931ce7bdu, 0xa2684f05u); B2O_ROUND4_NEXT(0x803b9ef6u, 0x5a417d2cu); B2O_ROUND4_NEXT(0x5167482au, 0x0dc3e9bfu); \
+        B2O_ROUND4_NEXT(0x76543210u, 0xfedcba98u); B2O_ROUND4_NEXT(0x6df984aeu, 0x357b20c1u);                                           \
+        B2O_MSG4_ARRIVED(mx0, my0, mx1, my1);                                         \
+        B2O_ROUND4_BODY();                                                            \
+    } while (0)
+
+__device__ __forceinline__ void blake2b_node_4lane_before(const uint64_t* msg, uint32_t j, uint64_t& h_lo, uint64_t& h_hi) {
+    const uint32_t sh = 8u * j;
     const uint64_t iv_a = B2_IV[j], iv_b = B2_IV[4 + j];
     const uint64_t h0 = (j == 0) ? (iv_a ^ 0x01010040ull) : iv_a;
     uint64_t a = h0, b = iv_b, c = iv_a, d = iv_b;
-    if (j == 0) d ^= (uint64_t)len;   // t0 = message length
-    if (j == 2) d = ~d;               // final block
-    const char* base = reinterpret_cast<const char*>(lin) + SWEEP;
-#define B2_W(k) (*reinterpret_cast<const uint64_t*>(base + W.a[k]))
-    // one G on (a, b, c, d) with `an` = a + x already formed; leaves `an` = (a moved by PA) + xnext, c and d moved by PC / PD
-#define B2_GQ(y, PA, PC, PD, xnext)                                \
-    do {                                                           \
-        a = an + b;                                                \
-        d = rotr64(d ^ a, 32);                                     \
-        c = c + d;                                                 \
-        b = rotr64(b ^ c, 24);                                     \
-        uint64_t ay = a + (y);                                     \
-        B2_OPAQUE(ay);                                             \
-        a = ay + b;                                                \
-        d = rotr64(d ^ a, 16);                                     \
-        an = quad_perm64<PA>(a) + (xnext);                         \
-        B2_OPAQUE(an);                                             \
-        c = c + d;                                                 \
-        b = rotr64(b ^ c, 63);                                     \
-        d = quad_perm64<PD>(d);                                    \
-        c = quad_perm64<PC>(c);                                    \
-    } while (0)
-    uint64_t x0 = B2_W(0), x1 = B2_W(1), x2 = B2_W(2), x3 = B2_W(3);
-    uint64_t an = a + x0;
-    // column step in lane j = column j; then a comes from lane j - 1, c from j + 1, d from j + 2 (frame of the diagonal step: lane L
-    // holds a[L-1], b[L], c[L+1], d[L+2] = diagonal L - 1); after it a from lane j + 1, c from j - 1, d from j + 2 (columns again)
-#define B2_ROUNDQ(next, last)                                                        \
-    do {                                                                             \
-        const uint64_t y0 = B2_W(4 * (next) + 0), y1 = B2_W(4 * (next) + 1), y2 = B2_W(4 * (next) + 2), y3 = B2_W(4 * (next) + 3); \
-        __builtin_amdgcn_sched_barrier(0);                                           \
-        B2_GQ(x1, 0x93, 0x39, 0x4E, x2);                                             \
-        B2_GQ(x3, 0x39, 0x93, 0x4E, (last) ? 0ull : y0);                             \
-        x1 = y1; x2 = y2; x3 = y3;                                                   \
-    } while (0)
-    B2_ROUNDQ(1, false); B2_ROUNDQ(2, false); B2_ROUNDQ(3, false); B2_ROUNDQ(4, false); B2_ROUNDQ(5, false); B2_ROUNDQ(6, false);
-    B2_ROUNDQ(7, false); B2_ROUNDQ(8, false); B2_ROUNDQ(9, false); B2_ROUNDQ(0, false); B2_ROUNDQ(1, false); B2_ROUNDQ(1, true);     // (the last prefetch is not used)
-#undef B2_ROUNDQ
-#undef B2_GQ
-#undef B2_W
-    h_lo = h0 ^ an ^ c;               // (after the last G `an` is a itself, back in its column)
+    if (j == 0) d ^= 128ull;
+    if (j == 2) d = ~d;
+    B2O_ROUNDS4();
+    h_lo = h0 ^ a ^ c;
     h_hi = iv_b ^ b ^ d;
 }
-
 
 constexpr int REPS = 64;
 
@@ -113,13 +99,11 @@ __global__ void __launch_bounds__(256) hash_kernel(const uint64_t* in, uint64_t*
     const uint32_t t = threadIdx.x, n = t >> 2, j = t & 3u;
     for (uint32_t i = t; i < 64 * 17; i += 256) lin[i] = in[i];
     __syncthreads();
-    QuadWords W;
-    quad_words(n, j, W);
     uint64_t lo = 0, hi = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < REPS; ++r) {
-        if (VARIANT == 0) blake2b_node_4lane(lin + 17u * n, j, lo, hi);
-        else blake2b_quad<0>(lin, W, 128u, j, lo, hi);
+        if (VARIANT == 0) blake2b_node_4lane_before(lin + 17u * n, j, lo, hi);
+        else blake2b_node_4lane(lin + 17u * n, j, lo, hi);
         lin[17u * n + j] = lo;                        // the digest goes back into the message (own quad's slot only)
         lin[17u * n + 4u + j] = hi;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -173,18 +157,18 @@ int main() {
         for (int rep = 0; rep < 3; ++rep) {
             if (variant == 0) hipLaunchKernelGGL(hash_kernel<0>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, d_ticks);
             else hipLaunchKernelGGL(hash_kernel<1>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, d_ticks);
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
         }
-        hipMemcpy(tk.data(), d_ticks, tk.size() * 8, hipMemcpyDeviceToHost);
-        hipMemcpy(o.data(), d_out, o.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(tk.data(), d_ticks, tk.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(o.data(), d_out, o.size() * 8, hipMemcpyDeviceToHost);
         return mean_ticks(tk) / REPS;
     };
     const double c0 = run_hash(0, o0), c1 = run_hash(1, o1);
     size_t bad = 0;
     for (size_t i = 0; i < o0.size(); ++i) bad += o0[i] != o1[i];
     printf("four lanes per compression, one wave per SIMD, %d compressions back to back (s_memtime = shader cycles):\n", REPS);
-    printf("  library (csrc/merkle.cuh blake2b_node_4lane)        : %7.1f cycles per compression\n", c0);
-    printf("  quad    (addresses once, prefetch, chain cut; opaque asm %d) : %7.1f cycles per compression     results identical: %s\n", B2_OPAQUE_ASM, c1, bad ? "NO" : "yes");
+    printf("  before  (b, c, d rotate; hipcc's association of the adds)               : %7.1f cycles per compression\n", c0);
+    printf("  library (csrc/merkle.cuh blake2b_node_4lane: b stays, early asm add, vector rotations) : %7.1f cycles per compression     results identical: %s\n", c1, bad ? "NO" : "yes");
     const char* names[5] = {"v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "v_mov_b32_dpp", "v_xor_b32_dpp"};
     printf("dependent chains in a lone wave, cycles per instruction (one chain | two independent chains interleaved, per instruction):\n");
     auto run_chain = [&](auto kernel) -> double {
