@@ -113,6 +113,34 @@ __global__ void __launch_bounds__(256) hash_kernel(const uint64_t* in, uint64_t*
     if ((t & 63u) == 0) ticks[blockIdx.x * 4 + (t >> 6)] = t1 - t0;
 }
 
+// a climb as the tree kernels run it: merkle_level_4lane (message addresses per level, the level's stores to LDS and to the tree)
+// and a workgroup barrier per level, 128 digests -> 1, CLIMBS times; cycles per LEVEL
+constexpr int CLIMBS = 16;
+template <int MODE> __global__ void __launch_bounds__(256) climb_kernel(const uint64_t* in, uint64_t* tree, unsigned long long* ticks) {
+    __shared__ uint64_t linA[64 * 17], linB[32 * 17];
+    const uint32_t t = threadIdx.x;
+    uint64_t* out = tree + (size_t)blockIdx.x * 8 * 128;
+    unsigned long long total = 0;
+    for (int rep = 0; rep < CLIMBS; ++rep) {
+        for (uint32_t i = t; i < 64 * 17; i += 256) linA[i] = in[i] + rep;
+        __syncthreads();
+        uint64_t* src = linA; uint64_t* dst = linB; uint64_t* o = out;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        for (uint32_t w = 128; w > 1; w >>= 1) {
+            if (MODE == 1) {          // timing only: no stores of the level to the tree
+                const uint32_t n = t >> 2, j = t & 3u;
+                if (n < (w >> 1)) { uint64_t lo, hi; blake2b_node_4lane(src + 17u * n, j, lo, hi); dst[lin_off(n) + j] = lo; dst[lin_off(n) + 4u + j] = hi; }
+            } else merkle_level_4lane(src, dst, o, w >> 1, t);
+            if (MODE == 2 && (w >> 1) <= 16) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+            else __syncthreads();
+            o += 8 * (w >> 1);
+            uint64_t* x = src; src = dst; dst = x;
+        }
+        total += __builtin_amdgcn_s_memtime() - t0;
+    }
+    if ((t & 63u) == 0) ticks[blockIdx.x * 4 + (t >> 6)] = total;
+}
+
 // dependent chains: KIND 0 v_xor_b32, 1 v_alignbit_b32, 2 v_lshl_add_u64, 3 v_mov_b32_dpp quad_perm, 4 v_xor_b32_dpp; CHAINS independent chains interleaved
 constexpr int CHAIN = 1024;
 template <int KIND, int CHAINS>
@@ -169,6 +197,17 @@ int main() {
     printf("four lanes per compression, one wave per SIMD, %d compressions back to back (s_memtime = shader cycles):\n", REPS);
     printf("  before  (b, c, d rotate; hipcc's association of the adds)               : %7.1f cycles per compression\n", c0);
     printf("  library (csrc/merkle.cuh blake2b_node_4lane: b stays, early asm add, vector rotations) : %7.1f cycles per compression     results identical: %s\n", c1, bad ? "NO" : "yes");
+    {
+        uint64_t* d_tree; CHK(hipMalloc(&d_tree, (size_t)blocks * 8 * 128 * 8));
+        auto climb = [&](auto kernel) -> double {
+            for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_in, d_tree, d_ticks); (void)hipDeviceSynchronize(); }
+            (void)hipMemcpy(tk.data(), d_ticks, tk.size() * 8, hipMemcpyDeviceToHost);
+            double s0 = 0; for (int b = 0; b < blocks; ++b) s0 += (double)tk[b * 4];
+            return s0 / blocks / CLIMBS / 7;
+        };
+        const double l0 = climb(climb_kernel<0>), l1 = climb(climb_kernel<1>), l2 = climb(climb_kernel<2>);
+        printf("  a climb of 7 levels (128 digests -> 1) by merkle_level_4lane + a workgroup barrier per level: %7.1f cycles per level;  without the level's stores to the tree %7.1f;  wave-level sync from 16 parents down %7.1f\n", l0, l1, l2);
+    }
     const char* names[5] = {"v_xor_b32", "v_alignbit_b32", "v_lshl_add_u64", "v_mov_b32_dpp", "v_xor_b32_dpp"};
     printf("dependent chains in a lone wave, cycles per instruction (one chain | two independent chains interleaved, per instruction):\n");
     auto run_chain = [&](auto kernel) -> double {
