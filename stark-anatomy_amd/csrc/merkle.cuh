@@ -10,6 +10,10 @@
 #ifndef SC_MERKLE_4LANE
 #define SC_MERKLE_4LANE 1      // narrow tree levels: four lanes per BLAKE2b compression (0: one lane per hash everywhere)
 #endif
+#ifndef SC_FOUR_LANE_FROM
+#define SC_FOUR_LANE_FROM 128    // merkle_subtree_kernel<*, FOUR_LANE>: the width (digests) from which the levels run four lanes per hash.  256 (the 128-parent
+                                 // level in two sweeps of 64 instead of one lane per hash) measured no better: the eight-level climb 23.1 us against 22.5, Fri.prove +-0
+#endif
 #include "field.cuh"
 
 namespace sc {
@@ -199,10 +203,11 @@ __device__ __forceinline__ void blake2b_node_4lane(const uint64_t* msg, uint32_t
 __device__ __forceinline__ uint32_t lin_off(uint32_t n) { return (n >> 1) * 17u + (n & 1u) * 8u; }
 
 // one level by the 4-lane path: `parents` nodes from the 2*parents digests in `src` (lin layout) into `dst` (lin layout) and to
-// the tree (`out`: the level's place in global memory).  Threads >= 4*parents idle as whole quads.
-__device__ __forceinline__ void merkle_level_4lane(const uint64_t* src, uint64_t* dst, uint64_t* __restrict__ out, uint32_t parents, uint32_t t) {
-    const uint32_t n = t >> 2, j = t & 3u;
-    if (n < parents) {
+// the tree (`out`: the level's place in global memory).  Threads >= 4*parents idle as whole quads; a level wider than the workgroup's
+// `quads` (threads / 4) is taken in sweeps of that many nodes.
+__device__ __forceinline__ void merkle_level_4lane(const uint64_t* src, uint64_t* dst, uint64_t* __restrict__ out, uint32_t parents, uint32_t t, uint32_t quads) {
+    const uint32_t j = t & 3u;
+    for (uint32_t n = t >> 2; n < parents; n += quads) {
         uint64_t lo, hi;
         blake2b_node_4lane(src + 17u * n, j, lo, hi);
         dst[lin_off(n) + j] = lo;
@@ -510,7 +515,8 @@ template <bool LEAVES, bool FOUR_LANE, bool FOLD = false>
 __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restrict__ elems, uint64_t* __restrict__ levels, uint64_t N, int lvl0, int nlev, const FoldIn fold = FoldIn()) {
     __shared__ uint4 cur[LEAVES ? 256 * 5 : 256 * 4];  // this level's digests of the subtree (16 KiB); before that, the leaf stage's 80 bytes per thread
     constexpr bool four_lane = FOUR_LANE && (SC_MERKLE_4LANE != 0);
-    __shared__ uint64_t linA[four_lane ? 64 * 17 : 1], linB[four_lane ? 32 * 17 : 1];   // 4-lane path: 128 resp. 64 digests in the lin layout
+    constexpr uint32_t FOUR_LANE_FROM = SC_FOUR_LANE_FROM;      // the width (digests) at which a latency-bound launch hands over to the four-lane form
+    __shared__ uint64_t linA[four_lane ? (SC_FOUR_LANE_FROM / 2) * 17 : 1], linB[four_lane ? (SC_FOUR_LANE_FROM / 4) * 17 : 1];   // 4-lane path: FOUR_LANE_FROM resp. half as many digests in the lin layout
     const uint32_t t = threadIdx.x;
     const uint64_t wg = blockIdx.x;
     auto level_off = [N](int l) -> uint64_t { return l == 0 ? 0 : 2 * N - (N >> (l - 1)); };
@@ -552,7 +558,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
                 cur[dig_slot(t, k)] = v;
             }
             if constexpr (four_lane) {
-                if (width == 128) {
+                if (width == FOUR_LANE_FROM) {
 #pragma unroll
                     for (uint32_t w = 0; w < 8; ++w) linA[lin_off(t) + w] = h[w];
                 }
@@ -565,7 +571,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         }
         if (l == nlev) return;
         if constexpr (four_lane) {
-            if (width == 128) break;                   // latency-bound launch: the remaining levels (<= 64 nodes) go four lanes per hash
+            if (width == FOUR_LANE_FROM) break;        // latency-bound launch: the remaining levels go four lanes per hash
         }
         width >>= 1;
         if (t < width) {
@@ -585,7 +591,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(const Fe* __restric
         uint64_t* dst = linB;
         for (++l; l <= nlev; ++l) {
             width >>= 1;
-            merkle_level_4lane(src, dst, levels + 8 * (level_off(lvl0 + l) + wg * width), width, t);
+            merkle_level_4lane(src, dst, levels + 8 * (level_off(lvl0 + l) + wg * width), width, t, 64u);
             __syncthreads();
             uint64_t* s = src; src = dst; dst = s;
         }
@@ -631,7 +637,7 @@ __global__ void __launch_bounds__(1024) merkle_tail_kernel(uint64_t* level, uint
     uint64_t* dst = linB;
     for (; w > 1; w >>= 1) {
         uint64_t* nxt = cur + 8 * w;
-        merkle_level_4lane(src, dst, nxt, (uint32_t)(w >> 1), threadIdx.x);
+        merkle_level_4lane(src, dst, nxt, (uint32_t)(w >> 1), threadIdx.x, 256u);
         __syncthreads();
         cur = nxt;
         uint64_t* s = src; src = dst; dst = s;
