@@ -333,8 +333,9 @@ int sc_fri_commit_dev(const void* d_codeword, uint64_t N, const uint64_t offset[
  * opened element and authentication path of the proof.  `extra_count` further (tree, device vector) pairs of N leaves -- FastStark's
  * committed codewords, fast_stark.py:154-175 -- are opened in the same launch at the sorted positions
  * {i, i + extra_shift, i + N/2, i + extra_shift + N/2 (mod N)} over the top-level indices i (written to extra_indices_out, 4 *
- * num_tests of them).  Openings per pair, in this order: codeword j of the commit phase (j < rounds): [a (num_tests), b = a + half
- * (num_tests)] if j < rounds - 1, then [c = the previous round's a (num_tests)] if j > 0; every further pair: the sorted positions.
+ * num_tests of them).  Openings per pair, in this order: codeword j of the commit phase: [a (num_tests), b = a + half (num_tests)] if
+ * j < rounds - 1 -- the c positions of the round before (= that round's a) are this codeword's a or b, whichever half they lie in, and
+ * are opened once --, the last codeword [c (num_tests)]; every further pair: the sorted positions.
  * `answers` (answers_bytes >= the sum below) = [opened elements, 16 bytes each, padded to a multiple of 256 bytes][paths, 64 * log2
  * N_pair bytes per opening][the positions, u64 each], pairs concatenated.  A buffer of sc_host_alloc is written by the kernel itself
  * across the bus (no staging copy); any other host pointer works through two copies.  Outputs of the commit phase as for

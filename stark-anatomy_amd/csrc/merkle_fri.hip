@@ -725,6 +725,9 @@ int sc_host_free(void* p) {
     return SC_OK;
 }
 
+// openings of codeword j of a commit phase of `rounds` codewords in sc_fri_prove_dev's answers: its own round's a and b; the c positions
+// of the round before are among them (c = that round's a, which is this round's a or b), except in the last codeword, which has no round of its own
+static inline uint64_t fri_openings_of_codeword(uint32_t j, uint32_t rounds, uint32_t s) { return j + 1 < rounds ? 2ull * s : (j > 0 ? (uint64_t)s : 0ull); }
 // Fri.prove (fri.py:115-130) in ONE call -- see include/starkcore.h.  The commit phase is sc_fri_commit_dev's; then, without
 // leaving the library: the last codeword comes to the host, the transcript [prior digests..., roots..., [last codeword]] is
 // pickled (csrc/proof_pickle.h) and hashed (SHAKE-256, ip.py:18-25), the top-level indices are sampled (fri.py:36-51, :122), the
@@ -766,7 +769,7 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     uint64_t total = 0;
     size_t path_bytes = 0;
     for (uint32_t j = 0; j < rounds; ++j) {
-        const uint64_t k = (j + 1 < rounds ? 2ull * s : 0) + (j > 0 ? s : 0);
+        const uint64_t k = fri_openings_of_codeword(j, rounds, s);
         total += k;
         path_bytes += k * 64 * (size_t)ilog2(N >> j);
     }
@@ -856,8 +859,11 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
             for (uint32_t t = 0; t < s; ++t) cur[t] %= half;
             for (uint32_t t = 0; t < s; ++t) idx[at++] = cur[t];
             for (uint32_t t = 0; t < s; ++t) idx[at++] = cur[t] + half;
+        } else if (j > 0) {
+            // (only the LAST codeword opens the c positions of the round before on their own: everywhere else c = prev[t] is this
+            // codeword's a[t] or b[t] -- prev[t] mod half resp. that + half -- and is opened once)
+            for (uint32_t t = 0; t < s; ++t) idx[at++] = prev[t];
         }
-        if (j > 0) for (uint32_t t = 0; t < s; ++t) idx[at++] = prev[t];
         prev = cur;
     }
     if (extra_count) {
@@ -896,7 +902,7 @@ int sc_fri_prove_dev(const void* d_codeword, uint64_t N, const uint64_t offset[2
     for (uint64_t t = 0; t < rounds + extra_count; ++t) {
         const bool own = t < rounds;
         const sc_merkle* tree = own ? trees_out[t] : extra_trees[t - rounds];
-        const uint64_t k = own ? ((t + 1 < rounds ? 2ull * s : 0) + (t > 0 ? s : 0)) : 4ull * s;
+        const uint64_t k = own ? fri_openings_of_codeword((uint32_t)t, rounds, s) : 4ull * s;
         if (!k) continue;
         QueryTree& T = Q.t[Q.count++];
         T.levels = tree->d_levels;

@@ -38,8 +38,9 @@
 // addresses in this process, nothing is copied into the description
 //   'Q' u32 s  u32 field  u32 k  | k x (u64 key_base, u32 depth) | u64 elems  u64 paths  u64 positions
 //                            every round of a query phase over k codewords: codeword j's openings lie in the three arrays in
-//                            the order [a (s), b (s)] if j < k - 1, then [c (s)] if j > 0 (elements 16 bytes, paths 64 depth_j,
-//                            positions u64), codeword after codeword; 4 s (k - 1) items, as k - 1 'R' ops would produce
+//                            the order [a (s), b (s)] if j < k - 1, [c (s)] for the last one (elements 16 bytes, paths 64 depth_j,
+//                            positions u64), codeword after codeword; the c of a round whose next codeword is not the last is that
+//                            codeword's a or b (the same position, opened once); 4 s (k - 1) items, as k - 1 'R' ops would produce
 //   'P' u32 k  u32 field  u64 key_base  u32 depth  u64 positions  u64 values  u64 paths
 //                            as 'O', positions u64
 #pragma once
@@ -277,19 +278,23 @@ struct ProofPickler {
             size_t eo[65], po[65];
             eo[0] = po[0] = 0;
             for (uint32_t j = 0; j < nk; ++j) {
-                const size_t cnt = (j + 1 < nk ? 2ull * s_ : 0) + (j > 0 ? s_ : 0);
+                const size_t cnt = j + 1 < nk ? 2ull * s_ : (j > 0 ? s_ : 0);
                 eo[j + 1] = eo[j] + cnt;
                 po[j + 1] = po[j] + cnt * 64 * depth[j];
             }
             for (uint32_t i = 0; i + 1 < nk; ++i) {
-                const size_t c_at = i + 2 < nk ? 2ull * s_ : 0;
-                const size_t a0 = eo[i], b0 = eo[i] + s_, c0 = eo[i + 1] + c_at;
+                // c of round i = position a of round i in codeword i + 1: opened there as that codeword's a (slot t) or b (slot s + t) --
+                // whichever half it lies in -- unless codeword i + 1 is the last one, which holds nothing but these
+                const size_t a0 = eo[i], b0 = eo[i] + s_;
+                const uint64_t next_half = depth[i + 1] ? 1ull << (depth[i + 1] - 1) : 0;
+                auto c_slot = [&](uint32_t t) -> size_t { return i + 2 < nk ? (pos[a0 + t] < next_half ? t : s_ + t) : t; };
                 for (uint32_t t = 0; t < s_; ++t) {
+                    const size_t c0t = eo[i + 1] + c_slot(t);
                     item_begin(*L);
                     boundary();                                // save(tuple)
                     save_element(f, base[i] | (uint32_t)pos[a0 + t], el + 16 * (a0 + t));
                     save_element(f, base[i] | (uint32_t)pos[b0 + t], el + 16 * (b0 + t));
-                    save_element(f, base[i + 1] | (uint32_t)pos[c0 + t], el + 16 * (c0 + t));
+                    save_element(f, base[i + 1] | (uint32_t)pos[c0t], el + 16 * c0t);
                     put(0x87); memoize();                      // TUPLE3 MEMOIZE
                     item_end(*L);
                 }
@@ -297,7 +302,7 @@ struct ProofPickler {
                 for (uint32_t t = 0; t < s_; ++t) {
                     item_begin(*L); save_path(paths + po[i] + (size_t)t * 64 * dc, (uint32_t)dc); item_end(*L);
                     item_begin(*L); save_path(paths + po[i] + (size_t)(s_ + t) * 64 * dc, (uint32_t)dc); item_end(*L);
-                    item_begin(*L); save_path(paths + po[i + 1] + (c_at + t) * 64 * dn, (uint32_t)dn); item_end(*L);
+                    item_begin(*L); save_path(paths + po[i + 1] + c_slot(t) * 64 * dn, (uint32_t)dn); item_end(*L);
                 }
             }
             return p;

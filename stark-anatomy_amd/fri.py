@@ -242,8 +242,9 @@ class Fri:
         last_raw = ctypes.create_string_buffer(16 * n_last)
         top = (ctypes.c_uint64 * s)()
         quad = (ctypes.c_uint64 * (4 * s))()
-        # openings per pair (see include/starkcore.h): codeword j: 2 s of its own round (j < rounds - 1) + s for the round before (j > 0)
-        counts = [(2 * s if j + 1 < rounds else 0) + (s if j > 0 else 0) for j in range(rounds)] + [4 * s] * ne
+        # openings per pair (see include/starkcore.h): codeword j: the 2 s of its own round (j < rounds - 1) -- the c positions of the round
+        # before are among them -- and the last codeword the s of the round before
+        counts = [2 * s if j + 1 < rounds else (s if j > 0 else 0) for j in range(rounds)] + [4 * s] * ne
         depths = [(N >> j).bit_length() - 1 for j in range(rounds)] + [N.bit_length() - 1] * ne
         total = sum(counts)
         el_bytes = (16 * total + 255) & ~255

@@ -204,8 +204,9 @@ class FriQueryPhase:
     """every round of the query phase at once (fri.py:124-128), as sc_fri_prove_dev answered it: views of one pinned buffer, cut
     into rounds only when somebody serializes or reads the stream.
     holders[j]: codeword j's entry holder; counts / depths: openings and path depth per codeword, in the buffer's order ([a, b] of
-    its own round, then [c] of the round before); elems / paths: uint8 views of the opened residues (16 bytes each) and of the
-    authentication paths of those codewords, codeword after codeword; positions: the opened indices (uint64 view), likewise."""
+    its own round; the last codeword: [c] of the round before -- everywhere else that c is the codeword's own a or b, opened once);
+    elems / paths: uint8 views of the opened residues (16 bytes each) and of the authentication paths of those codewords, codeword
+    after codeword; positions: the opened indices (uint64 view), likewise."""
 
     def __init__(self, holders, s, counts, depths, elems, paths, positions):
         self.holders, self.s, self.counts, self.depths = holders, s, counts, depths
@@ -226,10 +227,15 @@ class FriQueryPhase:
             k = len(self.holders)
             self._rounds = []
             for i in range(k - 1):
-                c_at = 2 * s if i + 2 < k else 0
-                self._rounds.append(FriRound(self.holders[i], self.holders[i + 1], where[i][:s], where[i][s:2 * s], where[i + 1][c_at:c_at + s],
-                                             values[i][:16 * s], values[i][16 * s:32 * s], values[i + 1][16 * c_at:16 * (c_at + s)],
-                                             paths[i][:s], paths[i][s:2 * s], paths[i + 1][c_at:c_at + s]))
+                if i + 2 < k:
+                    # c = this round's a, in the next codeword: that codeword's own a (slot t) or b (slot s + t), whichever half it lies in
+                    slot = np.arange(s) + np.where(where[i][:s] < np.uint64(1 << (self.depths[i + 1] - 1)), 0, s)
+                else:
+                    slot = np.arange(s)
+                c_values = np.ascontiguousarray(values[i + 1].reshape(-1, 16)[slot]).reshape(-1)
+                self._rounds.append(FriRound(self.holders[i], self.holders[i + 1], where[i][:s], where[i][s:2 * s], where[i + 1][slot],
+                                             values[i][:16 * s], values[i][16 * s:32 * s], c_values,
+                                             paths[i][:s], paths[i][s:2 * s], paths[i + 1][slot]))
         return self._rounds
 
     payload_bytes = property(lambda self: int(self.elems.nbytes + self.paths.nbytes))

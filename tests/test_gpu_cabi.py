@@ -1053,8 +1053,9 @@ def test_fri_prove_in_one_call_through_the_cabi(sc, logN, s, prior_count):
         if j + 1 < rounds:
             idx = [i % half for i in idx]
             here += idx + [i + half for i in idx]
-        if j > 0:
-            here += prev
+            assert j == 0 or all(c in (a, a + half) for c, a in zip(prev, idx))      # (the c of the round before is opened as this a or b)
+        elif j > 0:
+            here += prev                                                          # the last codeword: nothing but the c of the round before
         prev = idx
         positions.append(here)
     extra_shift = 4

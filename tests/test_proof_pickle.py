@@ -193,8 +193,8 @@ def test_bytes_objects_of_a_frame_or_more_go_out_unframed(size, around):
 @pytest.mark.parametrize("seed", range(4))
 def test_query_phase_segment_from_the_one_call_provers_buffer(seed):
     """proof_objects.FriQueryPhase + DetachedEntries: the whole query phase described from ONE buffer in sc_fri_prove_dev's layout
-    (opened elements padded to 256 bytes, paths, positions; per codeword [a, b] of its own round then [c] of the round before) must
-    pickle like the per-round segments and like the objects -- including the sharing between a round's c entries and the next
+    (opened elements padded to 256 bytes, paths, positions; per codeword [a, b] of its own round -- the c of the round before is one of
+    them and is opened once -- and [c] for the last codeword) must pickle like the per-round segments and like the objects -- including the sharing between a round's c entries and the next
     round's a / b entries and the last codeword (pickle memoises by identity, fri.py:91, :104-105)."""
     rng = random.Random(100 + seed)
     field = MAIN
@@ -202,7 +202,7 @@ def test_query_phase_segment_from_the_one_call_provers_buffer(seed):
     sizes = [(128 if s > 20 else 16) << (rounds - 1 - r) for r in range(rounds)]
     cws = [FakeCodeword(n, field, rng) for n in sizes]
     top = rng.sample(range(sizes[0] // 2), s)
-    counts = [(2 * s if j + 1 < rounds else 0) + (s if j > 0 else 0) for j in range(rounds)]
+    counts = [2 * s if j + 1 < rounds else (s if j > 0 else 0) for j in range(rounds)]
     depths = [n.bit_length() - 1 for n in sizes]
     positions, idx, prev = [], list(top), None
     for j in range(rounds):
@@ -211,7 +211,7 @@ def test_query_phase_segment_from_the_one_call_provers_buffer(seed):
         if j + 1 < rounds:
             idx = [i % half for i in idx]
             here += idx + [i + half for i in idx]
-        if j > 0:
+        elif j > 0:
             here += prev
         prev = idx
         positions.append(here)
@@ -241,9 +241,11 @@ def test_query_phase_segment_from_the_one_call_provers_buffer(seed):
             paths = [np.frombuffer(raw, dtype=np.uint8).reshape(c, 64 * d) for raw, c, d in zip(path_arrays, counts, depths)]
             for i in range(rounds - 1):
                 a, half = positions[i][:s], sizes[i] // 2
-                c_at = 2 * s if i + 2 < rounds else 0
+                # where the next codeword's buffer holds the path of c = a: among its own a / b, or (last codeword) on its own
+                slot = [t + (0 if a[t] < sizes[i + 1] // 2 else s) for t in range(s)] if i + 2 < rounds else list(range(s))
+                assert [positions[i + 1][q] for q in slot] == a
                 lazy.add(po_.FriRound(cws[i], cws[i + 1], a, [x + half for x in a], a, cws[i].raw(a), cws[i].raw([x + half for x in a]), cws[i + 1].raw(a),
-                                      paths[i][:s], paths[i][s:2 * s], paths[i + 1][c_at:c_at + s]))
+                                      paths[i][:s], paths[i][s:2 * s], paths[i + 1][slot]))
         return ps
     rng_state = rng.getstate()
     one = stream("one buffer")

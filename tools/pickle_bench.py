@@ -36,7 +36,7 @@ def residues(count):
 
 
 top = rng.sample(range(sizes[0] // 2), s)
-counts = [(2 * s if j + 1 < rounds else 0) + (s if j > 0 else 0) for j in range(rounds)]
+counts = [2 * s if j + 1 < rounds else (s if j > 0 else 0) for j in range(rounds)]
 depths = [n.bit_length() - 1 for n in sizes]
 positions, idx, prev = [], list(top), None
 for j in range(rounds):
@@ -44,7 +44,7 @@ for j in range(rounds):
     if j + 1 < rounds:
         idx = [i % half for i in idx]
         here += idx + [i + half for i in idx]
-    if j > 0:
+    elif j > 0:
         here += prev
     prev = idx
     positions.append(here)
