@@ -63,11 +63,14 @@ struct TailParams {
     uint64_t seq;
     int trace;            // workgroup 0 stamps its phases into host->stamps
     uint32_t spin_limit;  // polls before a wait gives up (TAIL_SPIN_LIMIT; tests shorten it)
+    uint64_t* alpha_bar;  // nullptr, or [TAIL_MAX_ROUNDS][8] words of FINE-GRAINED DEVICE memory the host writes the challenges to through the BAR
+                          // (lo, hi, then -- behind an sfence -- [2] = seq): every workgroup polls it there, no read crosses the bus
 };
 
 #if defined(__HIPCC__)
 
 __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld_system(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ Fe ld_fe_agent(const Fe* p) { return Fe{ld_agent(&p->lo), ld_agent(&p->hi)}; }
 __device__ __forceinline__ void st_fe_agent(Fe* p, Fe v) { st_agent(&p->lo, v.lo); st_agent(&p->hi, v.hi); }
@@ -243,7 +246,15 @@ __global__ void __launch_bounds__(256) fri_tail_kernel(const TailParams P) {
                 if (t == 0) P.host->root[r][8] = P.seq;
                 stamp(4);
                 if (!last_round) {
-                    if (t == 0) {
+                    if (t == 0 && P.alpha_bar) {
+                        const uint64_t* slot = P.alpha_bar + 8u * (r + 1);
+                        uint32_t spins = 0;
+                        while (ld_system(slot + 2) != P.seq) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > P.spin_limit) { s_abort = 1; break; }
+                        }
+                        if (!s_abort) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); s_alpha = Fe{ld_system(slot), ld_system(slot + 1)}; }
+                    } else if (t == 0) {
                         uint32_t spins = 0;
                         while (P.host->alpha[r + 1][2] != P.seq) {
                             __builtin_amdgcn_s_sleep(1);
@@ -274,7 +285,15 @@ __global__ void __launch_bounds__(256) fri_tail_kernel(const TailParams P) {
             alpha = s_alpha;
         } else {
             if (wg >= nwg_next) return;                                // no later round has work for this workgroup
-            if (t == 0) {
+            if (t == 0 && P.alpha_bar) {
+                const uint64_t* slot = P.alpha_bar + 8u * (r + 1);
+                uint32_t spins = 0;
+                while (ld_system(slot + 2) != P.seq) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > P.spin_limit || __hip_atomic_load(&ctl->abort[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; break; }
+                }
+                if (!s_abort) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); s_alpha = Fe{ld_system(slot), ld_system(slot + 1)}; }
+            } else if (t == 0) {
                 uint32_t spins = 0;
                 while (ld_agent(&ctl->alpha[r + 1][2]) != P.seq) {
                     __builtin_amdgcn_s_sleep(2);

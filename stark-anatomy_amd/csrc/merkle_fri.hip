@@ -5,6 +5,7 @@
 #include "fri_tail.cuh"
 #include "transcript.h"
 #include "proof_pickle.h"
+#include <immintrin.h>      // _mm_sfence: the challenge written through the BAR (write-combined) must reach the device before its flag
 
 // split-and-fold (code/fri.py:85) rewritten as
 //   out[i] = (a + b)/2 + (a - b) * c * w^-i,   a = in[i], b = in[i + N/2], c = alpha / (2 * offset)
@@ -440,6 +441,31 @@ int sc_pickle_proof(const void* ops, uint64_t ops_len, const void* moduli, uint3
 namespace {
 std::vector<TailCtl*> g_tail_ctl_free;
 std::vector<TailHost*> g_tail_host_free;
+// The challenges' way back to the persistent kernel.  With a large BAR the host writes them straight into a few words of fine-grained
+// DEVICE memory (one block per TailCtl) and every workgroup polls them there: the polling read of workgroup 0 across the bus, its two
+// reads of the challenge and the hand-on through device memory are saved (profiles/r06/prequeue_latency.txt measured the slot).
+// STARKCORE_FRI_TAIL_BAR=0 or no large BAR: the pinned word of TailHost, as before.
+std::map<TailCtl*, uint64_t*> g_tail_alpha_bar;
+uint64_t* tail_alpha_bar_of(TailCtl* ctl) {
+    static const int want = [] {
+        const char* e = getenv("STARKCORE_FRI_TAIL_BAR");
+        if (e && atoi(e) == 0) return 0;
+        int large_bar = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return large_bar ? 1 : 0;
+    }();
+    if (!want) return nullptr;
+    auto it = g_tail_alpha_bar.find(ctl);
+    if (it != g_tail_alpha_bar.end()) return it->second;
+    uint64_t* p = nullptr;
+    if (hipExtMallocWithFlags((void**)&p, 4096, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    g_tail_alpha_bar[ctl] = p;
+    return p;
+}
 uint64_t g_tail_seq = 0;
 uint64_t g_tail_launches = 0, g_tail_fallbacks = 0;     // sc_fri_tail_stats
 int tail_blocks_get(TailCtl** c, TailHost** h) {
@@ -486,6 +512,8 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
     memset((void*)&P, 0, sizeof P);
     P.in0 = cur; P.log_n0 = (uint32_t)ilog2(n0); P.rounds = R; P.alpha0 = alpha0; P.pw_lo = pw->lo; P.pw_hi = pw->hi;
     P.ctl = ctl; P.host = host; P.seq = ++g_tail_seq;
+    static_assert(TAIL_MAX_ROUNDS * 8 * sizeof(uint64_t) <= 4096, "the challenge block");
+    P.alpha_bar = tail_alpha_bar_of(ctl);
     static const bool tracing = getenv("STARKCORE_FRI_TIMING") != nullptr;
     P.trace = tracing ? 1 : 0;
     P.spin_limit = g.fri_tail_stall >= 0 ? (1u << 13) : TAIL_SPIN_LIMIT;
@@ -568,9 +596,18 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
         const Fe alpha = sample_field(digest, 32);
         alphas_out[2 * r] = alpha.lo; alphas_out[2 * r + 1] = alpha.hi;
         if (g.fri_tail_stall == (int)k) { aborted = true; break; }      // tests: the challenge never comes; the kernel's wait gives up
-        host->alpha[k + 1][0] = alpha.lo;
-        host->alpha[k + 1][1] = alpha.hi;
-        __atomic_store_n(&host->alpha[k + 1][2], P.seq, __ATOMIC_RELEASE);
+        if (P.alpha_bar) {
+            volatile uint64_t* slot = P.alpha_bar + 8u * (k + 1);
+            slot[0] = alpha.lo;
+            slot[1] = alpha.hi;
+            _mm_sfence();
+            slot[2] = P.seq;
+            _mm_sfence();
+        } else {
+            host->alpha[k + 1][0] = alpha.lo;
+            host->alpha[k + 1][1] = alpha.hi;
+            __atomic_store_n(&host->alpha[k + 1][2], P.seq, __ATOMIC_RELEASE);
+        }
         host_stamp();
     }
     if (aborted) {
