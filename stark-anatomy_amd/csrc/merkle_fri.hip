@@ -446,6 +446,7 @@ std::vector<TailHost*> g_tail_host_free;
 // reads of the challenge and the hand-on through device memory are saved (profiles/r06/prequeue_latency.txt measured the slot).
 // STARKCORE_FRI_TAIL_BAR=0 or no large BAR: the pinned word of TailHost, as before.
 std::map<TailCtl*, uint64_t*> g_tail_alpha_bar;
+bool g_tail_bar_gave_up = false;      // a kernel that waited for a challenge written through the BAR timed out (not a test's stall): the pinned word from then on
 uint64_t* tail_alpha_bar_of(TailCtl* ctl) {
     static const int want = [] {
         const char* e = getenv("STARKCORE_FRI_TAIL_BAR");
@@ -454,7 +455,7 @@ uint64_t* tail_alpha_bar_of(TailCtl* ctl) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         return large_bar ? 1 : 0;
     }();
-    if (!want) return nullptr;
+    if (!want || g_tail_bar_gave_up) return nullptr;
     auto it = g_tail_alpha_bar.find(ctl);
     if (it != g_tail_alpha_bar.end()) return it->second;
     uint64_t* p = nullptr;
@@ -613,6 +614,7 @@ static int fri_tail_rounds(std::unique_lock<std::mutex>& lk, const Fe* cur, uint
     if (aborted) {
         (void)hipStreamSynchronize(st);                        // (a kernel still waiting for a challenge that will not come times out)
         (void)hipGetLastError();
+        if (P.alpha_bar && g.fri_tail_stall < 0) g_tail_bar_gave_up = true;
         give_back(false);
         ++g_tail_fallbacks;
         return TAIL_GAVE_UP;
